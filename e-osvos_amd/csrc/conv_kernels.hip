@@ -1,0 +1,409 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X) on the fp32 matrix cores.
+//
+// All three conv passes of the fine-tuning step (forward, data gradient, weight
+// gradient) are dense fp32 contractions; on CDNA4 the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) runs at the fp32 vector peak but needs one VGPR per operand
+// per lane and leaves the VALU free for address generation and the fused epilogues, so
+// every contraction here is tiled for it: 128 x {128,64} output tile per 256-thread
+// workgroup, four 64-lane waves in a 2x2 arrangement, each wave owning a
+// 64 x {64,32} sub-tile = 2 x {2,1} accumulators of 32x32 (f32x16 per lane).
+// Operands are gathered global -> registers -> LDS (double buffered, one barrier per
+// 32-deep K step, next tile's loads in flight behind the current tile's MFMAs); LDS rows
+// are padded by one 16-byte access so the ds_read_b128 fragment reads are conflict free.
+//
+// NHWC activations make the K dimension (input channels of one filter tap) contiguous for
+// the gathered operand, so no im2col buffer is ever materialised and 1x1, 3x3, dilated
+// and strided convolutions (and their data gradients, through the fractional-stride
+// gather) are the same kernel.
+#include "kernels.h"
+
+namespace eosvos {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of tiles
+// so neighbouring tiles (which share the gathered operand) meet in one L2.  Bijective for
+// every grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m, int n) {
+  if (p.scale) v *= p.scale[n];
+  if (p.bias) v += p.bias[n];
+  if (p.res) v += p.res[(size_t)m * p.ldres + n];
+  if (p.accum) v += p.y[(size_t)m * p.ldy + n];
+  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.mask && n >= p.mask_c0) v = (p.mask[(size_t)m * p.ldmask + n] > 0.f) ? v : 0.f;
+  return v;
+}
+
+template <int BN, bool KMAJOR>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int BM = 128, BK = 32;
+  constexpr int LDA = BK + 4;
+  constexpr int LDB = KMAJOR ? BN + 4 : BK + 4;
+  constexpr int A_EL = BM * LDA;
+  constexpr int B_EL = KMAJOR ? BK * LDB : BN * LDB;
+  constexpr int STAGE = A_EL + B_EL;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int T = p.KH * p.KW;
+  const int chunks = (p.Kc + BK - 1) / BK;
+  const int ksteps = T * chunks;
+  const int nt = (p.N + BN - 1) / BN;
+  const int tiles = ((p.M + BM - 1) / BM) * nt;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = bid / tiles;
+  const int tile = bid - z * tiles;
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int ks_begin = (int)(((long)ksteps * z) / p.splits);
+  const int ks_end = (int)(((long)ksteps * (z + 1)) / p.splits);
+
+  // ---- per-thread staging assignment ------------------------------------------------
+  constexpr int AF4 = BK / 4, AROWS = 256 / AF4, APASS = BM / AROWS;   // 8, 32, 4
+  const int a_c4 = tid % AF4, a_r = tid / AF4;
+  int a_sy0[APASS], a_sx0[APASS], a_img[APASS];
+  const int up = 1 << p.upshift;
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int m = m0 + a_r + i * AROWS;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_sy0[i] = oy * p.mul + p.off0;
+      a_sx0[i] = ox * p.mul + p.off0;
+      a_img[i] = b * p.Hi * p.Wi;
+    } else {
+      a_sy0[i] = -(1 << 28);
+      a_sx0[i] = 0;
+      a_img[i] = 0;
+    }
+  }
+  constexpr int BF4 = KMAJOR ? BN / 4 : BK / 4;
+  constexpr int BROWS = 256 / BF4;
+  constexpr int BPASS = (KMAJOR ? BK : BN) / BROWS;
+  const int b_c4 = tid % BF4, b_r = tid / BF4;
+
+  float4 ra[APASS], rb[BPASS];
+
+  auto load_tiles = [&](int ks) {
+    const int tap = ks / chunks;
+    const int c0 = (ks - tap * chunks) * BK;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int dy = ky * p.kstep, dx = kx * p.kstep;
+    const bool cok = (c0 + a_c4 * 4) < p.Kc;
+    float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (KMAJOR && p.kscale && cok) ks4 = ldg4(p.kscale + c0 + a_c4 * 4);
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int sy = a_sy0[i] + dy, sx = a_sx0[i] + dx;
+      bool ok = cok && sy >= 0 && sx >= 0 && ((sy | sx) & (up - 1)) == 0;
+      const int iy = sy >> p.upshift, ix = sx >> p.upshift;
+      ok = ok && iy < p.Hi && ix < p.Wi;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = ldg4(p.x + (size_t)(a_img[i] + iy * p.Wi + ix) * p.ldx + c0 + a_c4 * 4);
+      if (KMAJOR) { v.x *= ks4.x; v.y *= ks4.y; v.z *= ks4.z; v.w *= ks4.w; }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KMAJOR) {
+        const int k = c0 + b_r + i * BROWS;
+        const int n = n0 + b_c4 * 4;
+        if (k < p.Kc && n < p.N) v = ldg4(p.w + ((size_t)k * T + tap) * p.wK + n);
+      } else {
+        const int n = n0 + b_r + i * BROWS;
+        const int k = c0 + b_c4 * 4;
+        if (n < p.N && k < p.Kc) v = ldg4(p.w + ((size_t)n * T + tap) * p.wK + k);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + A_EL;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      *reinterpret_cast<float4*>(As + (a_r + i * AROWS) * LDA + a_c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i)
+      *reinterpret_cast<float4*>(Bs + (b_r + i * BROWS) * LDB + b_c4 * 4) = rb[i];
+  };
+
+  constexpr int TN = BN / 64;   // 32-wide accumulator columns per wave
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (ks_begin < ks_end) {
+    load_tiles(ks_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int buf = (ks - ks_begin) & 1;
+    const bool more = (ks + 1) < ks_end;
+    if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
+    const float* As = smem + buf * STAGE;
+    const float* Bs = As + A_EL;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a4[2];
+      float bv[TN][4];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        a4[tm] = *reinterpret_cast<const float4*>(As + (wm * 64 + tm * 32 + r) * LDA + kk * 8 + h * 4);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if (KMAJOR) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            bv[tn][j] = Bs[(kk * 8 + h * 4 + j) * LDB + wn * (BN / 2) + tn * 32 + r];
+        } else {
+          const float4 t = *reinterpret_cast<const float4*>(Bs + (wn * (BN / 2) + tn * 32 + r) * LDB + kk * 8 + h * 4);
+          bv[tn][0] = t.x; bv[tn][1] = t.y; bv[tn][2] = t.z; bv[tn][3] = t.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          const float av = j == 0 ? a4[tm].x : j == 1 ? a4[tm].y : j == 2 ? a4[tm].z : a4[tm].w;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(av, bv[tn][j], acc[tm][tn]);
+        }
+      }
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds column n = r of 16 rows per accumulator -------------------
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + wn * (BN / 2) + tn * 32 + r;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        const float v = acc[tm][tn][e];
+        if (p.splits > 1) p.ws[((size_t)z * p.M + m) * p.N + n] = v;
+        else p.y[(size_t)m * p.ldy + n] = conv_epilogue(p, v, m, n);
+      }
+    }
+}
+
+// Sum the split-K slabs and apply the fused epilogue.  One thread per 4 output channels.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArgs p) {
+  const long total4 = (long)p.M * (p.N >> 2);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int n4 = p.N >> 2;
+    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < p.splits; ++z) {
+      const float4 t = ldg4(p.ws + ((size_t)z * p.M + m) * p.N + n);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = conv_epilogue(p, o[j], m, n + j);
+    *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int conv_pick_splits(int M, int N, int ksteps) {
+  const int bn = (N > 64) ? 128 : 64;
+  const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
+  // aim for >= ~2 workgroups per CU (512 resident slots) but keep >= 8 K-steps per split
+  int s = 1;
+  while (tiles * s < 384 && ksteps / (s * 2) >= 8 && s < 32) s *= 2;
+  return s;
+}
+
+void launch_conv(const ConvArgs& a, hipStream_t s) {
+  const int bn = (a.N > 64) ? 128 : 64;
+  const int tiles = ((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  const dim3 grid(tiles * a.splits), block(256);
+  if (a.kmajor) {
+    if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, block, 0, s, a);
+  } else {
+    if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, block, 0, s, a);
+  }
+  if (a.splits > 1) {
+    const long total4 = (long)a.M * (a.N >> 2);
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient.  GEMM with M = cout, N = cin (one filter tap per workgroup column),
+// K = pixels.  Both operands are "k-major" in memory (a pixel's channels are contiguous),
+// so tiles are staged as [pixel][channel] rows and fragments are read with ds_read_b32
+// (consecutive lanes -> consecutive channels: conflict free).
+// ---------------------------------------------------------------------------------------
+template <int BMO, int BNI>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
+  constexpr int BKP = 32;
+  constexpr int LDA = BMO + 4, LDB = BNI + 4;
+  constexpr int A_EL = BKP * LDA, B_EL = BKP * LDB, STAGE = A_EL + B_EL;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int T = p.KH * p.KW;
+  const int ct = (p.Cout + BMO - 1) / BMO, it = (p.Cin + BNI - 1) / BNI;
+  const int tiles = ct * it * T;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = bid / tiles;
+  int tile = bid - z * tiles;
+  // taps fastest: the T workgroups that share one (cout, cin) tile pair read the same G tile
+  const int tap = tile % T; tile /= T;
+  const int co0 = (tile / it) * BMO, ci0 = (tile % it) * BNI;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+  const int P = p.B * p.Ho * p.Wo;
+  const int steps = (P + BKP - 1) / BKP;
+  const int st_begin = (int)(((long)steps * z) / p.splits);
+  const int st_end = (int)(((long)steps * (z + 1)) / p.splits);
+
+  constexpr int AF4 = BMO / 4, AROWS = 256 / AF4, APASS = BKP / AROWS;
+  constexpr int BF4 = BNI / 4, BROWS = 256 / BF4, BPASS = BKP / BROWS;
+  const int a_c4 = tid % AF4, a_r = tid / AF4;
+  const int b_c4 = tid % BF4, b_r = tid / BF4;
+  const bool a_cok = (co0 + a_c4 * 4) < p.Cout;
+  const bool b_cok = (ci0 + b_c4 * 4) < p.Cin;
+
+  float4 ra[APASS], rb[BPASS];
+  auto load_tiles = [&](int st) {
+    const int p0 = st * BKP;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int px = p0 + a_r + i * AROWS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_cok && px < P) v = ldg4(p.g + (size_t)px * p.ldg + co0 + a_c4 * 4);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int px = p0 + b_r + i * BROWS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_cok && px < P) {
+        const int hw = p.Ho * p.Wo;
+        const int b = px / hw, rem = px - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
+        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+          v = ldg4(p.x + (size_t)((b * p.Hi + iy) * p.Wi + ix) * p.ldx + ci0 + b_c4 * 4);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + A_EL;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      *reinterpret_cast<float4*>(As + (a_r + i * AROWS) * LDA + a_c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i)
+      *reinterpret_cast<float4*>(Bs + (b_r + i * BROWS) * LDB + b_c4 * 4) = rb[i];
+  };
+
+  constexpr int TM = BMO / 64, TN = BNI / 64;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (st_begin < st_end) {
+    load_tiles(st_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int st = st_begin; st < st_end; ++st) {
+    const int buf = (st - st_begin) & 1;
+    const bool more = (st + 1) < st_end;
+    if (more) load_tiles(st + 1);
+    const float* As = smem + buf * STAGE;
+    const float* Bs = As + A_EL;
+#pragma unroll
+    for (int s2 = 0; s2 < BKP / 2; ++s2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) av[tm] = As[(s2 * 2 + h) * LDA + wm * (BMO / 2) + tm * 32 + r];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bv[tn] = Bs[(s2 * 2 + h) * LDB + wn * (BNI / 2) + tn * 32 + r];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(av[tm], bv[tn], acc[tm][tn]);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.ws + (size_t)z * p.Cout * T * p.Cin;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int ci = ci0 + wn * (BNI / 2) + tn * 32 + r;
+      if (ci >= p.Cin) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * (BMO / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (co < p.Cout) out[((size_t)co * T + tap) * p.Cin + ci] = acc[tm][tn][e];
+      }
+    }
+}
+
+int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
+  const int bm = Cout > 64 ? 128 : 64, bn = Cin > 64 ? 128 : 64;
+  const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
+  const int steps = (P + 31) / 32;
+  int s = 1;
+  while (tiles * s < 512 && steps / (s * 2) >= 8 && s < 256) s *= 2;
+  return s;
+}
+
+void launch_wgrad(const WgradArgs& a, hipStream_t s) {
+  const int bm = a.Cout > 64 ? 128 : 64, bn = a.Cin > 64 ? 128 : 64;
+  const int T = a.KH * a.KW;
+  const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * T;
+  const dim3 grid(tiles * a.splits), block(256);
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, block, 0, s, a);
+  else if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, block, 0, s, a);
+  else if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, block, 0, s, a);
+}
+
+}  // namespace eosvos

@@ -1,0 +1,142 @@
+// Launcher declarations of the gfx950 kernels (conv_kernels.hip, misc_kernels.hip).
+// Host code (engine.cpp) only sees these plain-C++ functions; every launcher enqueues on
+// the given stream and never synchronises or allocates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eosvos {
+
+// ---------------------------------------------------------------------------------
+// Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//   out[m][n] = epilogue( sum_{tap,k} A[m][(tap,k)] * Wt[(tap,k)][n] )
+// m runs over destination pixels (B*Ho*Wo, NHWC), A is gathered from the NHWC source at
+//   sy = oy*mul + off0 + ky*kstep   (valid iff sy % up == 0, 0 <= sy/up < Hi; same in x)
+// which expresses both the forward conv (mul=stride, off0=-pad, kstep=dil, up=1) and its
+// data gradient (mul=1, off0=pad, kstep=-dil, up=stride).
+// Weights are always the engine layout W[cout][tap][cin]:
+//   forward : n = cout (rows of W, "n-major" B operand), k = cin
+//   dgrad   : n = cin, k = cout ("k-major" B operand read straight from W; the frozen-norm
+//             scale a[cout] is applied to A's k index while staging)
+// ---------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* x;       // gather source, NHWC, channel offset already applied
+  const float* w;       // W[cout][T][cin]
+  float* y;             // destination, NHWC, channel offset already applied
+  float* ws;            // split-K workspace [splits][M][N] (used when splits > 1)
+  int B, Hi, Wi, ldx;   // source geometry, floats per source pixel
+  int Kc;               // reduction channels per tap
+  int Ho, Wo, N, ldy;   // destination geometry
+  int KH, KW;
+  int mul, off0, kstep, upshift;  // up = 1 << upshift
+  int M;                // B*Ho*Wo
+  int wN, wK;           // dims of W as stored: W[wN][T][wK]  (fwd: N,Kc ; dgrad: Kc,N)
+  int kmajor;           // 0 forward, 1 dgrad
+  const float* scale;   // per-n multiply (fwd norm a), may be null
+  const float* bias;    // per-n add (fwd norm b / conv bias), may be null
+  const float* kscale;  // per-k multiply on A (dgrad: norm a of the conv), may be null
+  const float* res;     // fwd: residual added before ReLU; NHWC with ldres
+  int ldres;
+  const float* mask;    // dgrad: out = 0 where mask[m][n] <= 0 for n >= mask_c0
+  int ldmask, mask_c0;
+  int relu;
+  int accum;            // dgrad: add the existing contents of y
+  int splits;
+};
+void launch_conv(const ConvArgs& a, hipStream_t s);
+// grid-size helper shared with the engine's workspace sizing
+int conv_pick_splits(int M, int N, int ksteps32);
+
+// Weight gradient: ws[z][cout][tap][cin] = sum over the z-th pixel chunk of
+//   G[p][cout] * X[src(p,tap)][cin]
+struct WgradArgs {
+  const float* g;       // NHWC gradient w.r.t. the (pre-ReLU, post-norm) conv output
+  const float* x;       // NHWC conv input
+  float* ws;            // [splits][Cout][T][Cin]
+  int B, Ho, Wo, ldg, Cout;
+  int Hi, Wi, ldx, Cin;
+  int KH, KW, stride, pad, dil;
+  int splits;
+};
+void launch_wgrad(const WgradArgs& a, hipStream_t s);
+int wgrad_pick_splits(int P, int Cout, int Cin, int T);
+
+// ---------------------------------------------------------------------------------
+// misc_kernels.hip
+// ---------------------------------------------------------------------------------
+void launch_nchw_to_nhwc_pad(const float* src, float* dst, int B, int C, int H, int W, int pad,
+                             hipStream_t s);
+void launch_fill(float* p, int64_t n, float v, hipStream_t s);
+// OIHW <-> engine layout O,(kh,kw),I for one tensor
+void launch_oihw_to_ohwi(const float* src, float* dst, int O, int I, int T, hipStream_t s);
+void launch_ohwi_to_oihw(const float* src, float* dst, int O, int I, int T, float alpha, int add,
+                         hipStream_t s);
+void launch_fold_norm(const float* gamma, const float* beta, const float* mean, const float* var,
+                      float eps, float* a, float* b, int64_t n, hipStream_t s);
+
+// stem: 7x7 s2 conv on the zero-padded (3 px) NHWC3 frame + affine + ReLU; and its wgrad
+void launch_stem_fwd(const float* xpad, const float* w /*[64][49][3]*/, const float* a,
+                     const float* b, float* y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
+void launch_stem_wgrad(const float* xpad, const float* g, float* ws /*[chunks][64*147]*/, int B,
+                       int H, int W, int Ho, int Wo, int chunks, hipStream_t s);
+int stem_wgrad_chunks(int B, int Ho, int Wo);
+
+void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int Ho,
+                        int Wo, hipStream_t s);
+// g_x = relu_mask(x) * scatter(g_y)   (x = the ReLU output that was pooled)
+void launch_maxpool_bwd(const float* gy, const uint8_t* idx, const float* x, float* gx, int B, int H,
+                        int W, int C, int Ho, int Wo, hipStream_t s);
+
+// Bilinear resize tables (host-built, PyTorch's index/weight rule) live in device memory:
+struct ResizeTab {
+  int in, out;
+  const int* i0;      // [out]
+  const int* i1;      // [out]
+  const float* lam;   // [out] weight of i1
+  const int* lo;      // [in]  first output index touching input i
+  const int* hi;      // [in]  last  output index touching input i (inclusive)
+};
+void launch_resize_fwd(const float* x, int ldx, float* y, int ldy, int B, int C, ResizeTab th,
+                       ResizeTab tw, hipStream_t s);
+// gx = (mask? mask>0 : 1) * resize_backward(gy)
+void launch_resize_bwd(const float* gy, int ldgy, float* gx, int ldgx, const float* mask, int ldmask,
+                       int B, int C, ResizeTab th, ResizeTab tw, hipStream_t s);
+
+// ASPP image-pooling branch
+void launch_colsum(const float* x, int ldx, float* out /*[B][C]*/, int B, int P, int C, float alpha,
+                   float* scratch, hipStream_t s);
+// y[b][n] = relu(a[n]*sum_k W[n][k]*v[b][k] + b[n])
+void launch_gemv_fwd(const float* W, const float* v, const float* a, const float* b, float* y, int B,
+                     int N, int K, hipStream_t s);
+// gv[b][k] = sum_n gp[b][n]*a[n]*W[n][k] ;  dW[n][k] = sum_b gp[b][n]*v[b][k]
+void launch_gemv_bwd(const float* W, const float* v, const float* gp, const float* a, float* gv,
+                     float* dW, int B, int N, int K, hipStream_t s);
+void launch_bcast_pixels(const float* v /*[B][C]*/, float* y, int ldy, int B, int P, int C, float alpha,
+                         hipStream_t s);
+
+// classifier 1x1 conv with Cout = 1 (+bias) and its backward
+void launch_last_fwd(const float* x, const float* w, const float* bias, float* y, int64_t P, int C,
+                     hipStream_t s);
+void launch_last_bwd(const float* x, const float* w, const float* g, float* gx, float* ws_dw,
+                     int64_t P, int C, int chunks, hipStream_t s);
+int last_bwd_chunks(int64_t P);
+
+// BCE-with-logits mean + gradient; loss accumulates deterministically through `partial`
+void launch_bce(const float* logits, const float* gt, float* dlogits, float* loss, float* partial,
+                int64_t n, hipStream_t s);
+void launch_sigmoid(const float* x, float* y, int64_t n, hipStream_t s);
+void launch_merge_labels(const float* probs, int n_obj, int64_t n_pix, uint8_t* labels, hipStream_t s);
+
+// theta' = theta - lr[cout]*g, g = rowscale[cout] * sum_z ws[z][...]; optional gsum += g; g_out = g
+void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, const float* rowscale,
+                       const float* lr, float* gsum, float* gout, int64_t rowlen, int64_t n,
+                       hipStream_t s);
+// g_lr[c] += -sum_row(gsum*G) ;  (G itself is exported by launch_ohwi_to_oihw with add=1)
+void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen,
+                         hipStream_t s);
+void launch_radam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float wd,
+                  float beta1, float beta2, float eps, float step_size, int use_denom,
+                  float grad_scale, float grad_clip, hipStream_t s);
+void launch_clamp(float* p, int64_t n, float lo, float hi, hipStream_t s);
+
+}  // namespace eosvos

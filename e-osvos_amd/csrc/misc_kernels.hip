@@ -1,0 +1,654 @@
+// HBM-bound and small kernels of the e-OSVOS inner loop for gfx950: layout changes, the
+// 7x7 stem, max-pool, bilinear resize (+ gather-form backward), the ASPP image-pooling
+// branch, the 1-channel classifier conv, fused BCE loss + gradient, the fused
+// per-neuron-lr SGD update (split-K slab reduction included), meta-gradient reduction,
+// RAdam.  64-lane waves, 16-byte accesses where the layout allows, deterministic
+// (atomic-free) reductions everywhere so fine-tuning trajectories are reproducible.
+#include "kernels.h"
+
+namespace eosvos {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over a 256-thread block; result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* sh /*>=4 floats*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+static inline int grid_for(long n, int per_block, int cap = 4096) {
+  long b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+#define GRID_STRIDE(i, n) \
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ---- layout ---------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                        int C, int H, int W, int pad) {
+  const long n = (long)B * H * W;
+  const int Wp = W + 2 * pad, Hp = H + 2 * pad;
+  GRID_STRIDE(i, n) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int b = (int)(i / ((long)W * H));
+    float* d = dst + (((long)b * Hp + y + pad) * Wp + x + pad) * C;
+    for (int c = 0; c < C; ++c) d[c] = src[(((long)b * C + c) * H + y) * W + x];
+  }
+}
+void launch_nchw_to_nhwc_pad(const float* src, float* dst, int B, int C, int H, int W, int pad,
+                             hipStream_t s) {
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, B, C, H,
+                     W, pad);
+}
+
+__global__ void fill_kernel(float* p, long n, float v) { GRID_STRIDE(i, n) p[i] = v; }
+void launch_fill(float* p, int64_t n, float v, hipStream_t s) {
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, (long)n, v);
+}
+
+__global__ void oihw_to_ohwi_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I,
+                                    int T) {
+  const long n = (long)O * I * T;
+  GRID_STRIDE(e, n) {   // e indexes dst [o][t][i]
+    const int i = (int)(e % I);
+    const int t = (int)((e / I) % T);
+    const long o = e / ((long)I * T);
+    dst[e] = src[(o * I + i) * T + t];
+  }
+}
+void launch_oihw_to_ohwi(const float* src, float* dst, int O, int I, int T, hipStream_t s) {
+  const long n = (long)O * I * T;
+  hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, O, I, T);
+}
+__global__ void ohwi_to_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I,
+                                    int T, float alpha, int add) {
+  const long n = (long)O * I * T;
+  GRID_STRIDE(e, n) {   // e indexes dst [o][i][t]
+    const int t = (int)(e % T);
+    const int i = (int)((e / T) % I);
+    const long o = e / ((long)I * T);
+    const float v = alpha * src[(o * T + t) * I + i];
+    dst[e] = add ? dst[e] + v : v;
+  }
+}
+void launch_ohwi_to_oihw(const float* src, float* dst, int O, int I, int T, float alpha, int add,
+                         hipStream_t s) {
+  const long n = (long)O * I * T;
+  hipLaunchKernelGGL(ohwi_to_oihw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, O, I, T, alpha,
+                     add);
+}
+
+__global__ void fold_norm_kernel(const float* g, const float* be, const float* mu, const float* var,
+                                 float eps, float* a, float* b, long n) {
+  GRID_STRIDE(i, n) {
+    const float s = g[i] / sqrtf(var[i] + eps);
+    a[i] = s;
+    b[i] = be[i] - mu[i] * s;
+  }
+}
+void launch_fold_norm(const float* gamma, const float* beta, const float* mean, const float* var,
+                      float eps, float* a, float* b, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(fold_norm_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, gamma, beta, mean, var, eps,
+                     a, b, (long)n);
+}
+
+// ---- stem: 7x7 stride-2 conv, 3 -> 64, on the 3-pixel zero-padded NHWC3 frame ------------
+// One thread per output pixel, 64 accumulators; the 147x64 weight panel sits in LDS as
+// [k][cout] and is read with broadcast ds_read_b128 (every lane the same address).
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ xpad,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ a,
+                                                        const float* __restrict__ bb, float* __restrict__ y,
+                                                        int B, int H, int W, int Ho, int Wo) {
+  __shared__ __attribute__((aligned(16))) float wl[147 * 64];
+  for (int i = threadIdx.x; i < 147 * 64; i += 256) {
+    const int k = i >> 6, co = i & 63;
+    wl[i] = w[co * 147 + k];
+  }
+  __syncthreads();
+  const long P = (long)B * Ho * Wo;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+  const int Wp = W + 6, Hp = H + 6;
+  float acc[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  for (int ky = 0; ky < 7; ++ky) {
+    const float* xr = xpad + (((long)b * Hp + oy * 2 + ky) * Wp + ox * 2) * 3;
+#pragma unroll
+    for (int j = 0; j < 21; ++j) {
+      const float xv = xr[j];
+      const float4* wr = reinterpret_cast<const float4*>(wl + (ky * 21 + j) * 64);
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 wv = wr[c4];
+        acc[c4 * 4 + 0] = fmaf(xv, wv.x, acc[c4 * 4 + 0]);
+        acc[c4 * 4 + 1] = fmaf(xv, wv.y, acc[c4 * 4 + 1]);
+        acc[c4 * 4 + 2] = fmaf(xv, wv.z, acc[c4 * 4 + 2]);
+        acc[c4 * 4 + 3] = fmaf(xv, wv.w, acc[c4 * 4 + 3]);
+      }
+    }
+  }
+  float4* out = reinterpret_cast<float4*>(y + pix * 64);
+#pragma unroll
+  for (int c4 = 0; c4 < 16; ++c4) {
+    float4 v;
+    v.x = fmaxf(acc[c4 * 4 + 0] * a[c4 * 4 + 0] + bb[c4 * 4 + 0], 0.f);
+    v.y = fmaxf(acc[c4 * 4 + 1] * a[c4 * 4 + 1] + bb[c4 * 4 + 1], 0.f);
+    v.z = fmaxf(acc[c4 * 4 + 2] * a[c4 * 4 + 2] + bb[c4 * 4 + 2], 0.f);
+    v.w = fmaxf(acc[c4 * 4 + 3] * a[c4 * 4 + 3] + bb[c4 * 4 + 3], 0.f);
+    out[c4] = v;
+  }
+}
+void launch_stem_fwd(const float* xpad, const float* w, const float* a, const float* b, float* y, int B,
+                     int H, int W, int Ho, int Wo, hipStream_t s) {
+  const long P = (long)B * Ho * Wo;
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, xpad, w, a, b, y,
+                     B, H, W, Ho, Wo);
+}
+
+// Stem weight gradient: each workgroup reduces one chunk of output pixels into a
+// [64][147] slab.  Thread t owns cout = t & 63 and 37 consecutive k of wave-uniform group
+// t >> 6, so the patch values are wave-uniform (scalar) operands.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ xpad,
+                                                          const float* __restrict__ g, float* __restrict__ ws,
+                                                          int B, int H, int W, int Ho, int Wo, int chunks) {
+  const long P = (long)B * Ho * Wo;
+  const long per = (P + chunks - 1) / chunks;
+  const long p0 = (long)blockIdx.x * per;
+  long p1 = p0 + per;
+  if (p1 > P) p1 = P;
+  const int co = threadIdx.x & 63;
+  const int kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kbase = kg * 37;
+  const int Wp = W + 6, Hp = H + 6;
+  int koff[37];
+#pragma unroll
+  for (int i = 0; i < 37; ++i) {
+    int k = kbase + i;
+    if (k > 146) k = 146;
+    koff[i] = (k / 21) * Wp * 3 + (k % 21);
+  }
+  float acc[37];
+#pragma unroll
+  for (int i = 0; i < 37; ++i) acc[i] = 0.f;
+  for (long p = p0; p < p1; ++p) {
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
+    const float gv = g[p * 64 + co];
+    const float* xr = xpad + (((long)b * Hp + oy * 2) * Wp + ox * 2) * 3;
+#pragma unroll
+    for (int i = 0; i < 37; ++i) acc[i] = fmaf(gv, xr[koff[i]], acc[i]);
+  }
+  float* out = ws + (long)blockIdx.x * (64 * 147) + co * 147;
+#pragma unroll
+  for (int i = 0; i < 37; ++i)
+    if (kbase + i < 147) out[kbase + i] = acc[i];
+}
+int stem_wgrad_chunks(int B, int Ho, int Wo) {
+  const long P = (long)B * Ho * Wo;
+  long c = P / 128;
+  if (c < 1) c = 1;
+  if (c > 512) c = 512;
+  return (int)c;
+}
+void launch_stem_wgrad(const float* xpad, const float* g, float* ws, int B, int H, int W, int Ho, int Wo,
+                       int chunks, hipStream_t s) {
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(chunks), dim3(256), 0, s, xpad, g, ws, B, H, W, Ho, Wo, chunks);
+}
+
+// ---- max-pool 3x3 s2 p1 ------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long n = (long)B * Ho * Wo * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long pix = e / C4;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned char mi[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * H + iy) * W + ix) * C + c4 * 4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (first || vv[j] > m[j]) { m[j] = vv[j]; mi[j] = (unsigned char)(ky * 3 + kx); }
+        first = false;
+      }
+    }
+    *reinterpret_cast<float4*>(y + pix * C + c4 * 4) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<uchar4*>(idx + pix * C + c4 * 4) = make_uchar4(mi[0], mi[1], mi[2], mi[3]);
+  }
+}
+void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int Ho, int Wo,
+                        hipStream_t s) {
+  const long n = (long)B * Ho * Wo * (C >> 2);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, y, idx, B, H, W, C, Ho,
+                     Wo);
+}
+__global__ void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                   const float* __restrict__ x, float* __restrict__ gx, int B, int H, int W,
+                                   int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long n = (long)B * H * W * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long pix = e / C4;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;      // ceil((iy-1)/2) .. floor((iy+1)/2)
+    const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= Ho) continue;
+      const int ky = iy + 1 - 2 * oy;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= Wo) continue;
+        const int kx = ix + 1 - 2 * ox;
+        const unsigned char k = (unsigned char)(ky * 3 + kx);
+        const long o = (((long)b * Ho + oy) * Wo + ox) * C + c4 * 4;
+        const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o);
+        const float4 g = *reinterpret_cast<const float4*>(gy + o);
+        if (id.x == k) s[0] += g.x;
+        if (id.y == k) s[1] += g.y;
+        if (id.z == k) s[2] += g.z;
+        if (id.w == k) s[3] += g.w;
+      }
+    }
+    const float4 xv = *reinterpret_cast<const float4*>(x + pix * C + c4 * 4);
+    *reinterpret_cast<float4*>(gx + pix * C + c4 * 4) =
+        make_float4(xv.x > 0.f ? s[0] : 0.f, xv.y > 0.f ? s[1] : 0.f, xv.z > 0.f ? s[2] : 0.f,
+                    xv.w > 0.f ? s[3] : 0.f);
+  }
+}
+void launch_maxpool_bwd(const float* gy, const uint8_t* idx, const float* x, float* gx, int B, int H, int W,
+                        int C, int Ho, int Wo, hipStream_t s) {
+  const long n = (long)B * H * W * (C >> 2);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, gy, idx, x, gx, B, H, W, C,
+                     Ho, Wo);
+}
+
+// ---- bilinear resize ----------------------------------------------------------------------
+template <int V>
+__global__ void resize_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B,
+                                  int C, ResizeTab th, ResizeTab tw) {
+  const int CV = C / V;
+  const long n = (long)B * th.out * tw.out * CV;
+  GRID_STRIDE(e, n) {
+    const int cv = (int)(e % CV);
+    const long pix = e / CV;
+    const int ox = (int)(pix % tw.out), oy = (int)((pix / tw.out) % th.out);
+    const int b = (int)(pix / ((long)tw.out * th.out));
+    const int y0 = th.i0[oy], y1 = th.i1[oy], x0 = tw.i0[ox], x1 = tw.i1[ox];
+    const float ly = th.lam[oy], lx = tw.lam[ox];
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = x + (long)b * th.in * tw.in * ldx + cv * V;
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float v00 = base[((long)y0 * tw.in + x0) * ldx + j], v01 = base[((long)y0 * tw.in + x1) * ldx + j];
+      const float v10 = base[((long)y1 * tw.in + x0) * ldx + j], v11 = base[((long)y1 * tw.in + x1) * ldx + j];
+      o[j] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+    float* d = y + pix * ldy + cv * V;
+#pragma unroll
+    for (int j = 0; j < V; ++j) d[j] = o[j];
+  }
+}
+void launch_resize_fwd(const float* x, int ldx, float* y, int ldy, int B, int C, ResizeTab th, ResizeTab tw,
+                       hipStream_t s) {
+  if ((C & 3) == 0) {
+    const long n = (long)B * th.out * tw.out * (C / 4);
+    hipLaunchKernelGGL((resize_fwd_kernel<4>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, y, ldy,
+                       B, C, th, tw);
+  } else {
+    const long n = (long)B * th.out * tw.out * C;
+    hipLaunchKernelGGL((resize_fwd_kernel<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, y, ldy,
+                       B, C, th, tw);
+  }
+}
+template <int V>
+__global__ void resize_bwd_kernel(const float* __restrict__ gy, int ldgy, float* __restrict__ gx, int ldgx,
+                                  const float* __restrict__ mask, int ldmask, int B, int C, ResizeTab th,
+                                  ResizeTab tw) {
+  const int CV = C / V;
+  const long n = (long)B * th.in * tw.in * CV;
+  GRID_STRIDE(e, n) {
+    const int cv = (int)(e % CV);
+    const long pix = e / CV;
+    const int ix = (int)(pix % tw.in), iy = (int)((pix / tw.in) % th.in);
+    const int b = (int)(pix / ((long)tw.in * th.in));
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    const float* gb = gy + (long)b * th.out * tw.out * ldgy + cv * V;
+    for (int dy = th.lo[iy]; dy <= th.hi[iy]; ++dy) {
+      const float ly = th.lam[dy];
+      const float wy = (th.i0[dy] == iy ? 1.f - ly : 0.f) + (th.i1[dy] == iy ? ly : 0.f);
+      for (int dx = tw.lo[ix]; dx <= tw.hi[ix]; ++dx) {
+        const float lx = tw.lam[dx];
+        const float wx = (tw.i0[dx] == ix ? 1.f - lx : 0.f) + (tw.i1[dx] == ix ? lx : 0.f);
+        const float wgt = wy * wx;
+        const float* gp = gb + ((long)dy * tw.out + dx) * ldgy;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fmaf(wgt, gp[j], acc[j]);
+      }
+    }
+    float* d = gx + pix * ldgx + cv * V;
+    if (mask) {
+      const float* mk = mask + pix * ldmask + cv * V;
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = mk[j] > 0.f ? acc[j] : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = acc[j];
+    }
+  }
+}
+void launch_resize_bwd(const float* gy, int ldgy, float* gx, int ldgx, const float* mask, int ldmask, int B,
+                       int C, ResizeTab th, ResizeTab tw, hipStream_t s) {
+  if ((C & 3) == 0) {
+    const long n = (long)B * th.in * tw.in * (C / 4);
+    hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, gy, ldgy, gx,
+                       ldgx, mask, ldmask, B, C, th, tw);
+  } else {
+    const long n = (long)B * th.in * tw.in * C;
+    hipLaunchKernelGGL((resize_bwd_kernel<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, gy, ldgy, gx,
+                       ldgx, mask, ldmask, B, C, th, tw);
+  }
+}
+
+// ---- ASPP image pooling branch ---------------------------------------------------------------
+// scratch[b][chunk][c] = sum over the chunk's pixels ; out[b][c] = alpha * sum over chunks
+#define COLSUM_CHUNKS 32
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int ldx, float* __restrict__ scratch, int P,
+                                      int C) {
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int per = (P + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+  const int p0 = ch * per;
+  int p1 = p0 + per;
+  if (p1 > P) p1 = P;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += x[((long)b * P + p) * ldx + c];
+    scratch[((long)b * COLSUM_CHUNKS + ch) * C + c] = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ scratch, float* __restrict__ out, int B, int C,
+                                    float alpha) {
+  const long n = (long)B * C;
+  GRID_STRIDE(e, n) {
+    const int c = (int)(e % C), b = (int)(e / C);
+    float s = 0.f;
+    for (int ch = 0; ch < COLSUM_CHUNKS; ++ch) s += scratch[((long)b * COLSUM_CHUNKS + ch) * C + c];
+    out[e] = alpha * s;
+  }
+}
+void launch_colsum(const float* x, int ldx, float* out, int B, int P, int C, float alpha, float* scratch,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(COLSUM_CHUNKS, B), dim3(256), 0, s, x, ldx, scratch, P, C);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(grid_for((long)B * C, 256)), dim3(256), 0, s, scratch, out, B, C,
+                     alpha);
+}
+// one wave per (b, n)
+__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                        const float* __restrict__ a, const float* __restrict__ bb,
+                                                        float* __restrict__ y, int B, int N, int K) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= B * N) return;
+  const int lane = threadIdx.x & 63;
+  const int b = wid / N, n = wid - b * N;
+  float s = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 w4 = *reinterpret_cast<const float4*>(W + (long)n * K + k);
+    const float4 v4 = *reinterpret_cast<const float4*>(v + (long)b * K + k);
+    s = fmaf(w4.x, v4.x, s); s = fmaf(w4.y, v4.y, s); s = fmaf(w4.z, v4.z, s); s = fmaf(w4.w, v4.w, s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) y[wid] = fmaxf(s * a[n] + bb[n], 0.f);
+}
+void launch_gemv_fwd(const float* W, const float* v, const float* a, const float* b, float* y, int B, int N,
+                     int K, hipStream_t s) {
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, s, W, v, a, b, y, B, N, K);
+}
+__global__ void gemv_bwd_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                const float* __restrict__ gp, const float* __restrict__ a,
+                                float* __restrict__ gv, float* __restrict__ dW, int B, int N, int K) {
+  const long nv = (long)B * K, nw = (long)N * K;
+  GRID_STRIDE(e, nv + nw) {
+    if (e < nv) {
+      const int k = (int)(e % K), b = (int)(e / K);
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s = fmaf(gp[b * N + n] * a[n], W[(long)n * K + k], s);
+      gv[e] = s;
+    } else {
+      const long f = e - nv;
+      const int k = (int)(f % K), n = (int)(f / K);
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s = fmaf(gp[b * N + n], v[(long)b * K + k], s);
+      dW[f] = s;
+    }
+  }
+}
+void launch_gemv_bwd(const float* W, const float* v, const float* gp, const float* a, float* gv, float* dW,
+                     int B, int N, int K, hipStream_t s) {
+  const long n = (long)B * K + (long)N * K;
+  hipLaunchKernelGGL(gemv_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, W, v, gp, a, gv, dW, B, N, K);
+}
+__global__ void bcast_pixels_kernel(const float* __restrict__ v, float* __restrict__ y, int ldy, int B, int P,
+                                    int C, float alpha) {
+  const int C4 = C >> 2;
+  const long n = (long)B * P * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long pix = e / C4;
+    const int b = (int)(pix / P);
+    float4 t = *reinterpret_cast<const float4*>(v + (long)b * C + c4 * 4);
+    t.x *= alpha; t.y *= alpha; t.z *= alpha; t.w *= alpha;
+    *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = t;
+  }
+}
+void launch_bcast_pixels(const float* v, float* y, int ldy, int B, int P, int C, float alpha, hipStream_t s) {
+  const long n = (long)B * P * (C >> 2);
+  hipLaunchKernelGGL(bcast_pixels_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, v, y, ldy, B, P, C, alpha);
+}
+
+// ---- classifier conv (Cout = 1, bias) ------------------------------------------------------------
+__global__ __launch_bounds__(256) void last_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        long P, int C) {
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * 4;
+  for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += nw) {
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + p * C + c);
+      const float4 wv = *reinterpret_cast<const float4*>(w + c);
+      s = fmaf(xv.x, wv.x, s); s = fmaf(xv.y, wv.y, s); s = fmaf(xv.z, wv.z, s); s = fmaf(xv.w, wv.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[p] = s + bias[0];
+  }
+}
+void launch_last_fwd(const float* x, const float* w, const float* bias, float* y, int64_t P, int C,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(last_fwd_kernel, dim3(grid_for(P, 4, 4096)), dim3(256), 0, s, x, w, bias, y, (long)P, C);
+}
+// gx[p][c] = g[p]*w[c]*(x>0);  ws_dw[chunk][c] = sum_p g[p]*x[p][c];  ws_dw[chunk][C] = sum_p g[p]
+__global__ __launch_bounds__(256) void last_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ g, float* __restrict__ gx,
+                                                        float* __restrict__ ws, long P, int C, int chunks) {
+  const long per = (P + chunks - 1) / chunks;
+  const long p0 = (long)blockIdx.x * per;
+  long p1 = p0 + per;
+  if (p1 > P) p1 = P;
+  __shared__ float sh[4];
+  float gsum = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float wc = w[c];
+    float s = 0.f;
+    for (long p = p0; p < p1; ++p) {
+      const float gv = g[p];
+      const float xv = x[p * C + c];
+      s = fmaf(gv, xv, s);
+      gx[p * C + c] = xv > 0.f ? gv * wc : 0.f;
+    }
+    ws[(long)blockIdx.x * (C + 1) + c] = s;
+  }
+  for (long p = p0 + threadIdx.x; p < p1; p += 256) gsum += g[p];
+  gsum = block_sum_256(gsum, sh);
+  if (threadIdx.x == 0) ws[(long)blockIdx.x * (C + 1) + C] = gsum;
+}
+int last_bwd_chunks(int64_t P) {
+  long c = P / 64;
+  if (c < 1) c = 1;
+  if (c > 1024) c = 1024;
+  return (int)c;
+}
+void launch_last_bwd(const float* x, const float* w, const float* g, float* gx, float* ws_dw, int64_t P, int C,
+                     int chunks, hipStream_t s) {
+  hipLaunchKernelGGL(last_bwd_kernel, dim3(chunks), dim3(256), 0, s, x, w, g, gx, ws_dw, (long)P, C, chunks);
+}
+
+// ---- BCE with logits (mean) + gradient -------------------------------------------------------------
+#define BCE_BLOCKS 1024
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                   float* __restrict__ dx, float* __restrict__ partial, long n,
+                                                   float inv_n) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float xv = x[i], tv = t[i];
+    const float e = expf(-fabsf(xv));
+    s += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
+    const float sig = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[i] = (sig - tv) * inv_n;
+  }
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void bce_final_kernel(const float* __restrict__ partial, float* __restrict__ loss,
+                                                         int nb, float inv_n) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+void launch_bce(const float* logits, const float* gt, float* dlogits, float* loss, float* partial, int64_t n,
+                hipStream_t s) {
+  const int nb = grid_for(n, 256, BCE_BLOCKS);
+  const float inv_n = 1.0f / (float)n;
+  hipLaunchKernelGGL(bce_kernel, dim3(nb), dim3(256), 0, s, logits, gt, dlogits, partial, (long)n, inv_n);
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, s, partial, loss, nb, inv_n);
+}
+__global__ void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  GRID_STRIDE(i, n) {
+    const float xv = x[i];
+    const float e = expf(-fabsf(xv));
+    y[i] = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+  }
+}
+void launch_sigmoid(const float* x, float* y, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, y, (long)n);
+}
+__global__ void merge_labels_kernel(const float* __restrict__ probs, int n_obj, long n_pix,
+                                    uint8_t* __restrict__ labels) {
+  GRID_STRIDE(i, n_pix) {
+    float best = probs[i];
+    int arg = 0;
+    for (int o = 1; o < n_obj; ++o) {
+      const float v = probs[(long)o * n_pix + i];
+      if (v > best) { best = v; arg = o; }
+    }
+    labels[i] = best < 0.5f ? 0 : (uint8_t)(arg + 1);
+  }
+}
+void launch_merge_labels(const float* probs, int n_obj, int64_t n_pix, uint8_t* labels, hipStream_t s) {
+  hipLaunchKernelGGL(merge_labels_kernel, dim3(grid_for(n_pix, 256)), dim3(256), 0, s, probs, n_obj,
+                     (long)n_pix, labels);
+}
+
+// ---- fused slab reduction + per-neuron-lr SGD ----------------------------------------------------------
+__global__ void sgd_update_kernel(float* __restrict__ w, const float* __restrict__ ws, int splits, long slab,
+                                  const float* __restrict__ rowscale, const float* __restrict__ lr,
+                                  float* __restrict__ gsum, float* __restrict__ gout, long rowlen, long n) {
+  GRID_STRIDE(e, n) {
+    float g = 0.f;
+    for (int z = 0; z < splits; ++z) g += ws[(long)z * slab + e];
+    const long row = e / rowlen;
+    if (rowscale) g *= rowscale[row];
+    w[e] = w[e] - lr[row] * g;
+    if (gsum) gsum[e] += g;
+    if (gout) gout[e] = g;
+  }
+}
+void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, const float* rowscale,
+                       const float* lr, float* gsum, float* gout, int64_t rowlen, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(sgd_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, ws, splits, (long)slab,
+                     rowscale, lr, gsum, gout, (long)rowlen, (long)n);
+}
+// one block per row: glr[row] += -sum_e gsum[row][e] * G[row][e]
+__global__ __launch_bounds__(256) void meta_lr_grad_kernel(const float* __restrict__ gsum,
+                                                            const float* __restrict__ G, float* __restrict__ glr,
+                                                            long rowlen) {
+  __shared__ float sh[4];
+  const long base = (long)blockIdx.x * rowlen;
+  float s = 0.f;
+  for (long e = threadIdx.x; e < rowlen; e += 256) s = fmaf(gsum[base + e], G[base + e], s);
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) glr[blockIdx.x] -= s;
+}
+void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(meta_lr_grad_kernel, dim3(rows), dim3(256), 0, s, gsum, G, glr, (long)rowlen);
+}
+
+// ---- RAdam (radam.py:28-94) -----------------------------------------------------------------------------
+__global__ void radam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float wd, float beta1, float beta2,
+                             float eps, float step_size, int use_denom, float grad_scale, float grad_clip) {
+  GRID_STRIDE(i, n) {
+    float gr = g[i] * grad_scale;
+    if (grad_clip > 0.f) gr = fminf(fmaxf(gr, -grad_clip), grad_clip);
+    const float vv = v[i] * beta2 + (1.f - beta2) * gr * gr;
+    const float mm = m[i] * beta1 + (1.f - beta1) * gr;
+    v[i] = vv;
+    m[i] = mm;
+    float pv = p[i];
+    if (wd != 0.f) pv += (-wd * lr) * pv;
+    if (use_denom) pv += (-step_size * lr) * (mm / (sqrtf(vv) + eps));
+    else pv += (-step_size * lr) * mm;
+    p[i] = pv;
+  }
+}
+void launch_radam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float wd, float beta1,
+                  float beta2, float eps, float step_size, int use_denom, float grad_scale, float grad_clip,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(radam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, (long)n, lr, wd, beta1,
+                     beta2, eps, step_size, use_denom, grad_scale, grad_clip);
+}
+__global__ void clamp_kernel(float* p, long n, float lo, float hi) {
+  GRID_STRIDE(i, n) p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+void launch_clamp(float* p, int64_t n, float lo, float hi, hipStream_t s) {
+  hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, (long)n, lo, hi);
+}
+
+}  // namespace eosvos

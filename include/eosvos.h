@@ -1,0 +1,153 @@
+/*
+ * eosvos.h -- C-ABI of the MI355X-native e-OSVOS inner-loop engine (libeosvos.so).
+ *
+ * The reference (dvl-tum/e-osvos) is pure Python with no FFI layer of its own; the
+ * seam this library replaces is the Python duck-typed boundary between the
+ * orchestration loops (src/util/evaluate.py, src/util/meta_run.py, src/train_meta.py)
+ * and src/networks + src/meta_optim.  Each entry point below names the reference
+ * interface it stands in for (file:line under /root/reference).  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc / torch-ROCm `tensor.data_ptr()`)
+ *    unless the parameter name ends in `_host`;
+ *  - tensors crossing the boundary use the reference's layouts: images NCHW fp32,
+ *    parameters OIHW fp32 flattened in `named_parameters()` order, per-neuron learning
+ *    rates one float per output channel in the same tensor order;
+ *  - every call returns 0 on success, non-zero on error; `eosvos_last_error()` gives
+ *    the message.  No exceptions or aborts cross the ABI;
+ *  - an engine is bound to one HIP device + stream and is not thread-safe (one engine
+ *    per process/rank, as the reference has one model per process,
+ *    src/util/helper_func.py:499-512);
+ *  - work is enqueued on the engine's stream; calls that return host scalars
+ *    synchronise that stream.
+ */
+#ifndef EOSVOS_H
+#define EOSVOS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eosvos_engine eosvos_engine;
+
+#define EOSVOS_ARCH_RESNET50 50
+#define EOSVOS_ARCH_RESNET101 101
+#define EOSVOS_NORM_BN_FROZEN 0 /* BatchNorm in eval mode, frozen affine (deeplabv3plus.py:148-155,259-265) */
+
+/* ---- library / topology (host only, no GPU needed) ------------------------------ */
+const char* eosvos_version(void);
+const char* eosvos_last_error(void);
+
+/* Number of convolutions of DeepLabV3+ on `arch` (63 for ResNet-50); -1 on bad arch.
+ * Replaces: module enumeration of networks/deeplabv3plus.py:104-155. */
+int eosvos_num_convs(int arch);
+/* Fill info[9] = {cin, cout, k, stride, dilation, padding, has_norm, has_bias, param_offset}
+ * for conv `idx` in the reference's named_parameters() order.  param_offset is the
+ * offset (in floats) of its OIHW weight inside the flat parameter vector (a bias, if
+ * any, follows its weight). */
+int eosvos_conv_info(int arch, int idx, int64_t* info);
+/* Totals: trainable scalars (40 289 729 for R50), per-neuron lr scalars (28 658),
+ * norm channels (sum of Cout over the 62 norm layers). */
+int64_t eosvos_param_count(int arch);
+int64_t eosvos_lr_count(int arch);
+int64_t eosvos_norm_count(int arch);
+
+/* ---- engine life cycle ----------------------------------------------------------- */
+/* Replaces: init_parent_model() + model.to(device) (helper_func.py:339-385).
+ * `stream` is a hipStream_t (NULL = the device's default stream). */
+int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int width,
+                  int max_batch, int device_id, void* stream);
+int eosvos_destroy(eosvos_engine* e);
+int eosvos_synchronize(eosvos_engine* e);
+
+/* ---- state ------------------------------------------------------------------------ */
+/* Learned model initialisation (`model_init_*`, meta_optim.py:71-78): flat OIHW. */
+int eosvos_set_init(eosvos_engine* e, const float* flat_params);
+/* Learned per-neuron learning rates (`log_init_lr_*`, meta_optim.py:46-67), flat. */
+int eosvos_set_lr(eosvos_engine* e, const float* flat_lr);
+/* Frozen BatchNorm statistics + affine, each `eosvos_norm_count` floats, norm layers in
+ * module order; folded on device to a*x+b with eps (networks/deeplabv3plus.py:259-265). */
+int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta,
+                    const float* running_mean, const float* running_var, float eps);
+/* theta <- learned init.  Replaces MetaOptimizer.reset() (meta_optim.py:144-155). */
+int eosvos_reset(eosvos_engine* e);
+/* Current fine-tuned parameters, flat OIHW (model.state_dict() of the trainables). */
+int eosvos_get_params(eosvos_engine* e, float* flat_params_out);
+/* Overwrite the current parameters (model.load_state_dict, evaluate.py:200-203). */
+int eosvos_set_params(eosvos_engine* e, const float* flat_params);
+/* FIRST_STEP reset of online adaptation (evaluate.py:200-205,283-287). */
+int eosvos_snapshot_params(eosvos_engine* e);
+int eosvos_restore_params(eosvos_engine* e);
+
+/* ---- fine-tuning hot loop (evaluate.py:220-274) ----------------------------------- */
+/* logits = model(images)[-1]  (deeplabv3plus.py:282-301); keeps activations for backward.
+ * images: B x 3 x H x W, logits_out: B x 1 x H x W (may be NULL). */
+int eosvos_forward(eosvos_engine* e, const float* images, int batch, float* logits_out);
+/* Fused BCE-with-logits (mean over B*H*W, helper_func.py:32-37) of the last forward and
+ * its gradient.  loss_out: one device float (may be NULL). */
+int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss_out);
+/* autograd.grad + theta <- theta - lr (.) grad (meta_optim.py:177-214,
+ * meta_model.py:78-80), using the gradient left by eosvos_loss_bce.
+ * accumulate != 0 additionally adds the step's gradients into the task's sum_k g_k
+ * (meta-training, see eosvos_meta_grad). */
+int eosvos_backward_step(eosvos_engine* e, int accumulate);
+/* forward + loss + backward + update in one call; loss_host may be NULL (no sync). */
+int eosvos_finetune_step(eosvos_engine* e, const float* images, const float* masks, int batch,
+                         int accumulate, float* loss_host);
+/* Gradient of the last backward w.r.t. the trainables, flat OIHW (for parity tests). */
+int eosvos_get_grads(eosvos_engine* e, float* flat_grads_out);
+
+/* ---- inference (helper_func.py:131-142, evaluate.py:322-326) ----------------------- */
+/* probs = sigmoid(model(images)[-1]); probs_out B x 1 x H x W. */
+int eosvos_infer(eosvos_engine* e, const float* images, int batch, float* probs_out);
+/* labels[p] = 0 if max_o probs[o][p] < 0.5 else argmax_o + 1.  probs: n_obj x H*W. */
+int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t n_pix,
+                        uint8_t* labels_out);
+
+/* ---- meta-training task (meta_run.py:109-238) --------------------------------------- */
+/* theta <- init and sum_k g_k <- 0 (meta_optim.reset(); zero_grad(), meta_run.py:121-122). */
+int eosvos_meta_task_begin(eosvos_engine* e);
+/* Meta frame forward/backward at theta_K and closed-form first-order BPTT
+ * (bptt_loss.backward(), meta_run.py:214):  ADDS into flat_meta_grad
+ *   [0, lr_count)            d/d lr[c]   = -sum_{cin,kh,kw} (sum_k g_k) * G
+ *   [lr_count, +param_count) d/d init    = G                        (OIHW)
+ * which is the `named_parameters()` order of MetaOptimizer (log_init_lr_* then
+ * model_init_*).  meta_loss_host may be NULL. */
+int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, int batch,
+                     float* flat_meta_grad, float* meta_loss_host);
+
+/* ---- outer step (train_meta.py:361-373, radam.py:28-94, meta_optim.py:116-133) ------ */
+/* One RAdam step on n contiguous floats that share (lr, weight_decay):
+ * grad <- clamp(grad * grad_scale, +-grad_clip) (grad_clip <= 0: no clip); `step` is the
+ * 1-based step count; N_sma/step_size are computed on the host exactly as radam.py:62-79. */
+int eosvos_radam_step(eosvos_engine* e, float* param, const float* grad, float* exp_avg,
+                      float* exp_avg_sq, int64_t n, float lr, float weight_decay, float beta1,
+                      float beta2, float eps, int step, float grad_scale, float grad_clip);
+/* param <- clamp(param, lo, hi)  (clamp_init_lr; pass hi = +inf for max_lr None). */
+int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi);
+
+/* ---- instrumentation ----------------------------------------------------------------- */
+/* Time `reps` launches of the dominant conv kernel of the last finetune step's shape
+ * (decoder.last_conv.0 forward) with HIP events on the engine stream; returns the
+ * average milliseconds in *ms_host and the algorithmic FLOPs per launch in *flops_host. */
+int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host,
+                           double* flops_host);
+/* Low-level op entry used by the kernel parity tests: a single NHWC convolution
+ * y = relu?(a*conv(x,w)+b (+res)); w is OIHW; all dense tensors; stride/dil/pad as torch. */
+int eosvos_test_conv(eosvos_engine* e, const float* x_nhwc, const float* w_oihw,
+                     const float* scale, const float* bias, const float* res_nhwc, int relu,
+                     int B, int H, int W, int Cin, int Cout, int k, int stride, int dil, int pad,
+                     float* y_nhwc);
+/* dx = conv_dgrad(g), dw = conv_wgrad(g, x) for the same geometry (no norm scale). */
+int eosvos_test_conv_bwd(eosvos_engine* e, const float* x_nhwc, const float* w_oihw,
+                         const float* g_nhwc, int B, int H, int W, int Cin, int Cout, int k,
+                         int stride, int dil, int pad, float* dx_nhwc, float* dw_oihw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EOSVOS_H */

@@ -1,0 +1,178 @@
+"""torch-CPU restatement of the meta-optimizer side of the hot path.
+
+  * `finetune_step`  : `MetaOptimizer.step` (`src/meta_optim/meta_optim.py:177-214`)
+                       + `MetaModel.apply_param_groups_step` (`meta_model.py:78-80`)
+                       + `detach_param_groups` (`meta_model.py:62-65`), NEURON lrs
+                       (`meta_optim.py:46-67`): theta <- theta - lr[cout] * grad.
+  * `finetune`       : the evaluation fine-tune loop, `src/util/evaluate.py:220-274`
+                       (early stopping off, `cfgs/meta.yaml:97-99`).
+  * `meta_task`      : one task of `src/util/meta_run.py:109-238` with first-order
+                       gradients (`second_order_gradients: False`, `cfgs/meta.yaml:40`)
+                       and `bptt_epochs == num_epochs.train`; uses the closed form of
+                       SURVEY.md section 3.3 (theta_K = theta_0 - lr * sum_k g_k):
+                         d/d init = G,  d/d lr[c] = -sum_{cin,kh,kw}(sum_k g_k * G).
+  * `radam_step`     : `RAdam.step`, `src/util/radam.py:28-94`, per-tensor groups as
+                       built at `src/train_meta.py:110-127`.
+  * `outer_step`     : average / clip / RAdam / clamp, `src/train_meta.py:361-373` and
+                       `MetaOptimizer.clamp_init_lr` (`meta_optim.py:116-133`).
+  * `merge_labels`   : multi-object merge, `src/util/evaluate.py:322-326`.
+  * `online_adapt_schedule` : frame-range / propagated-frame index logic of
+                       `src/util/evaluate.py:140-193,227-253`.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+"""
+import math
+
+import torch
+
+from . import deeplab
+from .topology import trainable_names
+
+
+def loss_and_grads(P, x, y, encoder='resnet50', norm='bn'):
+    names = trainable_names(encoder)
+    Q = dict(P)
+    leaves = []
+    for n in names:
+        t = P[n].detach().clone().requires_grad_(True)
+        Q[n] = t
+        leaves.append(t)
+    logits = deeplab.forward(Q, x, encoder, norm)
+    loss = deeplab.bce_loss(logits, y)
+    grads = torch.autograd.grad(loss, leaves)
+    return loss.detach(), list(grads), logits.detach()
+
+
+def finetune_step(P, lrs, x, y, encoder='resnet50', norm='bn'):
+    """One inner step.  Returns (loss, grads, new P).  `lrs`: list aligned with
+    trainable_names(), each broadcastable against its tensor ((Cout,1,1,1) or (1,))."""
+    names = trainable_names(encoder)
+    loss, grads, _ = loss_and_grads(P, x, y, encoder, norm)
+    Pn = dict(P)
+    for n, lr, g in zip(names, lrs, grads):
+        Pn[n] = P[n] - g * lr
+    return loss, grads, Pn
+
+
+def finetune(P, lrs, batches, encoder='resnet50', norm='bn'):
+    """`batches`: iterable of (x, y).  Returns (loss list, final P)."""
+    losses = []
+    for x, y in batches:
+        loss, _, P = finetune_step(P, lrs, x, y, encoder, norm)
+        losses.append(float(loss))
+    return losses, P
+
+
+def meta_task(P0, lrs, train_batches, meta_batch, encoder='resnet50', norm='bn'):
+    """K inner steps + one meta frame.  Returns dict(meta_loss, train_losses,
+    g_init (list), g_lr (list shaped like lrs))."""
+    names = trainable_names(encoder)
+    P = P0
+    gsum = None
+    train_losses = []
+    for x, y in train_batches:
+        loss, grads, P = finetune_step(P, lrs, x, y, encoder, norm)
+        train_losses.append(float(loss))
+        gsum = [g.clone() for g in grads] if gsum is None else [a + g for a, g in zip(gsum, grads)]
+    xm, ym = meta_batch
+    meta_loss, G, _ = loss_and_grads(P, xm, ym, encoder, norm)
+    g_lr = []
+    for n, s, g, lr in zip(names, gsum, G, lrs):
+        prod = -(s * g)
+        if prod.dim() > 1:
+            prod = prod.sum(dim=tuple(range(1, prod.dim())), keepdim=True)
+        g_lr.append(prod.reshape(lr.shape))
+    return dict(meta_loss=float(meta_loss), train_losses=train_losses, g_init=G, g_lr=g_lr)
+
+
+def radam_scalars(step, beta1=0.9, beta2=0.999):
+    """(N_sma, step_size) of `radam.py:62-79` (degenerated_to_sgd=True)."""
+    beta2_t = beta2 ** step
+    n_sma_max = 2 / (1 - beta2) - 1
+    n_sma = n_sma_max - 2 * step * beta2_t / (1 - beta2_t)
+    if n_sma >= 5:
+        step_size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma
+                              * n_sma_max / (n_sma_max - 2)) / (1 - beta1 ** step)
+    else:
+        step_size = 1.0 / (1 - beta1 ** step)
+    return n_sma, step_size
+
+
+def radam_step(p, grad, state, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
+    """In-place on `p`; `state` = dict(step, exp_avg, exp_avg_sq) (created on first use)."""
+    if not state:
+        state['step'] = 0
+        state['exp_avg'] = torch.zeros_like(p)
+        state['exp_avg_sq'] = torch.zeros_like(p)
+    beta1, beta2 = betas
+    state['exp_avg_sq'].mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    state['exp_avg'].mul_(beta1).add_(grad, alpha=1 - beta1)
+    state['step'] += 1
+    n_sma, step_size = radam_scalars(state['step'], beta1, beta2)
+    if weight_decay != 0:
+        p.add_(p, alpha=-weight_decay * lr)
+    if n_sma >= 5:
+        denom = state['exp_avg_sq'].sqrt().add_(eps)
+        p.addcdiv_(state['exp_avg'], denom, value=-step_size * lr)
+    else:
+        p.add_(state['exp_avg'], alpha=-step_size * lr)
+    return p
+
+
+def outer_step(lr_params, init_params, lr_grads, init_grads, states, meta_batch_size,
+               model_init_lr=1e-5, log_init_lr_lr=1e-5, model_init_weight_decay=1e-3,
+               grad_clip=None, max_lr=None):
+    """`states`: list of per-tensor dicts, lr tensors first then init tensors (the
+    `named_parameters()` order of MetaOptimizer, `meta_optim.py:65-66,78`)."""
+    k = 0
+    for p, g in zip(lr_params, lr_grads):
+        g = g / meta_batch_size
+        if grad_clip is not None:
+            g = g.clamp(-grad_clip, grad_clip)
+        radam_step(p, g, states[k], log_init_lr_lr, 0.0)
+        k += 1
+    for p, g in zip(init_params, init_grads):
+        g = g / meta_batch_size
+        if grad_clip is not None:
+            g = g.clamp(-grad_clip, grad_clip)
+        radam_step(p, g, states[k], model_init_lr, model_init_weight_decay)
+        k += 1
+    for p in lr_params:  # clamp_init_lr, use_log_init_lr False: [0, max_lr]
+        p.clamp_(0, max_lr)
+
+
+def merge_labels(probs):
+    """probs: (n_obj, H, W) -> (H, W) uint8 labels.  `evaluate.py:322-326`."""
+    bg = probs.max(dim=0)[0].lt(0.5)
+    lab = probs.argmax(dim=0) + 1
+    lab[bg] = 0
+    return lab.to(torch.uint8)
+
+
+def online_adapt_schedule(num_frames, train_frame_id, step, train_batch_size):
+    """Rounds of the evaluation loop.  Each round: dict(eval_min, eval_max,
+    propagate_frames) -- `propagate_frames` are the earlier frames whose predicted
+    masks (if non-empty) join the first frame in the adaptation batch."""
+    rounds = []
+    if step:
+        meta_iter = range(train_frame_id + 1, num_frames, step)
+        s = step
+    else:
+        meta_iter = [None]
+        s = num_frames
+    eval_max = None
+    for r, _ in enumerate(meta_iter):
+        if r == 0:
+            eval_min = train_frame_id + 1
+            eval_max = eval_min
+            prop = []
+        else:
+            eval_min = eval_max
+            n_prop = min(step, train_batch_size)
+            start = step - n_prop + 1
+            prop = [eval_min - j for j in range(start, step)]
+        eval_max = min(eval_max + s, num_frames)
+        rounds.append(dict(eval_min=eval_min, eval_max=eval_max, propagate_frames=prop))
+        if eval_max == num_frames:
+            break
+    return rounds
