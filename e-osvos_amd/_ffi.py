@@ -1,0 +1,94 @@
+"""ctypes binding of libeosvos.so (include/eosvos.h).
+
+`cffi` is not installed in the target image, so the thin shim is `ctypes` (stdlib).
+There is deliberately no fallback: if the library is missing or a call fails, an
+exception is raised -- a silent CPU/eager path would void every parity claim.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeosvos.so')
+
+c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+_E = ctypes.c_void_p
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    'eosvos_version': (ctypes.c_char_p, []),
+    'eosvos_last_error': (ctypes.c_char_p, []),
+    'eosvos_num_convs': (ctypes.c_int, [ctypes.c_int]),
+    'eosvos_conv_info': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    'eosvos_param_count': (ctypes.c_int64, [ctypes.c_int]),
+    'eosvos_lr_count': (ctypes.c_int64, [ctypes.c_int]),
+    'eosvos_norm_count': (ctypes.c_int64, [ctypes.c_int]),
+    'eosvos_create': (ctypes.c_int, [ctypes.POINTER(_E), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'eosvos_destroy': (ctypes.c_int, [_E]),
+    'eosvos_synchronize': (ctypes.c_int, [_E]),
+    'eosvos_set_init': (ctypes.c_int, [_E, c_float_p]),
+    'eosvos_set_lr': (ctypes.c_int, [_E, c_float_p]),
+    'eosvos_set_norm': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float]),
+    'eosvos_reset': (ctypes.c_int, [_E]),
+    'eosvos_get_params': (ctypes.c_int, [_E, c_float_p]),
+    'eosvos_set_params': (ctypes.c_int, [_E, c_float_p]),
+    'eosvos_snapshot_params': (ctypes.c_int, [_E]),
+    'eosvos_restore_params': (ctypes.c_int, [_E]),
+    'eosvos_forward': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, c_float_p]),
+    'eosvos_loss_bce': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, c_float_p]),
+    'eosvos_backward_step': (ctypes.c_int, [_E, ctypes.c_int]),
+    'eosvos_finetune_step': (ctypes.c_int, [_E, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_float)]),
+    'eosvos_keep_grads': (ctypes.c_int, [_E, ctypes.c_int]),
+    'eosvos_get_grads': (ctypes.c_int, [_E, c_float_p]),
+    'eosvos_infer': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, c_float_p]),
+    'eosvos_merge_labels': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]),
+    'eosvos_meta_task_begin': (ctypes.c_int, [_E]),
+    'eosvos_meta_grad': (ctypes.c_int, [_E, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                        ctypes.POINTER(ctypes.c_float)]),
+    'eosvos_radam_step': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int64,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_float, ctypes.c_int, ctypes.c_float, ctypes.c_float]),
+    'eosvos_clamp': (ctypes.c_int, [_E, c_float_p, ctypes.c_int64, ctypes.c_float, ctypes.c_float]),
+    'eosvos_time_hot_kernel': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                              ctypes.POINTER(ctypes.c_double)]),
+    'eosvos_debug_tensor': (ctypes.c_int, [_E, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p),
+                                           ctypes.POINTER(ctypes.c_int64)]),
+    'eosvos_test_conv': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                        ctypes.c_int] + [ctypes.c_int] * 9 + [c_float_p]),
+    'eosvos_test_conv_bwd': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 9 +
+                             [c_float_p, c_float_p]),
+}
+
+_lib = None
+
+
+class EosvosError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libeosvos.so (once) and declare every prototype of include/eosvos.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EosvosError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc):
+    if rc != 0:
+        raise EosvosError(load().eosvos_last_error().decode() or f'eosvos call failed ({rc})')

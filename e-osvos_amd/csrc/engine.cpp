@@ -1,0 +1,870 @@
+// Host side of libeosvos.so: the DeepLabV3+/ResNet graph of the e-OSVOS inner loop as an
+// explicit forward / backward / fused-update program over the gfx950 kernels of
+// conv_kernels.hip and misc_kernels.hip, behind the C-ABI of include/eosvos.h.
+//
+// Reference semantics (files under /root/reference/src):
+//   forward   networks/deeplabv3plus.py:32-53,84-93,282-301 (+ torchvision ResNet/ASPP)
+//   norm      BatchNorm in eval mode with frozen affine (deeplabv3plus.py:148-155,259-265)
+//             == per-channel a*x+b, fused into every conv epilogue
+//   loss      helper_func.py:32-37 (BCEWithLogits, mean)
+//   step      meta_optim/meta_optim.py:177-214 + meta_model.py:78-80
+//   meta-grad util/meta_run.py:109-238 (first-order BPTT, closed form of SURVEY 3.3)
+//   outer     train_meta.py:361-373, util/radam.py:28-94
+//
+// Data layout in HBM: activations NHWC fp32 (channels contiguous = GEMM K of the gathered
+// operand), weights W[cout][kh*kw][cin] per conv inside one flat arena that keeps the
+// reference's tensor order and offsets (only the two inner axes are permuted), concat
+// buffers are written in place by their producers (channel-slice views), gradients of
+// activations hold dL/d(pre-ReLU) so the ReLU mask and the frozen-norm scale never need
+// their own pass.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/eosvos.h"
+#include "kernels.h"
+
+using namespace eosvos;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+#define HIPOK(expr)                                                                      \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + std::to_string(__LINE__)); \
+  } while (0)
+
+namespace {
+
+struct ConvL {
+  int cin, cout, k, stride, dil, pad;
+  bool norm, bias;
+  int64_t poff;   // offset of the weight in the flat parameter arena (bias follows)
+  int64_t lroff;  // offset of its per-neuron lr (bias lr follows)
+  int64_t noff;   // offset of its norm channels
+  int T() const { return k * k; }
+  int64_t wsize() const { return (int64_t)cout * cin * k * k; }
+};
+struct Block {
+  int c1, c2, c3, ds;  // conv indices, ds = -1 if none
+};
+struct Topo {
+  std::vector<ConvL> convs;
+  std::vector<Block> blocks;
+  int layer1_last_block;  // index of the block whose output is the low-level feature
+  int aspp[4], pool, project, dec1, dec_a, dec_b, last;
+  int64_t nparam, nlr, nnorm;
+};
+
+bool build_topo(int arch, Topo& t) {
+  int nb[4];
+  if (arch == EOSVOS_ARCH_RESNET50) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; }
+  else if (arch == EOSVOS_ARCH_RESNET101) { nb[0] = 3; nb[1] = 4; nb[2] = 23; nb[3] = 3; }
+  else return false;
+  t.convs.clear();
+  t.blocks.clear();
+  auto add = [&](int cin, int cout, int k, int s, int d, int p, bool norm, bool bias) {
+    ConvL c{cin, cout, k, s, d, p, norm, bias, 0, 0, 0};
+    t.convs.push_back(c);
+    return (int)t.convs.size() - 1;
+  };
+  add(3, 64, 7, 2, 1, 3, true, false);
+  int inpl = 64;
+  const int widths[4] = {64, 128, 256, 512};
+  for (int li = 0; li < 4; ++li) {
+    const int w = widths[li];
+    for (int bi = 0; bi < nb[li]; ++bi) {
+      const bool first = bi == 0;
+      const int s1 = (li == 2 && first) ? 2 : 1;   // reference surgery: layer3[0].conv1 stride 2
+      const int s2 = (li == 1 && first) ? 2 : 1;   // layer2[0].conv2 stride 2
+      int d = 1;
+      if (li == 3) d = bi == 0 ? 2 : (bi == nb[3] - 1 ? 8 : 4);
+      Block b;
+      b.c1 = add(inpl, w, 1, s1, 1, 0, true, false);
+      b.c2 = add(w, w, 3, s2, d, d, true, false);
+      b.c3 = add(w, 4 * w, 1, 1, 1, 0, true, false);
+      b.ds = first ? add(inpl, 4 * w, 1, s1 * s2, 1, 0, true, false) : -1;
+      t.blocks.push_back(b);
+      inpl = 4 * w;
+    }
+    if (li == 0) t.layer1_last_block = (int)t.blocks.size() - 1;
+  }
+  t.aspp[0] = add(2048, 256, 1, 1, 1, 0, true, false);
+  const int rates[3] = {6, 12, 18};
+  for (int i = 0; i < 3; ++i) t.aspp[i + 1] = add(2048, 256, 3, 1, rates[i], rates[i], true, false);
+  t.pool = add(2048, 256, 1, 1, 1, 0, true, false);
+  t.project = add(1280, 256, 1, 1, 1, 0, true, false);
+  t.dec1 = add(256, 48, 1, 1, 1, 0, true, false);
+  t.dec_a = add(304, 256, 3, 1, 1, 1, true, false);
+  t.dec_b = add(256, 256, 3, 1, 1, 1, true, false);
+  t.last = add(256, 1, 1, 1, 1, 0, false, true);
+  int64_t po = 0, lo = 0, no = 0;
+  for (auto& c : t.convs) {
+    c.poff = po; c.lroff = lo; c.noff = no;
+    po += c.wsize() + (c.bias ? c.cout : 0);
+    lo += c.cout + (c.bias ? 1 : 0);
+    if (c.norm) no += c.cout;
+  }
+  t.nparam = po; t.nlr = lo; t.nnorm = no;
+  return true;
+}
+
+inline int conv_out(int i, int k, int s, int d, int p) { return (i + 2 * p - d * (k - 1) - 1) / s + 1; }
+
+struct HostResize {
+  std::vector<int> i0, i1, lo, hi;
+  std::vector<float> lam;
+};
+// PyTorch upsample_bilinear2d source-index rule (ATen UpSample.h area_pixel_compute_*), fp32.
+HostResize make_resize(int in, int out, bool align_corners) {
+  HostResize r;
+  r.i0.resize(out); r.i1.resize(out); r.lam.resize(out);
+  r.lo.assign(in, out); r.hi.assign(in, -1);
+  float scale;
+  if (align_corners) scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  else scale = (float)in / (float)out;
+  for (int d = 0; d < out; ++d) {
+    float src;
+    if (align_corners) src = scale * (float)d;
+    else {
+      src = scale * ((float)d + 0.5f) - 0.5f;
+      if (src < 0.f) src = 0.f;
+    }
+    int i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    const int i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    r.i0[d] = i0; r.i1[d] = i1; r.lam[d] = src - (float)i0;
+    for (int i : {i0, i1}) {
+      if (d < r.lo[i]) r.lo[i] = d;
+      if (d > r.hi[i]) r.hi[i] = d;
+    }
+  }
+  return r;
+}
+
+}  // namespace
+
+struct eosvos_engine {
+  Topo t;
+  int arch, H, W, maxB, dev;
+  hipStream_t s;
+  int h2, w2, h4, w4, h8, w8, h16, w16;
+  std::vector<void*> allocs;
+
+  // parameters / state
+  float *Wp = nullptr, *Winit = nullptr, *Wsnap = nullptr, *lr = nullptr, *na = nullptr, *nb = nullptr;
+  float *gsum = nullptr, *gout = nullptr, *stage = nullptr;
+  bool keep_grads = false;
+  // activations
+  float *xpad, *c1, *p1;
+  uint8_t* p1idx;
+  struct BlkBuf { float *t1, *t2, *out, *dsb, *g_t1, *g_t2, *g_out; int Hi, Wi, Ho, Wo, Hm, Wm; const float* xin; float* g_xin; int Cin; };
+  std::vector<BlkBuf> bb;
+  float *g_c1, *g_p1;
+  float *cat, *g_cat, *vec, *gvec, *poolout, *gp, *colscratch, *proj, *g_proj;
+  float *dcat, *g_dcat, *d1, *g_d1, *d2, *g_d2, *lowlog, *g_low, *logits, *dlogits, *loss_dev, *bce_partial;
+  float *ws_conv, *ws_wg;
+  int64_t ws_conv_n = 0, ws_wg_n = 0;
+  ResizeTab up_h, up_w, fin_h, fin_w;  // decoder upsample (align_corners) and final resize
+  int lastB = 0;
+  bool have_loss_grad = false;
+
+  float* falloc(int64_t n) {
+    void* p = nullptr;
+    if (n < 1) n = 1;
+    if (hipMalloc(&p, (size_t)n * sizeof(float)) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    return (float*)p;
+  }
+  float* W_(int ci) { return Wp + t.convs[ci].poff; }
+  const float* A_(int ci) const { return t.convs[ci].norm ? na + t.convs[ci].noff : nullptr; }
+  const float* B_(int ci) const { return t.convs[ci].norm ? nb + t.convs[ci].noff : nullptr; }
+};
+
+namespace {
+
+int upload_resize(eosvos_engine* e, const HostResize& h, int in, int out, ResizeTab& tab) {
+  int* ib = (int*)e->falloc(2 * out + 2 * in);
+  float* lam = e->falloc(out);
+  if (!ib || !lam) return fail("hipMalloc resize table");
+  HIPOK(hipMemcpy(ib, h.i0.data(), out * 4, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(ib + out, h.i1.data(), out * 4, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(ib + 2 * out, h.lo.data(), in * 4, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(ib + 2 * out + in, h.hi.data(), in * 4, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(lam, h.lam.data(), out * 4, hipMemcpyHostToDevice));
+  tab.in = in; tab.out = out; tab.i0 = ib; tab.i1 = ib + out; tab.lo = ib + 2 * out; tab.hi = ib + 2 * out + in;
+  tab.lam = lam;
+  return 0;
+}
+
+// ---- conv helpers -----------------------------------------------------------------------------
+int ksteps_of(int T, int kc) { return T * ((kc + 31) / 32); }
+
+void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi, float* y, int ldy, int B,
+              const float* res, int ldres, bool relu) {
+  const ConvL& c = e->t.convs[ci];
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = e->W_(ci); a.y = y; a.ws = e->ws_conv;
+  a.B = B; a.Hi = Hi; a.Wi = Wi; a.ldx = ldx; a.Kc = c.cin;
+  a.Ho = conv_out(Hi, c.k, c.stride, c.dil, c.pad); a.Wo = conv_out(Wi, c.k, c.stride, c.dil, c.pad);
+  a.N = c.cout; a.ldy = ldy; a.KH = a.KW = c.k;
+  a.mul = c.stride; a.off0 = -c.pad; a.kstep = c.dil; a.upshift = 0;
+  a.M = B * a.Ho * a.Wo; a.wN = c.cout; a.wK = c.cin; a.kmajor = 0;
+  a.scale = e->A_(ci); a.bias = e->B_(ci);
+  a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
+  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(c.T(), c.cin));
+  launch_conv(a, e->s);
+}
+// gx[B,Hin,Win,cin] (ld ldgx) (+)= dgrad of conv ci applied to g[B,Ho,Wo,cout] (ld ldg)
+void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int Win, float* gx, int ldgx, int B,
+                bool accum, const float* mask, int ldmask, int mask_c0, const float* add = nullptr, int ldadd = 0) {
+  const ConvL& c = e->t.convs[ci];
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = g; a.w = e->W_(ci); a.y = gx; a.ws = e->ws_conv;
+  a.B = B; a.Hi = conv_out(Hin, c.k, c.stride, c.dil, c.pad); a.Wi = conv_out(Win, c.k, c.stride, c.dil, c.pad);
+  a.ldx = ldg; a.Kc = c.cout;
+  a.Ho = Hin; a.Wo = Win; a.N = c.cin; a.ldy = ldgx; a.KH = a.KW = c.k;
+  a.mul = 1; a.off0 = c.pad; a.kstep = -c.dil; a.upshift = c.stride == 2 ? 1 : 0;
+  a.M = B * Hin * Win; a.wN = c.cout; a.wK = c.cin; a.kmajor = 1;
+  a.kscale = e->A_(ci);
+  a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
+  a.res = add; a.ldres = ldadd;
+  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(c.T(), c.cout));
+  launch_conv(a, e->s);
+}
+// slabs of dW into ws_wg; returns the number of slabs
+int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x, int ldx, int Hin, int Win, int B) {
+  const ConvL& c = e->t.convs[ci];
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.x = x; a.ws = e->ws_wg;
+  a.B = B; a.Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad); a.Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
+  a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
+  a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
+  a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T());
+  launch_wgrad(a, e->s);
+  return a.splits;
+}
+// reduce slabs, scale by the frozen-norm a[cout], (optionally) theta <- theta - lr*g
+void apply_update(eosvos_engine* e, int ci, int splits, bool update, bool accumulate) {
+  const ConvL& c = e->t.convs[ci];
+  const int64_t n = c.wsize() + (c.bias ? c.cout : 0);
+  launch_sgd_update(e->W_(ci), e->ws_wg, splits, n, e->A_(ci), update ? e->lr + c.lroff : nullptr,
+                    accumulate ? e->gsum + c.poff : nullptr, e->keep_grads ? e->gout + c.poff : nullptr,
+                    (int64_t)c.T() * c.cin, n, e->s);
+}
+
+int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+}  // namespace
+
+extern "C" {
+
+const char* eosvos_version(void) { return "eosvos-mi355x 0.1 (gfx950, fp32 MFMA implicit-GEMM)"; }
+const char* eosvos_last_error(void) { return g_err.c_str(); }
+
+int eosvos_num_convs(int arch) {
+  Topo t;
+  if (!build_topo(arch, t)) return -1;
+  return (int)t.convs.size();
+}
+int eosvos_conv_info(int arch, int idx, int64_t* info) {
+  Topo t;
+  if (!build_topo(arch, t)) return fail("bad arch");
+  if (idx < 0 || idx >= (int)t.convs.size() || !info) return fail("bad conv index");
+  const ConvL& c = t.convs[idx];
+  info[0] = c.cin; info[1] = c.cout; info[2] = c.k; info[3] = c.stride; info[4] = c.dil; info[5] = c.pad;
+  info[6] = c.norm; info[7] = c.bias; info[8] = c.poff;
+  return 0;
+}
+int64_t eosvos_param_count(int arch) { Topo t; return build_topo(arch, t) ? t.nparam : -1; }
+int64_t eosvos_lr_count(int arch) { Topo t; return build_topo(arch, t) ? t.nlr : -1; }
+int64_t eosvos_norm_count(int arch) { Topo t; return build_topo(arch, t) ? t.nnorm : -1; }
+
+int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int width, int max_batch,
+                  int device_id, void* stream) {
+  if (!out) return fail("null out");
+  if (norm_mode != EOSVOS_NORM_BN_FROZEN) return fail("only EOSVOS_NORM_BN_FROZEN is implemented");
+  if (height < 32 || width < 32 || max_batch < 1) return fail("bad geometry");
+  eosvos_engine* e = new eosvos_engine();
+  if (!build_topo(arch, e->t)) { delete e; return fail("bad arch"); }
+  e->arch = arch; e->H = height; e->W = width; e->maxB = max_batch; e->dev = device_id;
+  e->s = (hipStream_t)stream;
+  HIPOK(hipSetDevice(device_id));
+  const Topo& t = e->t;
+  const int B = max_batch, H = height, W = width;
+  e->h2 = conv_out(H, 7, 2, 1, 3); e->w2 = conv_out(W, 7, 2, 1, 3);
+  e->h4 = conv_out(e->h2, 3, 2, 1, 1); e->w4 = conv_out(e->w2, 3, 2, 1, 1);
+  e->h8 = conv_out(e->h4, 3, 2, 1, 1); e->w8 = conv_out(e->w4, 3, 2, 1, 1);
+  e->h16 = conv_out(e->h8, 1, 2, 1, 0); e->w16 = conv_out(e->w8, 1, 2, 1, 0);
+
+#define ALLOC(ptr, n)                                                  \
+  do {                                                                 \
+    ptr = e->falloc((int64_t)(n));                                     \
+    if (!ptr) { eosvos_destroy(e); return fail("hipMalloc " #ptr); }  \
+  } while (0)
+  ALLOC(e->Wp, t.nparam); ALLOC(e->Winit, t.nparam); ALLOC(e->Wsnap, t.nparam);
+  ALLOC(e->gout, t.nparam); ALLOC(e->stage, t.nparam);
+  ALLOC(e->lr, t.nlr); ALLOC(e->na, t.nnorm); ALLOC(e->nb, t.nnorm);
+  ALLOC(e->xpad, (int64_t)B * (H + 6) * (W + 6) * 3);
+  HIPOK(hipMemset(e->xpad, 0, (size_t)B * (H + 6) * (W + 6) * 3 * 4));
+  HIPOK(hipMemset(e->Wp, 0, (size_t)t.nparam * 4));
+  HIPOK(hipMemset(e->Winit, 0, (size_t)t.nparam * 4));
+  HIPOK(hipMemset(e->lr, 0, (size_t)t.nlr * 4));
+  const int64_t n2 = (int64_t)B * e->h2 * e->w2, n4 = (int64_t)B * e->h4 * e->w4;
+  const int64_t n16 = (int64_t)B * e->h16 * e->w16;
+  ALLOC(e->c1, n2 * 64); ALLOC(e->g_c1, n2 * 64);
+  ALLOC(e->p1, n4 * 64); ALLOC(e->g_p1, n4 * 64);
+  { float* t8; ALLOC(t8, (n4 * 64 + 3) / 4); e->p1idx = (uint8_t*)t8; }
+
+  int64_t wsc = 1, wsw = 1;
+  auto track = [&](int ci, int Hin, int Win) {
+    const ConvL& c = t.convs[ci];
+    const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
+    const int Mf = B * Ho * Wo, Md = B * Hin * Win;
+    wsc = max64(wsc, (int64_t)conv_pick_splits(Mf, c.cout, ksteps_of(c.T(), c.cin)) * Mf * c.cout);
+    wsc = max64(wsc, (int64_t)conv_pick_splits(Md, c.cin, ksteps_of(c.T(), c.cout)) * Md * c.cin);
+    wsw = max64(wsw, (int64_t)wgrad_pick_splits(Mf, c.cout, c.cin, c.T()) * c.wsize());
+  };
+  // bottleneck buffers
+  int Hc = e->h4, Wc = e->w4, Cc = 64;
+  const float* xin = e->p1;
+  float* gxin = e->g_p1;
+  for (size_t i = 0; i < t.blocks.size(); ++i) {
+    const Block& b = t.blocks[i];
+    const ConvL &c1 = t.convs[b.c1], &c2 = t.convs[b.c2], &c3 = t.convs[b.c3];
+    eosvos_engine::BlkBuf bf;
+    bf.Hi = Hc; bf.Wi = Wc; bf.Cin = Cc; bf.xin = xin; bf.g_xin = gxin;
+    bf.Hm = conv_out(Hc, 1, c1.stride, 1, 0); bf.Wm = conv_out(Wc, 1, c1.stride, 1, 0);
+    bf.Ho = conv_out(bf.Hm, 3, c2.stride, c2.dil, c2.pad); bf.Wo = conv_out(bf.Wm, 3, c2.stride, c2.dil, c2.pad);
+    const int64_t nm = (int64_t)B * bf.Hm * bf.Wm, no = (int64_t)B * bf.Ho * bf.Wo;
+    ALLOC(bf.t1, nm * c1.cout); ALLOC(bf.g_t1, nm * c1.cout);
+    ALLOC(bf.t2, no * c2.cout); ALLOC(bf.g_t2, no * c2.cout);
+    ALLOC(bf.out, no * c3.cout); ALLOC(bf.g_out, no * c3.cout);
+    bf.dsb = nullptr;
+    if (b.ds >= 0) ALLOC(bf.dsb, no * c3.cout);
+    track(b.c1, Hc, Wc); track(b.c2, bf.Hm, bf.Wm); track(b.c3, bf.Ho, bf.Wo);
+    if (b.ds >= 0) track(b.ds, Hc, Wc);
+    e->bb.push_back(bf);
+    Hc = bf.Ho; Wc = bf.Wo; Cc = c3.cout; xin = bf.out; gxin = bf.g_out;
+  }
+  if (Hc != e->h16 || Wc != e->w16) { eosvos_destroy(e); return fail("internal: stride-16 geometry mismatch"); }
+  ALLOC(e->cat, n16 * 1280); ALLOC(e->g_cat, n16 * 1280);
+  ALLOC(e->vec, (int64_t)B * 2048); ALLOC(e->gvec, (int64_t)B * 2048);
+  ALLOC(e->poolout, (int64_t)B * 256); ALLOC(e->gp, (int64_t)B * 256);
+  ALLOC(e->colscratch, (int64_t)B * 32 * 2048);
+  ALLOC(e->proj, n16 * 256); ALLOC(e->g_proj, n16 * 256);
+  ALLOC(e->dcat, n4 * 304); ALLOC(e->g_dcat, n4 * 304);
+  ALLOC(e->d1, n4 * 256); ALLOC(e->g_d1, n4 * 256);
+  ALLOC(e->d2, n4 * 256); ALLOC(e->g_d2, n4 * 256);
+  ALLOC(e->lowlog, n4); ALLOC(e->g_low, n4);
+  ALLOC(e->logits, (int64_t)B * H * W); ALLOC(e->dlogits, (int64_t)B * H * W);
+  ALLOC(e->loss_dev, 4); ALLOC(e->bce_partial, 1024);
+  for (int i = 0; i < 4; ++i) track(t.aspp[i], e->h16, e->w16);
+  track(t.project, e->h16, e->w16); track(t.dec1, e->h4, e->w4);
+  track(t.dec_a, e->h4, e->w4); track(t.dec_b, e->h4, e->w4);
+  wsw = max64(wsw, (int64_t)stem_wgrad_chunks(B, e->h2, e->w2) * 64 * 147);
+  wsw = max64(wsw, (int64_t)last_bwd_chunks(n4) * 257);
+  wsw = max64(wsw, (int64_t)256 * 2048);
+  ALLOC(e->ws_conv, wsc); ALLOC(e->ws_wg, wsw);
+  e->ws_conv_n = wsc; e->ws_wg_n = wsw;
+#undef ALLOC
+  if (upload_resize(e, make_resize(e->h16, e->h4, true), e->h16, e->h4, e->up_h)) { eosvos_destroy(e); return 1; }
+  if (upload_resize(e, make_resize(e->w16, e->w4, true), e->w16, e->w4, e->up_w)) { eosvos_destroy(e); return 1; }
+  if (upload_resize(e, make_resize(e->h4, H, false), e->h4, H, e->fin_h)) { eosvos_destroy(e); return 1; }
+  if (upload_resize(e, make_resize(e->w4, W, false), e->w4, W, e->fin_w)) { eosvos_destroy(e); return 1; }
+  // identity norm until eosvos_set_norm
+  launch_fill(e->na, t.nnorm, 1.f, e->s);
+  launch_fill(e->nb, t.nnorm, 0.f, e->s);
+  HIPOK(hipStreamSynchronize(e->s));
+  *out = e;
+  return 0;
+}
+
+int eosvos_destroy(eosvos_engine* e) {
+  if (!e) return 0;
+  hipStreamSynchronize(e->s);
+  for (void* p : e->allocs) hipFree(p);
+  delete e;
+  return 0;
+}
+int eosvos_synchronize(eosvos_engine* e) {
+  if (!e) return fail("null engine");
+  HIPOK(hipStreamSynchronize(e->s));
+  return 0;
+}
+
+// flat OIHW -> engine arena (dst), through the permute kernel per conv
+static void import_params(eosvos_engine* e, const float* flat, float* dst) {
+  for (const ConvL& c : e->t.convs) {
+    launch_oihw_to_ohwi(flat + c.poff, dst + c.poff, c.cout, c.cin, c.T(), e->s);
+    if (c.bias) hipMemcpyAsync(dst + c.poff + c.wsize(), flat + c.poff + c.wsize(), c.cout * 4, hipMemcpyDeviceToDevice, e->s);
+  }
+}
+static void export_params(eosvos_engine* e, const float* src, float* flat, float alpha, int add) {
+  for (const ConvL& c : e->t.convs) {
+    launch_ohwi_to_oihw(src + c.poff, flat + c.poff, c.cout, c.cin, c.T(), alpha, add, e->s);
+    if (c.bias) launch_ohwi_to_oihw(src + c.poff + c.wsize(), flat + c.poff + c.wsize(), c.cout, 1, 1, alpha, add, e->s);
+  }
+}
+
+int eosvos_set_init(eosvos_engine* e, const float* flat_params) {
+  if (!e || !flat_params) return fail("null argument");
+  import_params(e, flat_params, e->Winit);
+  HIPOK(hipMemcpyAsync(e->Wp, e->Winit, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_set_lr(eosvos_engine* e, const float* flat_lr) {
+  if (!e || !flat_lr) return fail("null argument");
+  HIPOK(hipMemcpyAsync(e->lr, flat_lr, (size_t)e->t.nlr * 4, hipMemcpyDeviceToDevice, e->s));
+  return 0;
+}
+int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, const float* mean,
+                    const float* var, float eps) {
+  if (!e || !gamma || !beta || !mean || !var) return fail("null argument");
+  launch_fold_norm(gamma, beta, mean, var, eps, e->na, e->nb, e->t.nnorm, e->s);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_reset(eosvos_engine* e) {
+  if (!e) return fail("null engine");
+  HIPOK(hipMemcpyAsync(e->Wp, e->Winit, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
+  return 0;
+}
+int eosvos_get_params(eosvos_engine* e, float* out) {
+  if (!e || !out) return fail("null argument");
+  export_params(e, e->Wp, out, 1.f, 0);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_set_params(eosvos_engine* e, const float* flat) {
+  if (!e || !flat) return fail("null argument");
+  import_params(e, flat, e->Wp);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_snapshot_params(eosvos_engine* e) {
+  if (!e) return fail("null engine");
+  HIPOK(hipMemcpyAsync(e->Wsnap, e->Wp, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
+  return 0;
+}
+int eosvos_restore_params(eosvos_engine* e) {
+  if (!e) return fail("null engine");
+  HIPOK(hipMemcpyAsync(e->Wp, e->Wsnap, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
+  return 0;
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+static int forward_impl(eosvos_engine* e, const float* images, int B) {
+  const Topo& t = e->t;
+  hipStream_t s = e->s;
+  launch_nchw_to_nhwc_pad(images, e->xpad, B, 3, e->H, e->W, 3, s);
+  launch_stem_fwd(e->xpad, e->W_(0), e->A_(0), e->B_(0), e->c1, B, e->H, e->W, e->h2, e->w2, s);
+  launch_maxpool_fwd(e->c1, e->p1, e->p1idx, B, e->h2, e->w2, 64, e->h4, e->w4, s);
+  for (size_t i = 0; i < t.blocks.size(); ++i) {
+    const Block& b = t.blocks[i];
+    auto& f = e->bb[i];
+    const int cmid = t.convs[b.c1].cout, cout = t.convs[b.c3].cout;
+    conv_fwd(e, b.c1, f.xin, f.Cin, f.Hi, f.Wi, f.t1, cmid, B, nullptr, 0, true);
+    conv_fwd(e, b.c2, f.t1, cmid, f.Hm, f.Wm, f.t2, cmid, B, nullptr, 0, true);
+    const float* res = f.xin;
+    int ldres = f.Cin;
+    if (b.ds >= 0) {
+      conv_fwd(e, b.ds, f.xin, f.Cin, f.Hi, f.Wi, f.dsb, cout, B, nullptr, 0, false);
+      res = f.dsb; ldres = cout;
+    }
+    conv_fwd(e, b.c3, f.t2, cmid, f.Ho, f.Wo, f.out, cout, B, res, ldres, true);
+  }
+  const float* l4 = e->bb.back().out;
+  const int P16 = e->h16 * e->w16;
+  for (int i = 0; i < 4; ++i)
+    conv_fwd(e, t.aspp[i], l4, 2048, e->h16, e->w16, e->cat + 256 * i, 1280, B, nullptr, 0, true);
+  launch_colsum(l4, 2048, e->vec, B, P16, 2048, 1.0f / (float)P16, e->colscratch, s);
+  launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, s);
+  launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s);
+  conv_fwd(e, t.project, e->cat, 1280, e->h16, e->w16, e->proj, 256, B, nullptr, 0, true);
+  const float* low = e->bb[t.layer1_last_block].out;
+  conv_fwd(e, t.dec1, low, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true);
+  launch_resize_fwd(e->proj, 256, e->dcat, 304, B, 256, e->up_h, e->up_w, s);
+  conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, B, nullptr, 0, true);
+  conv_fwd(e, t.dec_b, e->d1, 256, e->h4, e->w4, e->d2, 256, B, nullptr, 0, true);
+  const ConvL& lc = t.convs[t.last];
+  launch_last_fwd(e->d2, e->W_(t.last), e->W_(t.last) + lc.wsize(), e->lowlog, (int64_t)B * e->h4 * e->w4, 256, s);
+  launch_resize_fwd(e->lowlog, 1, e->logits, 1, B, 1, e->fin_h, e->fin_w, s);
+  e->lastB = B;
+  e->have_loss_grad = false;
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(std::string("forward launch: ") + hipGetErrorString(err));
+  return 0;
+}
+
+// ---- backward + fused update ----------------------------------------------------------------------
+static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
+  const Topo& t = e->t;
+  hipStream_t s = e->s;
+  const int B = e->lastB;
+  if (B < 1 || !e->have_loss_grad) return fail("backward without forward + loss");
+  if (accumulate && !e->gsum) return fail("accumulate without eosvos_meta_task_begin");
+  const int64_t P4 = (int64_t)B * e->h4 * e->w4;
+  const int P16 = e->h16 * e->w16;
+  // final resize
+  launch_resize_bwd(e->dlogits, 1, e->g_low, 1, nullptr, 0, B, 1, e->fin_h, e->fin_w, s);
+  // classifier conv (Cout = 1)
+  {
+    const int chunks = last_bwd_chunks(P4);
+    launch_last_bwd(e->d2, e->W_(t.last), e->g_low, e->g_d2, e->ws_wg, P4, 256, chunks, s);
+    apply_update(e, t.last, chunks, update, accumulate);
+  }
+  // decoder 3x3 convs
+  {
+    int sp = conv_wgrad(e, t.dec_b, e->g_d2, 256, e->d1, 256, e->h4, e->w4, B);
+    conv_dgrad(e, t.dec_b, e->g_d2, 256, e->h4, e->w4, e->g_d1, 256, B, false, e->d1, 256, 0);
+    apply_update(e, t.dec_b, sp, update, accumulate);
+    sp = conv_wgrad(e, t.dec_a, e->g_d1, 256, e->dcat, 304, e->h4, e->w4, B);
+    // channels [0,256) of dcat are the (unclamped) upsampled ASPP output: no ReLU mask there
+    conv_dgrad(e, t.dec_a, e->g_d1, 256, e->h4, e->w4, e->g_dcat, 304, B, false, e->dcat, 304, 256);
+    apply_update(e, t.dec_a, sp, update, accumulate);
+  }
+  // decoder.conv1 on the low-level feature: raw gradient into g_out of layer1's last block
+  float* g_low_feat = e->bb[t.layer1_last_block].g_out;
+  const float* low = e->bb[t.layer1_last_block].out;
+  {
+    int sp = conv_wgrad(e, t.dec1, e->g_dcat + 256, 304, low, 256, e->h4, e->w4, B);
+    conv_dgrad(e, t.dec1, e->g_dcat + 256, 304, e->h4, e->w4, g_low_feat, 256, B, false, nullptr, 0, 0);
+    apply_update(e, t.dec1, sp, update, accumulate);
+  }
+  // decoder upsample backward (+ ReLU mask of the projection output)
+  launch_resize_bwd(e->g_dcat, 304, e->g_proj, 256, e->proj, 256, B, 256, e->up_h, e->up_w, s);
+  // ASPP projection
+  {
+    int sp = conv_wgrad(e, t.project, e->g_proj, 256, e->cat, 1280, e->h16, e->w16, B);
+    conv_dgrad(e, t.project, e->g_proj, 256, e->h16, e->w16, e->g_cat, 1280, B, false, e->cat, 1280, 0);
+    apply_update(e, t.project, sp, update, accumulate);
+  }
+  float* g_l4 = e->bb.back().g_out;
+  const float* l4 = e->bb.back().out;
+  // image-pooling branch: gp = sum_p g_cat[:,1024:1280]; g_l4 starts as the broadcast of its input gradient
+  {
+    launch_colsum(e->g_cat + 1024, 1280, e->gp, B, P16, 256, 1.f, e->colscratch, s);
+    launch_gemv_bwd(e->W_(t.pool), e->vec, e->gp, e->A_(t.pool), e->gvec, e->ws_wg, B, 256, 2048, s);
+    launch_bcast_pixels(e->gvec, g_l4, 2048, B, P16, 2048, 1.0f / (float)P16, s);
+    apply_update(e, t.pool, 1, update, accumulate);
+  }
+  for (int i = 0; i < 4; ++i) {
+    int sp = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B);
+    const bool lastone = i == 3;
+    conv_dgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, e->h16, e->w16, g_l4, 2048, B, true,
+               lastone ? l4 : nullptr, 2048, 0);
+    apply_update(e, t.aspp[i], sp, update, accumulate);
+  }
+  // bottlenecks, last to first.  g_out of each block = dL/d(pre-ReLU block output).
+  for (int i = (int)t.blocks.size() - 1; i >= 0; --i) {
+    const Block& b = t.blocks[i];
+    auto& f = e->bb[i];
+    const int cmid = t.convs[b.c1].cout, cout = t.convs[b.c3].cout;
+    int sp = conv_wgrad(e, b.c3, f.g_out, cout, f.t2, cmid, f.Ho, f.Wo, B);
+    conv_dgrad(e, b.c3, f.g_out, cout, f.Ho, f.Wo, f.g_t2, cmid, B, false, f.t2, cmid, 0);
+    apply_update(e, b.c3, sp, update, accumulate);
+    sp = conv_wgrad(e, b.c2, f.g_t2, cmid, f.t1, cmid, f.Hm, f.Wm, B);
+    conv_dgrad(e, b.c2, f.g_t2, cmid, f.Hm, f.Wm, f.g_t1, cmid, B, false, f.t1, cmid, 0);
+    apply_update(e, b.c2, sp, update, accumulate);
+    // gradient w.r.t. the block input: conv1 path + identity / downsample path
+    const bool is_first_block = i == 0;
+    // the low-level feature already holds decoder.conv1's contribution
+    bool have = (i == t.layer1_last_block + 1);
+    const float* inmask = is_first_block ? nullptr : f.xin;   // p1 is a max-pool output: masked in maxpool_bwd
+    if (b.ds >= 0) {
+      sp = conv_wgrad(e, b.ds, f.g_out, cout, f.xin, f.Cin, f.Hi, f.Wi, B);
+      conv_dgrad(e, b.ds, f.g_out, cout, f.Hi, f.Wi, f.g_xin, f.Cin, B, have, nullptr, 0, 0);
+      apply_update(e, b.ds, sp, update, accumulate);
+      sp = conv_wgrad(e, b.c1, f.g_t1, cmid, f.xin, f.Cin, f.Hi, f.Wi, B);
+      conv_dgrad(e, b.c1, f.g_t1, cmid, f.Hi, f.Wi, f.g_xin, f.Cin, B, true, inmask, f.Cin, 0);
+      apply_update(e, b.c1, sp, update, accumulate);
+    } else {
+      // identity path: g_xin = mask * (dgrad_conv1(g_t1) + g_out)
+      if (have) return fail("internal: identity block after the low-level tap is unsupported");
+      sp = conv_wgrad(e, b.c1, f.g_t1, cmid, f.xin, f.Cin, f.Hi, f.Wi, B);
+      conv_dgrad(e, b.c1, f.g_t1, cmid, f.Hi, f.Wi, f.g_xin, f.Cin, B, false, inmask, f.Cin, 0, f.g_out, cout);
+      apply_update(e, b.c1, sp, update, accumulate);
+    }
+  }
+  // stem
+  launch_maxpool_bwd(e->g_p1, e->p1idx, e->c1, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s);
+  {
+    const int chunks = stem_wgrad_chunks(B, e->h2, e->w2);
+    launch_stem_wgrad(e->xpad, e->g_c1, e->ws_wg, B, e->H, e->W, e->h2, e->w2, chunks, s);
+    apply_update(e, 0, chunks, update, accumulate);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(std::string("backward launch: ") + hipGetErrorString(err));
+  return 0;
+}
+
+int eosvos_forward(eosvos_engine* e, const float* images, int batch, float* logits_out) {
+  if (!e || !images) return fail("null argument");
+  if (batch < 1 || batch > e->maxB) return fail("batch out of range");
+  if (forward_impl(e, images, batch)) return 1;
+  if (logits_out)
+    HIPOK(hipMemcpyAsync(logits_out, e->logits, (size_t)batch * e->H * e->W * 4, hipMemcpyDeviceToDevice, e->s));
+  return 0;
+}
+int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss_out) {
+  if (!e || !masks) return fail("null argument");
+  if (batch != e->lastB) return fail("loss batch differs from the last forward");
+  launch_bce(e->logits, masks, e->dlogits, e->loss_dev, e->bce_partial, (int64_t)batch * e->H * e->W, e->s);
+  e->have_loss_grad = true;
+  if (loss_out) HIPOK(hipMemcpyAsync(loss_out, e->loss_dev, 4, hipMemcpyDeviceToDevice, e->s));
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_backward_step(eosvos_engine* e, int accumulate) {
+  if (!e) return fail("null engine");
+  return backward_impl(e, true, accumulate != 0);
+}
+int eosvos_finetune_step(eosvos_engine* e, const float* images, const float* masks, int batch, int accumulate,
+                         float* loss_host) {
+  if (eosvos_forward(e, images, batch, nullptr)) return 1;
+  if (eosvos_loss_bce(e, masks, batch, nullptr)) return 1;
+  if (backward_impl(e, true, accumulate != 0)) return 1;
+  if (loss_host) {
+    HIPOK(hipMemcpyAsync(loss_host, e->loss_dev, 4, hipMemcpyDeviceToHost, e->s));
+    HIPOK(hipStreamSynchronize(e->s));
+  }
+  return 0;
+}
+int eosvos_get_grads(eosvos_engine* e, float* out) {
+  if (!e || !out) return fail("null argument");
+  if (!e->keep_grads) return fail("gradients are only kept after eosvos_keep_grads(e, 1)");
+  export_params(e, e->gout, out, 1.f, 0);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_keep_grads(eosvos_engine* e, int on) {
+  if (!e) return fail("null engine");
+  e->keep_grads = on != 0;
+  return 0;
+}
+
+int eosvos_infer(eosvos_engine* e, const float* images, int batch, float* probs_out) {
+  if (!e || !images || !probs_out) return fail("null argument");
+  if (batch < 1 || batch > e->maxB) return fail("batch out of range");
+  if (forward_impl(e, images, batch)) return 1;
+  launch_sigmoid(e->logits, probs_out, (int64_t)batch * e->H * e->W, e->s);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t n_pix, uint8_t* labels) {
+  if (!e || !probs || !labels || n_obj < 1) return fail("bad argument");
+  launch_merge_labels(probs, n_obj, n_pix, labels, e->s);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+
+int eosvos_meta_task_begin(eosvos_engine* e) {
+  if (!e) return fail("null engine");
+  if (!e->gsum) {
+    e->gsum = e->falloc(e->t.nparam);
+    if (!e->gsum) return fail("hipMalloc gsum");
+  }
+  HIPOK(hipMemsetAsync(e->gsum, 0, (size_t)e->t.nparam * 4, e->s));
+  return eosvos_reset(e);
+}
+int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, int batch, float* flat_meta_grad,
+                     float* meta_loss_host) {
+  if (!e || !images || !masks || !flat_meta_grad) return fail("null argument");
+  if (!e->gsum) return fail("eosvos_meta_grad without eosvos_meta_task_begin");
+  if (eosvos_forward(e, images, batch, nullptr)) return 1;
+  if (eosvos_loss_bce(e, masks, batch, nullptr)) return 1;
+  const bool keep = e->keep_grads;
+  e->keep_grads = true;
+  const int rc = backward_impl(e, false, false);
+  e->keep_grads = keep;
+  if (rc) return 1;
+  const Topo& t = e->t;
+  for (const ConvL& c : t.convs) {
+    launch_meta_lr_grad(e->gsum + c.poff, e->gout + c.poff, flat_meta_grad + c.lroff, c.cout, (int64_t)c.T() * c.cin, e->s);
+    if (c.bias)
+      launch_meta_lr_grad(e->gsum + c.poff + c.wsize(), e->gout + c.poff + c.wsize(), flat_meta_grad + c.lroff + c.cout,
+                          c.cout, 1, e->s);
+  }
+  export_params(e, e->gout, flat_meta_grad + t.nlr, 1.f, 1);
+  HIPOK(hipGetLastError());
+  if (meta_loss_host) {
+    HIPOK(hipMemcpyAsync(meta_loss_host, e->loss_dev, 4, hipMemcpyDeviceToHost, e->s));
+    HIPOK(hipStreamSynchronize(e->s));
+  }
+  return 0;
+}
+
+int eosvos_radam_step(eosvos_engine* e, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      int64_t n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
+                      float grad_scale, float grad_clip) {
+  if (!e || !param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail("bad argument");
+  // radam.py:62-79 in double, as the reference's Python floats
+  const double b1 = beta1, b2 = beta2;
+  const double beta2_t = pow(b2, (double)step);
+  const double n_sma_max = 2.0 / (1.0 - b2) - 1.0;
+  const double n_sma = n_sma_max - 2.0 * step * beta2_t / (1.0 - beta2_t);
+  double step_size;
+  int use_denom = 0;
+  if (n_sma >= 5.0) {
+    step_size = sqrt((1.0 - beta2_t) * (n_sma - 4.0) / (n_sma_max - 4.0) * (n_sma - 2.0) / n_sma * n_sma_max /
+                     (n_sma_max - 2.0)) / (1.0 - pow(b1, (double)step));
+    use_denom = 1;
+  } else {
+    step_size = 1.0 / (1.0 - pow(b1, (double)step));
+  }
+  launch_radam(param, grad, exp_avg, exp_avg_sq, n, lr, weight_decay, beta1, beta2, eps, (float)step_size,
+               use_denom, grad_scale, grad_clip, e->s);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi) {
+  if (!e || !param) return fail("null argument");
+  launch_clamp(param, n, lo, hi, e->s);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+
+int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host, double* flops_host) {
+  if (!e || !ms_host || !flops_host || batch < 1 || batch > e->maxB || reps < 1) return fail("bad argument");
+  const Topo& t = e->t;
+  hipEvent_t a, b;
+  HIPOK(hipEventCreate(&a));
+  HIPOK(hipEventCreate(&b));
+  conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);   // warm
+  HIPOK(hipEventRecord(a, e->s));
+  for (int i = 0; i < reps; ++i) conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);
+  HIPOK(hipEventRecord(b, e->s));
+  HIPOK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPOK(hipEventElapsedTime(&ms, a, b));
+  *ms_host = ms / reps;
+  *flops_host = 2.0 * (double)batch * e->h4 * e->w4 * 256.0 * 304.0 * 9.0;
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return 0;
+}
+
+int eosvos_debug_tensor(eosvos_engine* e, const char* name, float** ptr, int64_t* dims4) {
+  if (!e || !name || !ptr || !dims4) return fail("null argument");
+  const int B = e->lastB > 0 ? e->lastB : 1;
+  const std::string n(name);
+  auto set = [&](float* p, int h, int w, int c) { *ptr = p; dims4[0] = B; dims4[1] = h; dims4[2] = w; dims4[3] = c; return 0; };
+  if (n == "c1") return set(e->c1, e->h2, e->w2, 64);
+  if (n == "p1") return set(e->p1, e->h4, e->w4, 64);
+  if (n == "g_c1") return set(e->g_c1, e->h2, e->w2, 64);
+  if (n == "g_p1") return set(e->g_p1, e->h4, e->w4, 64);
+  if (n == "cat") return set(e->cat, e->h16, e->w16, 1280);
+  if (n == "g_cat") return set(e->g_cat, e->h16, e->w16, 1280);
+  if (n == "proj") return set(e->proj, e->h16, e->w16, 256);
+  if (n == "g_proj") return set(e->g_proj, e->h16, e->w16, 256);
+  if (n == "dcat") return set(e->dcat, e->h4, e->w4, 304);
+  if (n == "g_dcat") return set(e->g_dcat, e->h4, e->w4, 304);
+  if (n == "d1") return set(e->d1, e->h4, e->w4, 256);
+  if (n == "d2") return set(e->d2, e->h4, e->w4, 256);
+  if (n == "g_d1") return set(e->g_d1, e->h4, e->w4, 256);
+  if (n == "g_d2") return set(e->g_d2, e->h4, e->w4, 256);
+  if (n == "lowlog") return set(e->lowlog, e->h4, e->w4, 1);
+  if (n == "g_low") return set(e->g_low, e->h4, e->w4, 1);
+  if (n == "logits") return set(e->logits, e->H, e->W, 1);
+  if (n == "dlogits") return set(e->dlogits, e->H, e->W, 1);
+  if (n.rfind("blk", 0) == 0) {
+    const size_t dot = n.find('.');
+    if (dot == std::string::npos) return fail("bad block tensor name");
+    const int i = atoi(n.substr(3, dot - 3).c_str());
+    if (i < 0 || i >= (int)e->bb.size()) return fail("block index out of range");
+    const auto& f = e->bb[i];
+    const Block& b = e->t.blocks[i];
+    const int cmid = e->t.convs[b.c1].cout, cout = e->t.convs[b.c3].cout;
+    const std::string k = n.substr(dot + 1);
+    if (k == "t1") return set(f.t1, f.Hm, f.Wm, cmid);
+    if (k == "t2") return set(f.t2, f.Ho, f.Wo, cmid);
+    if (k == "out") return set(f.out, f.Ho, f.Wo, cout);
+    if (k == "g_t1") return set(f.g_t1, f.Hm, f.Wm, cmid);
+    if (k == "g_t2") return set(f.g_t2, f.Ho, f.Wo, cmid);
+    if (k == "g_out") return set(f.g_out, f.Ho, f.Wo, cout);
+    if (k == "dsb" && f.dsb) return set(f.dsb, f.Ho, f.Wo, cout);
+  }
+  return fail("unknown debug tensor " + n);
+}
+
+// ---- low-level op entry points for the kernel parity tests -----------------------------------------
+int eosvos_test_conv(eosvos_engine* e, const float* x, const float* w_oihw, const float* scale, const float* bias,
+                     const float* res, int relu, int B, int H, int W, int Cin, int Cout, int k, int stride, int dil,
+                     int pad, float* y) {
+  if (!e || !x || !w_oihw || !y) return fail("null argument");
+  if (Cin % 4 || Cout % 4) return fail("channels must be multiples of 4");
+  float *w = nullptr, *ws = nullptr;
+  const int T = k * k;
+  HIPOK(hipMalloc((void**)&w, (size_t)Cout * Cin * T * 4));
+  launch_oihw_to_ohwi(w_oihw, w, Cout, Cin, T, e->s);
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.y = y;
+  a.B = B; a.Hi = H; a.Wi = W; a.ldx = Cin; a.Kc = Cin;
+  a.Ho = conv_out(H, k, stride, dil, pad); a.Wo = conv_out(W, k, stride, dil, pad);
+  a.N = Cout; a.ldy = Cout; a.KH = a.KW = k; a.mul = stride; a.off0 = -pad; a.kstep = dil;
+  a.M = B * a.Ho * a.Wo; a.wN = Cout; a.wK = Cin; a.scale = scale; a.bias = bias; a.res = res; a.ldres = Cout;
+  a.relu = relu;
+  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(T, Cin));
+  HIPOK(hipMalloc((void**)&ws, (size_t)a.splits * a.M * a.N * 4));
+  a.ws = ws;
+  launch_conv(a, e->s);
+  HIPOK(hipStreamSynchronize(e->s));
+  hipFree(w);
+  hipFree(ws);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_test_conv_bwd(eosvos_engine* e, const float* x, const float* w_oihw, const float* g, int B, int H, int W,
+                         int Cin, int Cout, int k, int stride, int dil, int pad, float* dx, float* dw_oihw) {
+  if (!e || !x || !w_oihw || !g || !dx || !dw_oihw) return fail("null argument");
+  if (Cin % 4 || Cout % 4) return fail("channels must be multiples of 4");
+  const int T = k * k;
+  const int Ho = conv_out(H, k, stride, dil, pad), Wo = conv_out(W, k, stride, dil, pad);
+  float *w = nullptr, *ws = nullptr, *wsw = nullptr, *dw = nullptr;
+  HIPOK(hipMalloc((void**)&w, (size_t)Cout * Cin * T * 4));
+  HIPOK(hipMalloc((void**)&dw, (size_t)Cout * Cin * T * 4));
+  launch_oihw_to_ohwi(w_oihw, w, Cout, Cin, T, e->s);
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = g; a.w = w; a.y = dx;
+  a.B = B; a.Hi = Ho; a.Wi = Wo; a.ldx = Cout; a.Kc = Cout;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.ldy = Cin; a.KH = a.KW = k; a.mul = 1; a.off0 = pad; a.kstep = -dil;
+  a.upshift = stride == 2 ? 1 : 0;
+  a.M = B * H * W; a.wN = Cout; a.wK = Cin; a.kmajor = 1;
+  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(T, Cout));
+  HIPOK(hipMalloc((void**)&ws, (size_t)a.splits * a.M * a.N * 4));
+  a.ws = ws;
+  launch_conv(a, e->s);
+  WgradArgs g2;
+  memset(&g2, 0, sizeof(g2));
+  g2.g = g; g2.x = x; g2.B = B; g2.Ho = Ho; g2.Wo = Wo; g2.ldg = Cout; g2.Cout = Cout; g2.Hi = H; g2.Wi = W;
+  g2.ldx = Cin; g2.Cin = Cin; g2.KH = g2.KW = k; g2.stride = stride; g2.pad = pad; g2.dil = dil;
+  g2.splits = wgrad_pick_splits(B * Ho * Wo, Cout, Cin, T);
+  HIPOK(hipMalloc((void**)&wsw, (size_t)g2.splits * Cout * Cin * T * 4));
+  g2.ws = wsw;
+  launch_wgrad(g2, e->s);
+  const int64_t n = (int64_t)Cout * Cin * T;
+  launch_sgd_update(dw, wsw, g2.splits, n, nullptr, nullptr, nullptr, dw, (int64_t)T * Cin, n, e->s);
+  launch_ohwi_to_oihw(dw, dw_oihw, Cout, Cin, T, 1.f, 0, e->s);
+  HIPOK(hipStreamSynchronize(e->s));
+  hipFree(w); hipFree(ws); hipFree(wsw); hipFree(dw);
+  HIPOK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

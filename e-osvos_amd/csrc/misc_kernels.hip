@@ -594,7 +594,7 @@ __global__ void sgd_update_kernel(float* __restrict__ w, const float* __restrict
     for (int z = 0; z < splits; ++z) g += ws[(long)z * slab + e];
     const long row = e / rowlen;
     if (rowscale) g *= rowscale[row];
-    w[e] = w[e] - lr[row] * g;
+    if (lr) w[e] = w[e] - lr[row] * g;
     if (gsum) gsum[e] += g;
     if (gout) gout[e] = g;
   }

@@ -1,0 +1,222 @@
+"""Python handle on one `eosvos_engine` (one per process / GPU, like the reference's one
+model per process, `src/util/helper_func.py:499-512`).
+
+torch-ROCm is used for device memory and streams only; every arithmetic call goes through
+the C-ABI of include/eosvos.h.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi
+from .topology import ARCH_ID, norm_layers, trainable
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    def __init__(self, encoder='resnet50', height=480, width=854, max_batch=3, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise _ffi.EosvosError('no GPU visible: the e-osvos_amd engine has no CPU path')
+        self.lib = _ffi.load()
+        self.encoder = encoder
+        self.arch = ARCH_ID[encoder]
+        self.device = torch.device(device)
+        self.height, self.width, self.max_batch = height, width, max_batch
+        self.n_param = int(self.lib.eosvos_param_count(self.arch))
+        self.n_lr = int(self.lib.eosvos_lr_count(self.arch))
+        self.n_norm = int(self.lib.eosvos_norm_count(self.arch))
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = ctypes.c_void_p()
+        _ffi.check(self.lib.eosvos_create(ctypes.byref(h), self.arch, 0, height, width, max_batch,
+                                          self.device.index or 0, ctypes.c_void_p(self.stream.cuda_stream)))
+        self.h = h
+        self._loss = torch.zeros(1, device=self.device)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.eosvos_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ----------------------------------------------------------------------
+    def set_init(self, flat):
+        flat = _dev_f32(flat, self.device)
+        assert flat.numel() == self.n_param
+        _ffi.check(self.lib.eosvos_set_init(self.h, _ptr(flat)))
+        self.synchronize()
+
+    def set_lr(self, flat):
+        flat = _dev_f32(flat, self.device)
+        assert flat.numel() == self.n_lr
+        _ffi.check(self.lib.eosvos_set_lr(self.h, _ptr(flat)))
+        self.synchronize()
+
+    def set_norm(self, gamma, beta, mean, var, eps=1e-5):
+        ts = [_dev_f32(t, self.device) for t in (gamma, beta, mean, var)]
+        assert all(t.numel() == self.n_norm for t in ts)
+        _ffi.check(self.lib.eosvos_set_norm(self.h, *[_ptr(t) for t in ts], ctypes.c_float(eps)))
+        self.synchronize()
+
+    def load_model_state(self, state_dict, lrs=None):
+        """Convenience: reference-style model state dict (+ list of NEURON lr tensors)."""
+        names = [n for n, _ in trainable(self.encoder)]
+        self.set_init(torch.cat([state_dict[n].reshape(-1).float() for n in names]))
+        nl = norm_layers(self.encoder)
+        cat = lambda suf: torch.cat([state_dict[p + suf].reshape(-1).float() for p, _ in nl])
+        self.set_norm(cat('.weight'), cat('.bias'), cat('.running_mean'), cat('.running_var'))
+        if lrs is not None:
+            self.set_lr(torch.cat([l.reshape(-1).float() for l in lrs]))
+
+    def reset(self):
+        _ffi.check(self.lib.eosvos_reset(self.h))
+
+    def get_params(self):
+        out = torch.empty(self.n_param, device=self.device)
+        _ffi.check(self.lib.eosvos_get_params(self.h, _ptr(out)))
+        return out
+
+    def set_params(self, flat):
+        flat = _dev_f32(flat, self.device)
+        _ffi.check(self.lib.eosvos_set_params(self.h, _ptr(flat)))
+        self.synchronize()
+
+    def snapshot(self):
+        _ffi.check(self.lib.eosvos_snapshot_params(self.h))
+
+    def restore(self):
+        _ffi.check(self.lib.eosvos_restore_params(self.h))
+
+    # ---- hot loop -------------------------------------------------------------------
+    def _check_images(self, images):
+        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        b, c, h, w = images.shape
+        assert c == 3 and h == self.height and w == self.width and 1 <= b <= self.max_batch, images.shape
+        return b
+
+    def forward(self, images, want_logits=True):
+        b = self._check_images(images)
+        out = torch.empty(b, 1, self.height, self.width, device=self.device) if want_logits else None
+        _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(out) if want_logits else None))
+        return out
+
+    def loss_bce(self, masks):
+        assert masks.is_cuda and masks.dtype == torch.float32 and masks.is_contiguous()
+        loss = torch.empty(1, device=self.device)
+        _ffi.check(self.lib.eosvos_loss_bce(self.h, _ptr(masks), masks.shape[0], _ptr(loss)))
+        return loss
+
+    def backward_step(self, accumulate=False):
+        _ffi.check(self.lib.eosvos_backward_step(self.h, int(accumulate)))
+
+    def finetune_step(self, images, masks, accumulate=False, sync_loss=True):
+        b = self._check_images(images)
+        assert masks.is_cuda and masks.is_contiguous() and masks.shape[0] == b
+        if sync_loss:
+            l = ctypes.c_float()
+            _ffi.check(self.lib.eosvos_finetune_step(self.h, _ptr(images), _ptr(masks), b, int(accumulate),
+                                                     ctypes.byref(l)))
+            return l.value
+        _ffi.check(self.lib.eosvos_finetune_step(self.h, _ptr(images), _ptr(masks), b, int(accumulate), None))
+        return None
+
+    def keep_grads(self, on=True):
+        _ffi.check(self.lib.eosvos_keep_grads(self.h, int(on)))
+
+    def get_grads(self):
+        out = torch.empty(self.n_param, device=self.device)
+        _ffi.check(self.lib.eosvos_get_grads(self.h, _ptr(out)))
+        return out
+
+    def infer(self, images):
+        b = self._check_images(images)
+        out = torch.empty(b, 1, self.height, self.width, device=self.device)
+        _ffi.check(self.lib.eosvos_infer(self.h, _ptr(images), b, _ptr(out)))
+        return out
+
+    def merge_labels(self, probs):
+        """probs: (n_obj, H, W) device fp32 -> (H, W) uint8.  `evaluate.py:322-326`."""
+        probs = probs.contiguous()
+        n_obj = probs.shape[0]
+        n_pix = probs[0].numel()
+        out = torch.empty(probs.shape[1:], dtype=torch.uint8, device=self.device)
+        _ffi.check(self.lib.eosvos_merge_labels(self.h, _ptr(probs), n_obj, n_pix, _ptr(out)))
+        return out
+
+    # ---- meta-training ----------------------------------------------------------------
+    def meta_task_begin(self):
+        _ffi.check(self.lib.eosvos_meta_task_begin(self.h))
+
+    def meta_grad(self, images, masks, flat_meta_grad):
+        b = self._check_images(images)
+        assert flat_meta_grad.numel() == self.n_lr + self.n_param and flat_meta_grad.is_cuda
+        l = ctypes.c_float()
+        _ffi.check(self.lib.eosvos_meta_grad(self.h, _ptr(images), _ptr(masks), b, _ptr(flat_meta_grad),
+                                             ctypes.byref(l)))
+        return l.value
+
+    def radam_step(self, param, grad, exp_avg, exp_avg_sq, lr, weight_decay, step, grad_scale=1.0,
+                   grad_clip=0.0, betas=(0.9, 0.999), eps=1e-8):
+        _ffi.check(self.lib.eosvos_radam_step(self.h, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                              param.numel(), lr, weight_decay, betas[0], betas[1], eps, step,
+                                              grad_scale, grad_clip))
+
+    def clamp(self, param, lo, hi):
+        _ffi.check(self.lib.eosvos_clamp(self.h, _ptr(param), param.numel(), lo, hi))
+
+    def synchronize(self):
+        _ffi.check(self.lib.eosvos_synchronize(self.h))
+
+    def time_hot_kernel(self, batch, reps=20):
+        ms, fl = ctypes.c_float(), ctypes.c_double()
+        _ffi.check(self.lib.eosvos_time_hot_kernel(self.h, batch, reps, ctypes.byref(ms), ctypes.byref(fl)))
+        return ms.value, fl.value
+
+    def debug_tensor(self, name):
+        """Copy of a named internal NHWC buffer as a (B,C,H,W) tensor (parity tests)."""
+        ptr = ctypes.c_void_p()
+        dims = (ctypes.c_int64 * 4)()
+        _ffi.check(self.lib.eosvos_debug_tensor(self.h, name.encode(), ctypes.byref(ptr), dims))
+        b, h, w, c = [int(d) for d in dims]
+        n = b * h * w * c
+        out = torch.empty(n, device=self.device)
+        self.synchronize()
+        import ctypes as _c
+        hip = _c.CDLL('libamdhip64.so')
+        rc = hip.hipMemcpy(_c.c_void_p(out.data_ptr()), ptr, _c.c_size_t(n * 4), 3)  # device to device
+        if rc != 0:
+            raise _ffi.EosvosError(f'hipMemcpy failed ({rc})')
+        return out.view(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+
+    # ---- low-level op tests --------------------------------------------------------------
+    def test_conv(self, x_nhwc, w_oihw, scale, bias, res, relu, stride, dil, pad):
+        B, H, W, Cin = x_nhwc.shape
+        Cout, _, k, _ = w_oihw.shape
+        Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        y = torch.empty(B, Ho, Wo, Cout, device=self.device)
+        p = lambda t: _ptr(t) if t is not None else None
+        _ffi.check(self.lib.eosvos_test_conv(self.h, _ptr(x_nhwc), _ptr(w_oihw), p(scale), p(bias), p(res),
+                                             int(relu), B, H, W, Cin, Cout, k, stride, dil, pad, _ptr(y)))
+        return y
+
+    def test_conv_bwd(self, x_nhwc, w_oihw, g_nhwc, stride, dil, pad):
+        B, H, W, Cin = x_nhwc.shape
+        Cout, _, k, _ = w_oihw.shape
+        dx = torch.empty_like(x_nhwc)
+        dw = torch.empty_like(w_oihw)
+        _ffi.check(self.lib.eosvos_test_conv_bwd(self.h, _ptr(x_nhwc), _ptr(w_oihw), _ptr(g_nhwc), B, H, W, Cin,
+                                                 Cout, k, stride, dil, pad, _ptr(dx), _ptr(dw)))
+        return dx, dw

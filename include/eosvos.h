@@ -98,7 +98,9 @@ int eosvos_backward_step(eosvos_engine* e, int accumulate);
 /* forward + loss + backward + update in one call; loss_host may be NULL (no sync). */
 int eosvos_finetune_step(eosvos_engine* e, const float* images, const float* masks, int batch,
                          int accumulate, float* loss_host);
-/* Gradient of the last backward w.r.t. the trainables, flat OIHW (for parity tests). */
+/* Gradient of the last backward w.r.t. the trainables, flat OIHW (for parity tests); the
+ * engine only materialises it after eosvos_keep_grads(e, 1) (one extra 161 MB write/step). */
+int eosvos_keep_grads(eosvos_engine* e, int on);
 int eosvos_get_grads(eosvos_engine* e, float* flat_grads_out);
 
 /* ---- inference (helper_func.py:131-142, evaluate.py:322-326) ----------------------- */
@@ -136,6 +138,10 @@ int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi);
  * average milliseconds in *ms_host and the algorithmic FLOPs per launch in *flops_host. */
 int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host,
                            double* flops_host);
+/* Device pointer + {B,H,W,C} of a named internal NHWC activation / gradient buffer of the
+ * last forward/backward ("c1","p1","blk<i>.out","cat","proj","dcat","d1","d2","lowlog",
+ * "logits", "g_*" ...), for the per-stage parity tests. */
+int eosvos_debug_tensor(eosvos_engine* e, const char* name, float** ptr_out, int64_t* dims4_out);
 /* Low-level op entry used by the kernel parity tests: a single NHWC convolution
  * y = relu?(a*conv(x,w)+b (+res)); w is OIHW; all dense tensors; stride/dil/pad as torch. */
 int eosvos_test_conv(eosvos_engine* e, const float* x_nhwc, const float* w_oihw,
