@@ -629,6 +629,17 @@ int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss
   HIPOK(hipGetLastError());
   return 0;
 }
+int eosvos_bce(eosvos_engine* e, const float* logits, const float* masks, int64_t n, float* loss_out,
+               float* dlogits_out) {
+  if (!e || !logits || !masks || !loss_out || n < 1) return fail("bad argument");
+  if (!dlogits_out && n > (int64_t)e->maxB * e->H * e->W) return fail("n exceeds the engine's scratch");
+  // without a caller buffer the gradient goes to the engine's own dlogits scratch, which
+  // invalidates a pending eosvos_loss_bce gradient
+  if (!dlogits_out) e->have_loss_grad = false;
+  launch_bce(logits, masks, dlogits_out ? dlogits_out : e->dlogits, loss_out, e->bce_partial, n, e->s);
+  HIPOK(hipGetLastError());
+  return 0;
+}
 int eosvos_backward_step(eosvos_engine* e, int accumulate) {
   if (!e) return fail("null engine");
   return backward_impl(e, true, accumulate != 0);

@@ -118,6 +118,13 @@ class Engine:
         _ffi.check(self.lib.eosvos_loss_bce(self.h, _ptr(masks), masks.shape[0], _ptr(loss)))
         return loss
 
+    def bce(self, logits, masks):
+        """Mean BCE-with-logits of arbitrary device tensors (no gradient kept)."""
+        logits, masks = logits.contiguous(), masks.contiguous()
+        loss = torch.empty(1, device=self.device)
+        _ffi.check(self.lib.eosvos_bce(self.h, _ptr(logits), _ptr(masks), logits.numel(), _ptr(loss), None))
+        return loss
+
     def backward_step(self, accumulate=False):
         _ffi.check(self.lib.eosvos_backward_step(self.h, int(accumulate)))
 

@@ -1,0 +1,110 @@
+"""Meta-training outer loop on the engine: one process per GPU, tasks sharded over ranks,
+ONE all-reduce (RCCL over xGMI) of the flat meta-gradient per meta-iteration, then every
+rank applies the identical fused RAdam step -- no parameter broadcast needed.
+
+Replaces the reference's worker/main split:
+  * task loop          `src/util/meta_run.py:109-238`  (K inner steps, meta frame,
+                       `bptt_loss.backward()`, NaN guard `:209-211,226`)
+  * gradient hand-off  `meta_run.py:237-238` (unsynchronised `+=` into shared CPU tensors)
+                       -> deterministic device all-reduce
+  * outer step         `src/train_meta.py:361-373` (average by meta_batch_size, optional
+                       clip, RAdam with per-tensor groups `:110-127`, `clamp_init_lr`)
+The flat state vector is [log_init_lr_* | model_init_*] in `MetaOptimizer.named_parameters()`
+order (`meta_optim.py:65-66,78`), the reference's OIHW layout.
+"""
+import math
+
+import torch
+
+from .topology import neuron_lr_shape, trainable
+
+
+class MetaTrainer:
+    def __init__(self, engine, dist=None, meta_batch_size=4, model_init_lr=1e-5, log_init_lr_lr=1e-5,
+                 model_init_weight_decay=1e-3, grad_clip=None, max_lr=None):
+        self.eng = engine
+        self.dist = dist
+        self.meta_batch_size = meta_batch_size
+        self.model_init_lr, self.log_init_lr_lr = model_init_lr, log_init_lr_lr
+        self.wd, self.grad_clip, self.max_lr = model_init_weight_decay, grad_clip, max_lr
+        n = engine.n_lr + engine.n_param
+        dev = engine.device
+        self.state = torch.zeros(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.task_grad = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self.step = 0
+        self.skipped_tasks = 0
+
+    # ---- state ------------------------------------------------------------------------
+    def load_state(self, model_state, lrs):
+        """model_state: reference-style model state dict; lrs: list of NEURON lr tensors."""
+        names = [n for n, _ in trainable(self.eng.encoder)]
+        dev = self.eng.device
+        self.state[:self.eng.n_lr] = torch.cat([l.reshape(-1).float() for l in lrs]).to(dev)
+        self.state[self.eng.n_lr:] = torch.cat([model_state[n].reshape(-1).float() for n in names]).to(dev)
+        self.eng.load_model_state(model_state, lrs)
+
+    def state_dict(self):
+        """`meta_optim_state_dict` of the reference checkpoints (train_meta.py:277-286)."""
+        out, off = {}, 0
+        tr = trainable(self.eng.encoder)
+        for n, shape in tr:
+            s = neuron_lr_shape(shape)
+            k = math.prod(s)
+            out['log_init_lr_' + n.replace('.', '-')] = self.state[off:off + k].view(s)
+            off += k
+        for n, shape in tr:
+            k = math.prod(shape)
+            out['model_init_' + n.replace('.', '-')] = self.state[off:off + k].view(shape)
+            off += k
+        return out
+
+    def _push_state(self):
+        self.eng.set_lr(self.state[:self.eng.n_lr])
+        self.eng.set_init(self.state[self.eng.n_lr:])
+
+    # ---- one task ---------------------------------------------------------------------
+    def run_task(self, x_train, y_train, x_meta, y_meta, inner_steps=5):
+        """Returns (train losses or None, meta loss).  Adds the task's meta-gradient into
+        self.grad unless the meta loss is NaN (meta_run.py:209-211,226: skipped tasks
+        contribute zeros but the average still divides by meta_batch_size)."""
+        eng = self.eng
+        eng.meta_task_begin()
+        for _ in range(inner_steps):
+            eng.finetune_step(x_train, y_train, accumulate=True, sync_loss=False)
+        self.task_grad.zero_()
+        meta_loss = eng.meta_grad(x_meta, y_meta, self.task_grad)
+        if math.isnan(meta_loss):
+            self.skipped_tasks += 1
+        else:
+            self.grad.add_(self.task_grad)
+        return meta_loss
+
+    # ---- one meta-iteration --------------------------------------------------------------
+    def meta_iteration(self, local_tasks, inner_steps=5):
+        """local_tasks: this rank's share of the meta-batch: [(x_train, y_train, x_meta, y_meta)]."""
+        losses = [self.run_task(*t, inner_steps=inner_steps) for t in local_tasks]
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(self.grad)             # sum over ranks, one 161 MB message
+        self.outer_step()
+        return losses
+
+    def outer_step(self):
+        eng = self.eng
+        self.step += 1
+        nl = eng.n_lr
+        scale = 1.0 / self.meta_batch_size
+        clip = float(self.grad_clip) if self.grad_clip is not None else 0.0
+        for lo, hi, lr, wd in ((0, nl, self.log_init_lr_lr, 0.0), (nl, self.state.numel(), self.model_init_lr, self.wd)):
+            eng.radam_step(self.state[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                           lr, wd, self.step, grad_scale=scale, grad_clip=clip)
+        eng.clamp(self.state[:nl], 0.0, float('inf') if self.max_lr is None else float(self.max_lr))
+        self.grad.zero_()
+        self._push_state()
+
+
+def shard_tasks(n_tasks, rank, world):
+    """Rank r of R takes tasks {r, r+R, ...} (`meta_run.py:39`)."""
+    return list(range(rank, n_tasks, world))

@@ -90,6 +90,12 @@ int eosvos_forward(eosvos_engine* e, const float* images, int batch, float* logi
 /* Fused BCE-with-logits (mean over B*H*W, helper_func.py:32-37) of the last forward and
  * its gradient.  loss_out: one device float (may be NULL). */
 int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss_out);
+/* Stand-alone BCE-with-logits mean over n elements of caller tensors (compute_loss with
+ * `batch_average: False` per sample, helper_func.py:36-39; run_loader metrics :131-134).
+ * dlogits_out may be NULL (engine scratch is used; a pending eosvos_loss_bce gradient is
+ * then invalidated). */
+int eosvos_bce(eosvos_engine* e, const float* logits, const float* masks, int64_t n,
+               float* loss_out, float* dlogits_out);
 /* autograd.grad + theta <- theta - lr (.) grad (meta_optim.py:177-214,
  * meta_model.py:78-80), using the gradient left by eosvos_loss_bce.
  * accumulate != 0 additionally adds the step's gradients into the task's sum_k g_k

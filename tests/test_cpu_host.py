@@ -1,0 +1,169 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares (no compute calls), its topology table agrees with the Python mirror, the
+golden layout and the oracle, the product never imports the oracle, and the N>1 outer-step
+logic (task sharding + all-reduce + identical update on every rank) under gloo."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, 'e-osvos_amd', 'libeosvos.so')):
+        ge.build()
+    from eosvos_amd import _ffi
+    return _ffi.load()
+
+
+def test_header_symbols_exported(lib):
+    from eosvos_amd import _ffi
+    hdr = open(os.path.join(ROOT, 'include', 'eosvos.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(eosvos_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/eosvos.h but not exported'
+    assert declared == _ffi.exported_symbols(), 'ctypes binding and header disagree'
+    assert b'gfx950' in lib.eosvos_version()
+
+
+def test_topology_c_vs_python_vs_golden(lib, golden_dir):
+    from eosvos_amd import topology
+    g = json.load(open(os.path.join(golden_dir, 'g1_layout.json')))
+    for enc, arch in (('resnet50', 50), ('resnet101', 101)):
+        infos = topology.conv_infos(enc)
+        assert lib.eosvos_num_convs(arch) == len(infos) == len(g[enc + '_convs'])
+        off = 0
+        for i, c in enumerate(infos):
+            buf = (ctypes.c_int64 * 9)()
+            assert lib.eosvos_conv_info(arch, i, buf) == 0
+            assert list(buf)[:8] == [c.cin, c.cout, c.k, c.stride, c.dil, c.pad, int(c.norm is not None), int(c.bias)]
+            assert buf[8] == off
+            off += c.cout * c.cin * c.k * c.k + (c.cout if c.bias else 0)
+            assert g[enc + '_convs'][i] == [c.name, c.cin, c.cout, c.k, c.stride, c.dil, c.pad, c.bias]
+        assert lib.eosvos_param_count(arch) == off
+        assert lib.eosvos_lr_count(arch) == sum(s[0] for _, s in topology.trainable(enc))
+        assert lib.eosvos_norm_count(arch) == sum(c for _, c in topology.norm_layers(enc))
+    assert lib.eosvos_param_count(50) == 40289729 and lib.eosvos_lr_count(50) == 28658
+    assert lib.eosvos_num_convs(7) == -1
+    assert lib.eosvos_conv_info(50, 999, (ctypes.c_int64 * 9)()) != 0
+    assert b'index' in lib.eosvos_last_error()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'e-osvos_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), fn
+    for fn in os.listdir(os.path.join(pkg, 'csrc')):
+        assert 'oracle' not in open(os.path.join(pkg, 'csrc', fn), errors='ignore').read().lower() or fn == 'Makefile'
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from eosvos_amd import _ffi
+    from eosvos_amd.engine import Engine
+    with pytest.raises(_ffi.EosvosError):
+        Engine('resnet50', 96, 160, 1)
+
+
+def test_checkpoint_layout_compatible(golden_dir):
+    """A `.model` file written by the reference's MetaOptimizer.state_dict() layout loads, and
+    our state dict has the same key structure (train_meta.py:277-286)."""
+    ck = torch.load(os.path.join(golden_dir, 'g11_last_meta_iter.model'), weights_only=False)
+    assert set(ck) == {'meta_optim_state_dict', 'vis_win_names', 'meta_iter', 'meta_epoch'}
+    keys = json.load(open(os.path.join(golden_dir, 'g11_keys.json')))['keys']
+    assert [k for k, _ in keys] == list(ck['meta_optim_state_dict'])
+    n = len(keys) // 2
+    assert all(k.startswith('log_init_lr_') for k, _ in keys[:n])
+    assert all(k.startswith('model_init_') for k, _ in keys[n:])
+    from eosvos_amd.checkpoint import save_meta_checkpoint, load_meta_checkpoint
+    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'eosvos_ck_test.model')
+    save_meta_checkpoint(path, ck['meta_optim_state_dict'], meta_iter=7, meta_epoch=2, vis_win_names={'dummy': 'w'})
+    sd, info = load_meta_checkpoint(path)
+    assert list(sd) == list(ck['meta_optim_state_dict']) and info['meta_iter'] == 7
+    for k in sd:
+        assert torch.equal(sd[k], ck['meta_optim_state_dict'][k])
+    os.remove(path)
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from eosvos_amd.meta_run import MetaTrainer, shard_tasks
+from oracle import meta as ometa
+
+class FakeEngine:
+    """CPU stand-in with the Engine surface MetaTrainer uses; RAdam through the oracle."""
+    encoder = 'resnet50'
+    def __init__(self):
+        self.n_lr, self.n_param, self.device = 8, 40, torch.device('cpu')
+        self.states = {{}}
+    def load_model_state(self, *a): pass
+    def set_lr(self, t): self.lr = t.clone()
+    def set_init(self, t): self.init = t.clone()
+    def meta_task_begin(self): pass
+    def finetune_step(self, *a, **k): pass
+    def meta_grad(self, xm, ym, flat):
+        flat += self.task_vec
+        return float(self.task_loss)
+    def radam_step(self, p, g, m, v, lr, wd, step, grad_scale=1.0, grad_clip=0.0):
+        gg = g * grad_scale
+        if grad_clip > 0: gg = gg.clamp(-grad_clip, grad_clip)
+        st = dict(step=step - 1, exp_avg=m, exp_avg_sq=v)
+        ometa.radam_step(p, gg, st, lr, wd)
+    def clamp(self, p, lo, hi): p.clamp_(lo, hi)
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+eng = FakeEngine()
+mt = MetaTrainer(eng, dist=dist, meta_batch_size=4, grad_clip=None)
+g0 = torch.Generator().manual_seed(0)
+mt.state.copy_(torch.rand(48, generator=g0))
+tasks = [torch.randn(48, generator=torch.Generator().manual_seed(100 + t)) for t in range(4)]
+mine = shard_tasks(4, rank, world)
+for it in range(7):
+    for t in mine:
+        eng.task_vec, eng.task_loss = tasks[t] * (it + 1), (float('nan') if (t == 3 and it == 2) else 0.5)
+        mt.run_task(None, None, None, None, inner_steps=0)
+    dist.all_reduce(mt.grad)
+    mt.outer_step()
+torch.save(dict(state=mt.state, mine=mine, skipped=mt.skipped_tasks), {out!r} + f'.{{rank}}')
+dist.destroy_process_group()
+'''
+
+
+def test_outer_step_two_ranks_gloo(tmp_path):
+    """world_size 2 on CPU: sharded tasks + all-reduce(sum) + the same RAdam step on every
+    rank == the single-process result; NaN-skipped task contributes zeros."""
+    out = str(tmp_path / 'res')
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', OMP_NUM_THREADS='1')
+    for world in (2, 1):
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE=str(world)))
+                 for r in range(world)]
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res = [torch.load(out + f'.{r}', weights_only=False) for r in range(world)]
+        if world == 2:
+            assert res[0]['mine'] == [0, 2] and res[1]['mine'] == [1, 3]
+            assert torch.equal(res[0]['state'], res[1]['state'])        # identical update, no broadcast
+            assert res[0]['skipped'] + res[1]['skipped'] == 1
+            two = res[0]['state']
+        else:
+            np.testing.assert_allclose(two.numpy(), res[0]['state'].numpy(), rtol=1e-6, atol=1e-8)
+            assert float(res[0]['state'][:8].min()) >= 0

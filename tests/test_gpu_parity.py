@@ -1,0 +1,291 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the golden fixtures
+generated from the reference.  Needs an MI355X:  pytest -m gpu.
+
+Tolerances (BASELINE.json north_star): logits within 1e-3 fp32 absolute, integer label maps
+bit-exact after thresholding except where the oracle's own |logit| is within rounding of 0
+(the fixtures record that count); gradients/parameters relative to the tensor's max."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from eosvos_amd import synthetic, topology
+
+pytestmark = pytest.mark.gpu
+
+SMALL = (96, 160)
+FULL = (480, 854)
+DEV = 'cuda:0'
+LOGIT_TOL = 1e-3
+
+
+def fp(t):
+    t = t.detach().double().flatten().cpu()
+    idx = torch.linspace(0, t.numel() - 1, 16).long()
+    return np.concatenate([[t.sum().item(), t.norm().item()], t[idx].numpy()])
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+@pytest.fixture(scope='module')
+def weights():
+    return synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50')
+
+
+@pytest.fixture(scope='module')
+def small_engine(weights):
+    from eosvos_amd.engine import Engine
+    eng = Engine('resnet50', *SMALL, max_batch=3, device=DEV)
+    eng.load_model_state(*weights)
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope='module')
+def full_engine(weights):
+    from eosvos_amd.engine import Engine
+    eng = Engine('resnet50', *FULL, max_batch=3, device=DEV)
+    eng.load_model_state(*weights)
+    yield eng
+    eng.close()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, d, p     (every conv class of SURVEY.md Appendix B + ragged edges)
+    (1, 12, 20, 64, 64, 1, 1, 1, 0),
+    (2, 12, 20, 64, 128, 3, 1, 1, 1),
+    (1, 13, 21, 128, 64, 3, 2, 1, 1),
+    (1, 12, 21, 64, 256, 1, 2, 1, 0),
+    (1, 10, 14, 256, 128, 3, 1, 2, 2),
+    (1, 30, 54, 128, 64, 3, 1, 18, 18),
+    (1, 9, 11, 304, 256, 3, 1, 1, 1),
+    (2, 9, 11, 256, 48, 1, 1, 1, 0),
+    (1, 16, 16, 2048, 256, 3, 1, 6, 6),
+    (3, 24, 40, 64, 64, 3, 1, 1, 1),
+    (1, 5, 7, 1280, 256, 1, 1, 1, 0),
+    (1, 3, 3, 64, 64, 3, 1, 8, 8),          # every non-centre tap falls in the padding
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_ops(small_engine, case):
+    B, H, W, Ci, Co, k, s, d, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    a = torch.rand(Co, generator=g) + 0.5
+    b = torch.randn(Co, generator=g)
+    y = F.conv2d(x, w, None, s, p, d)
+    res = torch.randn_like(y)
+    ref = F.relu(y * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1) + res)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = small_engine.test_conv(nhwc(x), w.to(DEV), a.to(DEV), b.to(DEV), nhwc(res), True, s, d, p)
+    assert relerr(out.permute(0, 3, 1, 2), ref) < 2e-5
+    gy = torch.randn_like(y)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, s, p, d).backward(gy)
+    dx, dw = small_engine.test_conv_bwd(nhwc(x), w.to(DEV), nhwc(gy), s, d, p)
+    assert relerr(dx.permute(0, 3, 1, 2), xr.grad) < 2e-5
+    assert relerr(dw, wr.grad) < 2e-5
+
+
+def test_forward_small_vs_golden(small_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g2_forward.npz'))
+    x, _ = synthetic.synthetic_frames(2, *SMALL, seed=7)
+    small_engine.reset()
+    out = small_engine.forward(x.to(DEV)).cpu().numpy()
+    ref = g['small_bn_logits']
+    assert np.abs(out - ref).max() < LOGIT_TOL
+    flips = ((out >= 0) != (ref >= 0)).sum()
+    assert flips <= (np.abs(ref) < 1e-4).sum()
+    for name, key in (('p1', 'stem'), ('blk2.out', 'layer1'), ('blk6.out', 'layer2'), ('blk12.out', 'layer3'),
+                      ('blk15.out', 'layer4'), ('proj', 'aspp'), ('lowlog', 'low_logits')):
+        a, b = fp(small_engine.debug_tensor(name)), g[f'small_bn_tap_{key}']
+        assert abs(a[1] - b[1]) <= 1e-4 * abs(b[1]), (key, a[1], b[1])
+        assert np.abs(a[2:] - b[2:]).max() <= 1e-4 * max(np.abs(b[2:]).max(), 1e-3), key
+
+
+def test_forward_full_vs_golden(full_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g2_forward.npz'))
+    x, _ = synthetic.synthetic_frames(1, *FULL, seed=7)
+    full_engine.reset()
+    out = full_engine.forward(x.to(DEV)).cpu()
+    assert np.abs(out[0, 0, ::8, ::7].numpy() - g['full_bn_logits_sub']).max() < LOGIT_TOL
+    mask = np.packbits((out >= 0).numpy().astype(np.uint8))
+    diff = int(np.unpackbits(mask ^ g['full_bn_mask']).sum())
+    assert diff <= int(g['full_bn_near_zero'][0]), diff
+    a, b = fp(out), g['full_bn_logits_fp']
+    assert abs(a[1] - b[1]) <= 1e-4 * abs(b[1])
+    # inference post-processing: sigmoid + threshold == logits >= 0
+    probs = full_engine.infer(x.to(DEV)).cpu()
+    assert torch.equal(probs >= 0.5, out >= 0)
+    assert float((probs - torch.sigmoid(out)).abs().max()) < 1e-6
+
+
+def test_loss_and_grad_vs_golden(small_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g3_loss.npz'))
+    lg, gt = torch.from_numpy(g['logits']).to(DEV), torch.from_numpy(g['gt']).to(DEV)
+    loss = small_engine.bce(lg, gt)
+    assert abs(float(loss) - g['mean'][0]) < 2e-6 * max(1.0, abs(g['mean'][0]))
+    for b in range(lg.shape[0]):
+        assert abs(float(small_engine.bce(lg[b], gt[b])) - g['per_sample'][b]) < 2e-6 * max(1.0, g['per_sample'][b])
+
+
+def test_gradients_and_finetune_small_vs_golden(small_engine, weights, golden_dir):
+    """G4 + reduced C2 (T=5, B=3, fresh frames each iteration)."""
+    g = np.load(os.path.join(golden_dir, 'g45_finetune.npz'))
+    eng = small_engine
+    tr = topology.trainable('resnet50')
+    batches = [synthetic.synthetic_frames(3, *SMALL, seed=7 + it) for it in range(5)]
+    eng.reset()
+    eng.keep_grads(True)
+    losses = []
+    for it, (x, y) in enumerate(batches):
+        losses.append(eng.finetune_step(x.to(DEV), y.to(DEV)))
+        if it == 0:
+            grads = eng.get_grads().cpu()
+    eng.keep_grads(False)
+    np.testing.assert_allclose(losses, g['small_losses'], rtol=5e-4, atol=1e-5)
+    offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr])
+    for i in g['small_ids']:
+        ref = g[f'small_grad_{i}']
+        got = grads[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, tr[i][0]
+    ref_fp = g['small_grad_fp']
+    for i, (n, s) in enumerate(tr):
+        l2 = float(grads[offs[i]:offs[i + 1]].double().norm())
+        assert abs(l2 - ref_fp[i][1]) <= 1e-2 * ref_fp[i][1] + 1e-9, (n, l2, ref_fp[i][1])
+    params = eng.get_params().cpu()
+    for i in g['small_ids']:
+        ref = g[f'small_param_{i}']
+        got = params[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), tr[i][0]
+    out = eng.forward(batches[0][0].to(DEV)).cpu().numpy()
+    assert np.abs(out - g['small_final_logits']).max() < 5e-3
+
+
+def test_c1_finetune_full_vs_golden(full_engine, golden_dir):
+    """BASELINE configs[0]: 480x854, T=10, B=1 -- loss per iteration, final mask."""
+    g = np.load(os.path.join(golden_dir, 'g45_finetune.npz'))
+    eng = full_engine
+    x, y = synthetic.synthetic_frames(1, *FULL, seed=7)
+    xg, yg = x.to(DEV), y.to(DEV)
+    eng.reset()
+    losses = [eng.finetune_step(xg, yg) for _ in range(10)]
+    np.testing.assert_allclose(losses, g['c1_losses'], rtol=1e-3)
+    out = eng.forward(xg).cpu()
+    sub = out[0, 0, ::8, ::7].numpy()
+    assert np.abs(sub - g['c1_final_logits_sub']).max() < 2e-2      # 10 SGD steps amplify rounding
+    mask = np.packbits((out >= 0).numpy().astype(np.uint8))
+    diff = int(np.unpackbits(mask ^ g['c1_final_mask']).sum())
+    near = int((np.abs(g['c1_final_logits_sub']) < 2e-2).mean() * out.numel()) + int(g['c1_final_near_zero'][0])
+    assert diff <= max(near, 8), (diff, near)
+    tr = topology.trainable('resnet50')
+    offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr])
+    params = eng.get_params().cpu()
+    for i in range(len(tr)):
+        l2 = float(params[offs[i]:offs[i + 1]].double().norm())
+        assert abs(l2 - g['c1_param_fp'][i][1]) <= 1e-3 * g['c1_param_fp'][i][1], tr[i][0]
+
+
+def test_full_size_properties(full_engine):
+    """Size-independent properties at BASELINE's full size and batch (B=3): determinism,
+    reset/snapshot idempotence, batch independence of the forward pass."""
+    eng = full_engine
+    x, y = synthetic.synthetic_frames(3, *FULL, seed=11)
+    xg, yg = x.to(DEV), y.to(DEV)
+    eng.reset()
+    l0 = [eng.finetune_step(xg, yg) for _ in range(2)]
+    p0 = eng.get_params().clone()
+    eng.snapshot()
+    eng.finetune_step(xg, yg)
+    eng.restore()
+    assert torch.equal(eng.get_params(), p0)
+    eng.reset()
+    l1 = [eng.finetune_step(xg, yg) for _ in range(2)]
+    assert l0 == l1 and torch.equal(eng.get_params(), p0)       # bitwise reproducible
+    assert l0[1] < l0[0]
+    full = eng.forward(xg)
+    single = eng.forward(xg[1:2].contiguous())
+    assert float((full[1:2] - single).abs().max()) < 1e-5
+
+
+def test_merge_labels_vs_golden(small_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g6_merge.npz'))
+    for c in range(g['probs'].shape[0]):
+        lab = small_engine.merge_labels(torch.from_numpy(g['probs'][c]).to(DEV))
+        assert np.array_equal(lab.cpu().numpy(), g['labels'][c])
+
+
+@pytest.mark.parametrize('K', [2, 5])
+def test_meta_task_vs_golden(small_engine, weights, golden_dir, K):
+    g = np.load(os.path.join(golden_dir, 'g7_meta_task.npz'))
+    eng = small_engine
+    eng.load_model_state(*weights)
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1000 + K)
+    xm, ym = torch.flip(x, dims=[3]).contiguous(), torch.flip(y, dims=[3]).contiguous()
+    xg, yg = x.to(DEV), y.to(DEV)
+    eng.meta_task_begin()
+    tl = [eng.finetune_step(xg, yg, accumulate=True) for _ in range(K)]
+    flat = torch.zeros(eng.n_lr + eng.n_param, device=DEV)
+    ml = eng.meta_grad(xm.to(DEV), ym.to(DEV), flat)
+    np.testing.assert_allclose(tl, g[f'k{K}_train_losses'], rtol=5e-4)
+    assert abs(ml - g[f'k{K}_meta_loss'][0]) <= 5e-4 * abs(g[f'k{K}_meta_loss'][0])
+    flat = flat.cpu()
+    ref = g[f'k{K}_lr_grad']
+    lr_g = flat[:eng.n_lr].numpy()
+    assert np.abs(lr_g - ref).max() <= 5e-3 * np.abs(ref).max(), np.abs(lr_g - ref).max() / np.abs(ref).max()
+    tr = topology.trainable('resnet50')
+    offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr]) + eng.n_lr
+    for i, (n, s) in enumerate(tr):
+        l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
+        r = g[f'k{K}_init_grad_fp'][i][1]
+        assert abs(l2 - r) <= 1e-2 * r + 1e-9, (n, l2, r)
+    last = flat[offs[-3]:offs[-2]].view(*g[f'k{K}_init_grad_last'].shape).numpy()
+    assert np.abs(last - g[f'k{K}_init_grad_last']).max() <= 5e-3 * np.abs(g[f'k{K}_init_grad_last']).max()
+    # adding a second time doubles (the call ADDS into the flat buffer)
+    eng.load_model_state(*weights)
+
+
+def test_radam_vs_golden(small_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g8_radam.npz'))
+    eng = small_engine
+    ps = [torch.from_numpy(g[f'p0_{i}'].copy()).to(DEV) for i in range(3)]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    for step in range(8):
+        clip = 0.1 if step >= 6 else 0.0
+        for i in range(3):
+            gr = torch.from_numpy(g[f'g_{step}_{i}']).to(DEV)
+            eng.radam_step(ps[i], gr, ms[i], vs[i], 1e-5, 1e-3 if i > 0 else 0.0, step + 1,
+                           grad_scale=0.25, grad_clip=clip)
+        eng.clamp(ps[0], 0.0, float('inf'))
+        for i in range(3):
+            np.testing.assert_allclose(ps[i].cpu().numpy(), g[f'p_{step}_{i}'], rtol=2e-6, atol=1e-9)
+
+
+def test_meta_trainer_single_rank(small_engine, weights):
+    """Outer loop plumbing on one GPU: grads averaged, RAdam applied, state pushed back."""
+    from eosvos_amd.meta_run import MetaTrainer
+    eng = small_engine
+    mt = MetaTrainer(eng, dist=None, meta_batch_size=2)
+    mt.load_state(*weights)
+    s0 = mt.state.clone()
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=5)
+    xg, yg = x.to(DEV), y.to(DEV)
+    xm, ym = torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()
+    losses = mt.meta_iteration([(xg, yg, xm, ym), (xm, ym, xg, yg)], inner_steps=2)
+    assert all(np.isfinite(losses))
+    d = (mt.state - s0).abs()
+    assert float(d.max()) > 0 and bool(torch.isfinite(mt.state).all())
+    assert float(mt.state[:eng.n_lr].min()) >= 0
+    eng.reset()
+    assert torch.equal(eng.get_params(), mt.state[eng.n_lr:])    # new init pushed, layout round trip exact
+    sd = mt.state_dict()
+    assert list(sd)[0] == 'log_init_lr_backbone-conv1-weight' and len(sd) == 128
+    eng.load_model_state(*weights)
