@@ -208,6 +208,16 @@ int upload_resize(eosvos_engine* e, const HostResize& h, int in, int out, Resize
 
 // ---- conv helpers -----------------------------------------------------------------------------
 int ksteps_of(int T, int kc) { return T * ((kc + 31) / 32); }
+// EOSVOS_TRACE=1: one stderr line per MFMA launch (joined with rocprofv3's kernel trace by
+// tools/layer_report.py to get per-layer TFLOP/s)
+bool trace_on() {
+  static int on = -1;
+  if (on < 0) { const char* v = getenv("EOSVOS_TRACE"); on = (v && v[0] == '1') ? 1 : 0; }
+  return on == 1;
+}
+void trace(const char* kind, int ci, long M, long N, long K, int splits) {
+  if (trace_on()) fprintf(stderr, "EOSVOS_TRACE %s conv=%d M=%ld N=%ld K=%ld splits=%d flops=%.0f\n", kind, ci, M, N, K, splits, 2.0 * M * N * K);
+}
 
 void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi, float* y, int ldy, int B,
               const float* res, int ldres, bool relu) {
@@ -223,6 +233,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   a.scale = e->A_(ci); a.bias = e->B_(ci);
   a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
   a.splits = conv_pick_splits(a.M, a.N, ksteps_of(c.T(), c.cin));
+  trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, a.splits);
   launch_conv(a, e->s);
 }
 // gx[B,Hin,Win,cin] (ld ldgx) (+)= dgrad of conv ci applied to g[B,Ho,Wo,cout] (ld ldg)
@@ -241,6 +252,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
   a.res = add; a.ldres = ldadd;
   a.splits = conv_pick_splits(a.M, a.N, ksteps_of(c.T(), c.cout));
+  trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, a.splits);
   launch_conv(a, e->s);
 }
 // slabs of dW into ws_wg; returns the number of slabs
@@ -253,6 +265,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
   a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
   a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T());
+  trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits);
   launch_wgrad(a, e->s);
   return a.splits;
 }

@@ -1,0 +1,50 @@
+"""Join the engine's EOSVOS_TRACE launch log with a rocprofv3 kernel trace -> per-layer TFLOP/s.
+
+    EOSVOS_TRACE=1 rocprofv3 --kernel-trace --output-format csv -d out -- python3 bench.py ... 2> trace.log
+    python tools/layer_report.py out/*/*_kernel_trace.csv trace.log [n_last_steps]
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def main(trace_csv, log, steps=3):
+    rows = [r for r in csv.DictReader(open(trace_csv))]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    mf = [r for r in rows if 'conv_igemm_kernel' in r['Kernel_Name'] or 'wgrad_kernel<' in r['Kernel_Name']]
+    launches = []
+    for line in open(log, errors='ignore'):
+        m = re.search(r'EOSVOS_TRACE (\w+) conv=(\d+) M=(\d+) N=(\d+) K=(\d+) splits=(\d+) flops=(\d+)', line)
+        if m:
+            launches.append((m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)),
+                             int(m.group(6)), float(m.group(7))))
+    assert len(launches) == len(mf), (len(launches), len(mf))
+    # one step = from a conv=1 fwd launch to the next
+    starts = [i for i, l in enumerate(launches) if l[0] == 'fwd' and l[1] == 1]
+    per = starts[1] - starts[0] if len(starts) > 1 else len(launches)
+    agg = defaultdict(lambda: [0.0, 0.0, 0, None])
+    full = [s for s in starts if s + per <= len(launches)][-steps:]
+    for s in full:
+        for i in range(s, s + per):
+            k, ci, M, N, K, sp, fl = launches[i]
+            d = int(mf[i]['End_Timestamp']) - int(mf[i]['Start_Timestamp'])
+            a = agg[(i - s, k, ci)]
+            a[0] += d; a[1] += fl; a[2] += 1; a[3] = (M, N, K, sp, int(mf[i]['Grid_Size_X']) // 256)
+    tot_t = tot_f = 0
+    by_kind = defaultdict(lambda: [0.0, 0.0])
+    print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6}')
+    for (pos, k, ci), (t, f, n, info) in sorted(agg.items()):
+        us = t / n / 1e3
+        print(f'{pos:3d} {k:6} {ci:4d} {info[0]:7d} {info[1]:6d} {info[2]:6d} {info[3]:3d} {info[4]:5d} {us:8.1f} {f / t / 1e3:6.1f}')
+        tot_t += t / n; tot_f += f / n
+        by_kind[k][0] += t / n; by_kind[k][1] += f / n
+    print(f'MFMA kernels per step: {tot_t / 1e6:.2f} ms, {tot_f / 1e9:.1f} GFLOP, {tot_f / tot_t / 1e3:.1f} TF/s')
+    for k, (t, f) in by_kind.items():
+        print(f'  {k:6s} {t / 1e6:7.2f} ms {f / t / 1e3:6.1f} TF/s')
+    all_step = [r for r in rows]
+    print('all kernels in trace: %.2f ms' % (sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in all_step) / 1e6))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 3)
