@@ -33,16 +33,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__device__ __forceinline__ float conv_epilogue(const ConvArgs& p, float v, int m, int n) {
-  if (p.scale) v *= p.scale[n];
-  if (p.bias) v += p.bias[n];
-  if (p.res) v += p.res[(size_t)m * p.ldres + n];
-  if (p.accum) v += p.y[(size_t)m * p.ldy + n];
-  if (p.relu) v = fmaxf(v, 0.f);
-  if (p.mask && n >= p.mask_c0) v = (p.mask[(size_t)m * p.ldmask + n] > 0.f) ? v : 0.f;
+// ---- fused epilogue on 4 consecutive output channels ---------------------------------------
+__device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, int m, int n) {
+  if (p.scale) { const float4 s = ldg4(p.scale + n); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+  if (p.bias) { const float4 s = ldg4(p.bias + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+  if (p.res) { const float4 s = ldg4(p.res + (size_t)m * p.ldres + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+  if (p.accum) { const float4 s = ldg4(p.y + (size_t)m * p.ldy + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+  if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (p.mask && n >= p.mask_c0) {
+    const float4 s = ldg4(p.mask + (size_t)m * p.ldmask + n);
+    v.x = s.x > 0.f ? v.x : 0.f; v.y = s.y > 0.f ? v.y : 0.f; v.z = s.z > 0.f ? v.z : 0.f; v.w = s.w > 0.f ? v.w : 0.f;
+  }
   return v;
 }
 
+// Work decomposition ("stream-K"): the launch has nwg workgroups (<= 2 per CU, all resident);
+// the tiles x K-steps work units are dealt out in equal contiguous runs of `per` units, so a
+// workgroup walks through a few whole tiles plus at most one partial tile at each end of its
+// run.  Whole tiles get the fused epilogue directly; partial tiles are parked as raw fp32
+// slabs (ws[wg][0|1][BM][BN]) and conv_fixup_kernel sums them in workgroup order
+// (deterministic) and applies the epilogue.  This removes the 59-78 % wave-quantisation loss
+// a tile-per-workgroup grid has on 256 CUs for this network's shapes.
 template <int BN, bool KMAJOR>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int BM = 128, BK = 32;
@@ -51,6 +62,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int A_EL = BM * LDA;
   constexpr int B_EL = KMAJOR ? BK * LDB : BN * LDB;
   constexpr int STAGE = A_EL + B_EL;
+  constexpr int LDC = BN + 4;
+  static_assert(BM * LDC <= 2 * STAGE, "epilogue staging must fit the operand buffers");
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,188 +75,229 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
   const int ksteps = T * chunks;
   const int nt = (p.N + BN - 1) / BN;
   const int tiles = ((p.M + BM - 1) / BM) * nt;
+  const long U = (long)tiles * ksteps;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int z = bid / tiles;
-  const int tile = bid - z * tiles;
-  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
-  const int ks_begin = (int)(((long)ksteps * z) / p.splits);
-  const int ks_end = (int)(((long)ksteps * (z + 1)) / p.splits);
+  const long u_begin = (long)bid * p.per;
+  long u_end = u_begin + p.per;
+  if (u_end > U) u_end = U;
 
-  // ---- per-thread staging assignment ------------------------------------------------
   constexpr int AF4 = BK / 4, AROWS = 256 / AF4, APASS = BM / AROWS;   // 8, 32, 4
   const int a_c4 = tid % AF4, a_r = tid / AF4;
-  int a_sy0[APASS], a_sx0[APASS], a_img[APASS];
-  const int up = 1 << p.upshift;
-#pragma unroll
-  for (int i = 0; i < APASS; ++i) {
-    const int m = m0 + a_r + i * AROWS;
-    if (m < p.M) {
-      const int hw = p.Ho * p.Wo;
-      const int b = m / hw, rem = m - b * hw;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_sy0[i] = oy * p.mul + p.off0;
-      a_sx0[i] = ox * p.mul + p.off0;
-      a_img[i] = b * p.Hi * p.Wi;
-    } else {
-      a_sy0[i] = -(1 << 28);
-      a_sx0[i] = 0;
-      a_img[i] = 0;
-    }
-  }
   constexpr int BF4 = KMAJOR ? BN / 4 : BK / 4;
   constexpr int BROWS = 256 / BF4;
   constexpr int BPASS = (KMAJOR ? BK : BN) / BROWS;
   const int b_c4 = tid % BF4, b_r = tid / BF4;
+  const int up = 1 << p.upshift;
+  constexpr int TN = BN / 64;
 
-  float4 ra[APASS], rb[BPASS];
+  for (long u = u_begin; u < u_end;) {
+    const int tile = (int)(u / ksteps);
+    const int ks_begin = (int)(u - (long)tile * ksteps);
+    int ks_end = ksteps;
+    if ((long)ks_end - ks_begin > u_end - u) ks_end = ks_begin + (int)(u_end - u);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
 
-  auto load_tiles = [&](int ks) {
-    const int tap = ks / chunks;
-    const int c0 = (ks - tap * chunks) * BK;
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    const int dy = ky * p.kstep, dx = kx * p.kstep;
-    const bool cok = (c0 + a_c4 * 4) < p.Kc;
-    float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (KMAJOR && p.kscale && cok) ks4 = ldg4(p.kscale + c0 + a_c4 * 4);
+    int a_sy0[APASS], a_sx0[APASS], a_img[APASS];
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      const int sy = a_sy0[i] + dy, sx = a_sx0[i] + dx;
-      bool ok = cok && sy >= 0 && sx >= 0 && ((sy | sx) & (up - 1)) == 0;
-      const int iy = sy >> p.upshift, ix = sx >> p.upshift;
-      ok = ok && iy < p.Hi && ix < p.Wi;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = ldg4(p.x + (size_t)(a_img[i] + iy * p.Wi + ix) * p.ldx + c0 + a_c4 * 4);
-      if (KMAJOR) { v.x *= ks4.x; v.y *= ks4.y; v.z *= ks4.z; v.w *= ks4.w; }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KMAJOR) {
-        const int k = c0 + b_r + i * BROWS;
-        const int n = n0 + b_c4 * 4;
-        if (k < p.Kc && n < p.N) v = ldg4(p.w + ((size_t)k * T + tap) * p.wK + n);
+      const int m = m0 + a_r + i * AROWS;
+      if (m < p.M) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_sy0[i] = oy * p.mul + p.off0;
+        a_sx0[i] = ox * p.mul + p.off0;
+        a_img[i] = b * p.Hi * p.Wi;
       } else {
-        const int n = n0 + b_r + i * BROWS;
-        const int k = c0 + b_c4 * 4;
-        if (n < p.N && k < p.Kc) v = ldg4(p.w + ((size_t)n * T + tap) * p.wK + k);
+        a_sy0[i] = -(1 << 28);
+        a_sx0[i] = 0;
+        a_img[i] = 0;
       }
-      rb[i] = v;
     }
-  };
-  auto store_tiles = [&](int buf) {
-    float* As = smem + buf * STAGE;
-    float* Bs = As + A_EL;
+    float4 ra[APASS], rb[BPASS];
+    auto load_tiles = [&](int ks) {
+      const int tap = ks / chunks;
+      const int c0 = (ks - tap * chunks) * BK;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const int dy = ky * p.kstep, dx = kx * p.kstep;
+      const bool cok = (c0 + a_c4 * 4) < p.Kc;
+      float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (KMAJOR && p.kscale && cok) ks4 = ldg4(p.kscale + c0 + a_c4 * 4);
 #pragma unroll
-    for (int i = 0; i < APASS; ++i)
-      *reinterpret_cast<float4*>(As + (a_r + i * AROWS) * LDA + a_c4 * 4) = ra[i];
+      for (int i = 0; i < APASS; ++i) {
+        const int sy = a_sy0[i] + dy, sx = a_sx0[i] + dx;
+        bool ok = cok && sy >= 0 && sx >= 0 && ((sy | sx) & (up - 1)) == 0;
+        const int iy = sy >> p.upshift, ix = sx >> p.upshift;
+        ok = ok && iy < p.Hi && ix < p.Wi;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = ldg4(p.x + (size_t)(a_img[i] + iy * p.Wi + ix) * p.ldx + c0 + a_c4 * 4);
+        if (KMAJOR) { v.x *= ks4.x; v.y *= ks4.y; v.z *= ks4.z; v.w *= ks4.w; }
+        ra[i] = v;
+      }
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i)
-      *reinterpret_cast<float4*>(Bs + (b_r + i * BROWS) * LDB + b_c4 * 4) = rb[i];
-  };
-
-  constexpr int TN = BN / 64;   // 32-wide accumulator columns per wave
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  if (ks_begin < ks_end) {
-    load_tiles(ks_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-
-  for (int ks = ks_begin; ks < ks_end; ++ks) {
-    const int buf = (ks - ks_begin) & 1;
-    const bool more = (ks + 1) < ks_end;
-    if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
-    const float* As = smem + buf * STAGE;
-    const float* Bs = As + A_EL;
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 a4[2];
-      float bv[TN][4];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-        a4[tm] = *reinterpret_cast<const float4*>(As + (wm * 64 + tm * 32 + r) * LDA + kk * 8 + h * 4);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
+      for (int i = 0; i < BPASS; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KMAJOR) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            bv[tn][j] = Bs[(kk * 8 + h * 4 + j) * LDB + wn * (BN / 2) + tn * 32 + r];
+          const int k = c0 + b_r + i * BROWS;
+          const int n = n0 + b_c4 * 4;
+          if (k < p.Kc && n < p.N) v = ldg4(p.w + ((size_t)k * T + tap) * p.wK + n);
         } else {
-          const float4 t = *reinterpret_cast<const float4*>(Bs + (wn * (BN / 2) + tn * 32 + r) * LDB + kk * 8 + h * 4);
-          bv[tn][0] = t.x; bv[tn][1] = t.y; bv[tn][2] = t.z; bv[tn][3] = t.w;
+          const int n = n0 + b_r + i * BROWS;
+          const int k = c0 + b_c4 * 4;
+          if (n < p.N && k < p.Kc) v = ldg4(p.w + ((size_t)n * T + tap) * p.wK + k);
         }
+        rb[i] = v;
       }
+    };
+    auto store_tiles = [&](int buf) {
+      float* As = smem + buf * STAGE;
+      float* Bs = As + A_EL;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int i = 0; i < APASS; ++i)
+        *reinterpret_cast<float4*>(As + (a_r + i * AROWS) * LDA + a_c4 * 4) = ra[i];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          const float av = j == 0 ? a4[tm].x : j == 1 ? a4[tm].y : j == 2 ? a4[tm].z : a4[tm].w;
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(av, bv[tn][j], acc[tm][tn]);
-        }
-      }
-    }
-    if (more) store_tiles(buf ^ 1);
-    __syncthreads();
-  }
+      for (int i = 0; i < BPASS; ++i)
+        *reinterpret_cast<float4*>(Bs + (b_r + i * BROWS) * LDB + b_c4 * 4) = rb[i];
+    };
 
-  // ---- epilogue: lane holds column n = r of 16 rows per accumulator -------------------
+    f32x16 acc[2][TN];
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int n = n0 + wn * (BN / 2) + tn * 32 + r;
-      if (n >= p.N) continue;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        const float v = acc[tm][tn][e];
-        if (p.splits > 1) p.ws[((size_t)z * p.M + m) * p.N + n] = v;
-        else p.y[(size_t)m * p.ldy + n] = conv_epilogue(p, v, m, n);
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tiles(ks_begin);
+    __syncthreads();            // previous segment's epilogue reads of smem are done
+    store_tiles(0);
+    __syncthreads();
+
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const int buf = (ks - ks_begin) & 1;
+      const bool more = (ks + 1) < ks_end;
+      if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
+      const float* As = smem + buf * STAGE;
+      const float* Bs = As + A_EL;
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        float4 a4[2];
+        float bv[TN][4];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          a4[tm] = *reinterpret_cast<const float4*>(As + (wm * 64 + tm * 32 + r) * LDA + kk * 8 + h * 4);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          if (KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              bv[tn][j] = Bs[(kk * 8 + h * 4 + j) * LDB + wn * (BN / 2) + tn * 32 + r];
+          } else {
+            const float4 t = *reinterpret_cast<const float4*>(Bs + (wn * (BN / 2) + tn * 32 + r) * LDB + kk * 8 + h * 4);
+            bv[tn][0] = t.x; bv[tn][1] = t.y; bv[tn][2] = t.z; bv[tn][3] = t.w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            const float av = j == 0 ? a4[tm].x : j == 1 ? a4[tm].y : j == 2 ? a4[tm].z : a4[tm].w;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(av, bv[tn][j], acc[tm][tn]);
+          }
+        }
       }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
     }
+
+    // ---- epilogue: accumulators -> LDS tile -> full-row float4 stores ------------------------
+    float* Cs = smem;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          Cs[(wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (BN / 2) + tn * 32 + r] = acc[tm][tn][e];
+    __syncthreads();
+    const bool full = (ks_begin == 0 && ks_end == ksteps);
+    constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
+    const int c_c4 = tid % CF4, c_r = tid / CF4;
+    if (full) {
+      const int n = n0 + c_c4 * 4;
+      if (n < p.N) {
+#pragma unroll 4
+        for (int row = c_r; row < BM; row += CROWS) {
+          const int m = m0 + row;
+          if (m >= p.M) break;
+          const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c_c4 * 4);
+          *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + n) = conv_epilogue4(p, v, m, n);
+        }
+      }
+    } else {
+      float* slab = p.ws + ((size_t)bid * 2 + (u == u_begin ? 0 : 1)) * (BM * BN);
+#pragma unroll 4
+      for (int row = c_r; row < BM; row += CROWS)
+        *reinterpret_cast<float4*>(slab + row * BN + c_c4 * 4) = *reinterpret_cast<const float4*>(Cs + row * LDC + c_c4 * 4);
+    }
+    u += ks_end - ks_begin;
+  }
 }
 
-// Sum the split-K slabs and apply the fused epilogue.  One thread per 4 output channels.
-__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArgs p) {
-  const long total4 = (long)p.M * (p.N >> 2);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int n4 = p.N >> 2;
-    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+// Sum the parked partial tiles in workgroup order and apply the fused epilogue.
+template <int BN>
+__global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
+  constexpr int BM = 128, BK = 32;
+  const int T = p.KH * p.KW;
+  const int ksteps = T * ((p.Kc + BK - 1) / BK);
+  const int nt = (p.N + BN - 1) / BN;
+  const int tile = blockIdx.x;
+  const long a = (long)tile * ksteps, b = a + ksteps;
+  const int g0 = (int)(a / p.per), g1 = (int)((b - 1) / p.per);
+  if (g0 == g1) return;                       // computed whole by one workgroup
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
+  const int c_c4 = threadIdx.x % CF4, c_r = threadIdx.x / CF4;
+  const int n = n0 + c_c4 * 4;
+  if (n >= p.N) return;
+  for (int row = c_r; row < BM; row += CROWS) {
+    const int m = m0 + row;
+    if (m >= p.M) break;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < p.splits; ++z) {
-      const float4 t = ldg4(p.ws + ((size_t)z * p.M + m) * p.N + n);
+    for (int g = g0; g <= g1; ++g) {
+      const int slot = ((long)g * p.per >= a) ? 0 : 1;
+      const float4 t = ldg4(p.ws + ((size_t)g * 2 + slot) * (BM * BN) + row * BN + c_c4 * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    float o[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = conv_epilogue(p, o[j], m, n + j);
-    *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + n) = conv_epilogue4(p, s, m, n);
   }
 }
 
-int conv_pick_splits(int M, int N, int ksteps) {
-  const int bn = (N > 64) ? 128 : 64;
-  const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
-  // aim for >= ~2 workgroups per CU (512 resident slots) but keep >= 8 K-steps per split
-  int s = 1;
-  while (tiles * s < 384 && ksteps / (s * 2) >= 8 && s < 32) s *= 2;
-  return s;
+#define CONV_MAX_WG 512
+int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG * 2 * 128 * 128; }
+
+// returns the number of workgroups; fills a.per
+int conv_plan(ConvArgs& a) {
+  const int bn = (a.N > 64) ? 128 : 64;
+  const int T = a.KH * a.KW;
+  const int ksteps = T * ((a.Kc + 31) / 32);
+  const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  const long U = tiles * ksteps;
+  long nwg = CONV_MAX_WG;
+  // keep at least ~6 K-steps per workgroup (pipeline fill + epilogue amortisation)
+  if (U / nwg < 6) nwg = U / 6 > 0 ? U / 6 : 1;
+  long per = (U + nwg - 1) / nwg;
+  nwg = (U + per - 1) / per;
+  a.per = (int)per;
+  return (int)nwg;
 }
 
-void launch_conv(const ConvArgs& a, hipStream_t s) {
+void launch_conv(ConvArgs& a, hipStream_t s) {
   const int bn = (a.N > 64) ? 128 : 64;
-  const int tiles = ((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
-  const dim3 grid(tiles * a.splits), block(256);
+  const int nwg = conv_plan(a);
+  const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  const dim3 grid(nwg), block(256);
   if (a.kmajor) {
     if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, block, 0, s, a);
@@ -251,11 +305,11 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, block, 0, s, a);
   }
-  if (a.splits > 1) {
-    const long total4 = (long)a.M * (a.N >> 2);
-    int blocks = (int)((total4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a);
+  const int T = a.KH * a.KW;
+  const long ksteps = (long)T * ((a.Kc + 31) / 32);
+  if (a.per % ksteps != 0) {   // some tile is shared between workgroups
+    if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)tiles), block, 0, s, a);
+    else hipLaunchKernelGGL((conv_fixup_kernel<64>), dim3((unsigned)tiles), block, 0, s, a);
   }
 }
 
@@ -390,9 +444,17 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
   const int bm = Cout > 64 ? 128 : 64, bn = Cin > 64 ? 128 : 64;
   const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
   const int steps = (P + 31) / 32;
-  int s = 1;
-  while (tiles * s < 512 && steps / (s * 2) >= 8 && s < 256) s *= 2;
-  return s;
+  // pick the K split so that tiles*S fills whole rounds of the 512 resident workgroups
+  int best = 1;
+  double best_eff = 0.0;
+  for (int s = 1; s <= 512 && steps / s >= 4; ++s) {
+    const long wgs = (long)tiles * s;
+    const long rounds = (wgs + 511) / 512;
+    const double eff = (double)wgs / (double)(rounds * 512);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    if (eff >= 0.93) { best = s; break; }
+  }
+  return best;
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {

@@ -232,8 +232,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   a.M = B * a.Ho * a.Wo; a.wN = c.cout; a.wK = c.cin; a.kmajor = 0;
   a.scale = e->A_(ci); a.bias = e->B_(ci);
   a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
-  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(c.T(), c.cin));
-  trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, a.splits);
+  trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a));
   launch_conv(a, e->s);
 }
 // gx[B,Hin,Win,cin] (ld ldgx) (+)= dgrad of conv ci applied to g[B,Ho,Wo,cout] (ld ldg)
@@ -251,8 +250,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.kscale = e->A_(ci);
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
   a.res = add; a.ldres = ldadd;
-  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(c.T(), c.cout));
-  trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, a.splits);
+  trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
   launch_conv(a, e->s);
 }
 // slabs of dW into ws_wg; returns the number of slabs
@@ -341,13 +339,12 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   ALLOC(e->p1, n4 * 64); ALLOC(e->g_p1, n4 * 64);
   { float* t8; ALLOC(t8, (n4 * 64 + 3) / 4); e->p1idx = (uint8_t*)t8; }
 
-  int64_t wsc = 1, wsw = 1;
+  int64_t wsc = conv_ws_floats(), wsw = 1;
   auto track = [&](int ci, int Hin, int Win) {
     const ConvL& c = t.convs[ci];
     const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
     const int Mf = B * Ho * Wo, Md = B * Hin * Win;
-    wsc = max64(wsc, (int64_t)conv_pick_splits(Mf, c.cout, ksteps_of(c.T(), c.cin)) * Mf * c.cout);
-    wsc = max64(wsc, (int64_t)conv_pick_splits(Md, c.cin, ksteps_of(c.T(), c.cout)) * Md * c.cin);
+    (void)Md;
     wsw = max64(wsw, (int64_t)wgrad_pick_splits(Mf, c.cout, c.cin, c.T()) * c.wsize());
   };
   // bottleneck buffers
@@ -843,8 +840,7 @@ int eosvos_test_conv(eosvos_engine* e, const float* x, const float* w_oihw, cons
   a.N = Cout; a.ldy = Cout; a.KH = a.KW = k; a.mul = stride; a.off0 = -pad; a.kstep = dil;
   a.M = B * a.Ho * a.Wo; a.wN = Cout; a.wK = Cin; a.scale = scale; a.bias = bias; a.res = res; a.ldres = Cout;
   a.relu = relu;
-  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(T, Cin));
-  HIPOK(hipMalloc((void**)&ws, (size_t)a.splits * a.M * a.N * 4));
+  HIPOK(hipMalloc((void**)&ws, (size_t)conv_ws_floats() * 4));
   a.ws = ws;
   launch_conv(a, e->s);
   HIPOK(hipStreamSynchronize(e->s));
@@ -870,8 +866,7 @@ int eosvos_test_conv_bwd(eosvos_engine* e, const float* x, const float* w_oihw, 
   a.Ho = H; a.Wo = W; a.N = Cin; a.ldy = Cin; a.KH = a.KW = k; a.mul = 1; a.off0 = pad; a.kstep = -dil;
   a.upshift = stride == 2 ? 1 : 0;
   a.M = B * H * W; a.wN = Cout; a.wK = Cin; a.kmajor = 1;
-  a.splits = conv_pick_splits(a.M, a.N, ksteps_of(T, Cout));
-  HIPOK(hipMalloc((void**)&ws, (size_t)a.splits * a.M * a.N * 4));
+  HIPOK(hipMalloc((void**)&ws, (size_t)conv_ws_floats() * 4));
   a.ws = ws;
   launch_conv(a, e->s);
   WgradArgs g2;

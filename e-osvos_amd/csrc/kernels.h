@@ -23,7 +23,7 @@ struct ConvArgs {
   const float* x;       // gather source, NHWC, channel offset already applied
   const float* w;       // W[cout][T][cin]
   float* y;             // destination, NHWC, channel offset already applied
-  float* ws;            // split-K workspace [splits][M][N] (used when splits > 1)
+  float* ws;            // partial-tile slabs, conv_ws_floats() floats
   int B, Hi, Wi, ldx;   // source geometry, floats per source pixel
   int Kc;               // reduction channels per tap
   int Ho, Wo, N, ldy;   // destination geometry
@@ -41,11 +41,12 @@ struct ConvArgs {
   int ldmask, mask_c0;
   int relu;
   int accum;            // dgrad: add the existing contents of y
-  int splits;
+  int per;              // work units (tile x K-step) per workgroup, set by conv_plan
 };
-void launch_conv(const ConvArgs& a, hipStream_t s);
-// grid-size helper shared with the engine's workspace sizing
-int conv_pick_splits(int M, int N, int ksteps32);
+// fills a.per, launches the stream-K kernel (+ the fix-up kernel when tiles are shared)
+void launch_conv(ConvArgs& a, hipStream_t s);
+int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
+int64_t conv_ws_floats();            // size of ConvArgs::ws the launch may use
 
 // Weight gradient: ws[z][cout][tap][cin] = sum over the z-th pixel chunk of
 //   G[p][cout] * X[src(p,tap)][cin]
