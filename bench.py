@@ -119,7 +119,7 @@ def main():
                 'flops_per_launch': k_flops,
                 'whole_step_tflops': BATCH * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12}
 
-    extra = {'last_loss': last_loss}
+    extra = {'last_loss': last_loss, 'mfma_probe_tflops': eng.mfma_probe()}
     if not a.no_meta:
         # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4])
         mt = MetaTrainer(eng, dist=dist, meta_batch_size=world)

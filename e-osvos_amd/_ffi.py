@@ -53,6 +53,8 @@ _SIGNATURES = {
     'eosvos_clamp': (ctypes.c_int, [_E, c_float_p, ctypes.c_int64, ctypes.c_float, ctypes.c_float]),
     'eosvos_time_hot_kernel': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                               ctypes.POINTER(ctypes.c_double)]),
+    'eosvos_mfma_probe': (ctypes.c_int, [_E, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                         ctypes.POINTER(ctypes.c_double)]),
     'eosvos_debug_tensor': (ctypes.c_int, [_E, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p),
                                            ctypes.POINTER(ctypes.c_int64)]),
     'eosvos_test_conv': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,

@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
   const int tiles = ((p.M + BM - 1) / BM) * nt;
   const long U = (long)tiles * ksteps;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const long u_begin = (long)bid * p.per;
+  // data-parallel part: dp_q whole tiles per workgroup; stream-K part: `per` units of the rest
+  const long sk0 = (long)p.dp_q * gridDim.x * ksteps;
+  const long u_begin = sk0 + (long)bid * p.per;
   long u_end = u_begin + p.per;
   if (u_end > U) u_end = U;
+  int dp_i = 0;
 
   constexpr int AF4 = BK / 4, AROWS = 256 / AF4, APASS = BM / AROWS;   // 8, 32, 4
   const int a_c4 = tid % AF4, a_r = tid / AF4;
@@ -90,11 +93,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
   const int up = 1 << p.upshift;
   constexpr int TN = BN / 64;
 
-  for (long u = u_begin; u < u_end;) {
-    const int tile = (int)(u / ksteps);
-    const int ks_begin = (int)(u - (long)tile * ksteps);
-    int ks_end = ksteps;
-    if ((long)ks_end - ks_begin > u_end - u) ks_end = ks_begin + (int)(u_end - u);
+  for (long u = u_begin;;) {
+    int tile, ks_begin, ks_end = ksteps;
+    const bool dp = dp_i < p.dp_q;
+    if (dp) {
+      tile = bid * p.dp_q + dp_i;
+      ks_begin = 0;
+      ++dp_i;
+      if (tile >= tiles) continue;
+    } else if (u < u_end) {
+      tile = (int)(u / ksteps);
+      ks_begin = (int)(u - (long)tile * ksteps);
+      if ((long)ks_end - ks_begin > u_end - u) ks_end = ks_begin + (int)(u_end - u);
+    } else {
+      break;
+    }
     const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
 
     int a_sy0[APASS], a_sx0[APASS], a_img[APASS];
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
       for (int row = c_r; row < BM; row += CROWS)
         *reinterpret_cast<float4*>(slab + row * BN + c_c4 * 4) = *reinterpret_cast<const float4*>(Cs + row * LDC + c_c4 * 4);
     }
-    u += ks_end - ks_begin;
+    if (!dp) u += ks_end - ks_begin;
   }
 }
 
@@ -252,21 +265,25 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   const int T = p.KH * p.KW;
   const int ksteps = T * ((p.Kc + BK - 1) / BK);
   const int nt = (p.N + BN - 1) / BN;
-  const int tile = blockIdx.x;
+  const int tile = p.dp_q * p.nwg + blockIdx.x;
+  const long sk0 = (long)p.dp_q * p.nwg * ksteps;
   const long a = (long)tile * ksteps, b = a + ksteps;
-  const int g0 = (int)(a / p.per), g1 = (int)((b - 1) / p.per);
+  const int g0 = (int)((a - sk0) / p.per), g1 = (int)((b - 1 - sk0) / p.per);
   if (g0 == g1) return;                       // computed whole by one workgroup
   const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
   constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
   const int c_c4 = threadIdx.x % CF4, c_r = threadIdx.x / CF4;
   const int n = n0 + c_c4 * 4;
   if (n >= p.N) return;
-  for (int row = c_r; row < BM; row += CROWS) {
+  // blockIdx.y selects one eighth of the tile's rows (more, shorter workgroups: the sum is
+  // latency bound)
+  for (int row = blockIdx.y * (BM / 8) + c_r; row < (blockIdx.y + 1) * (BM / 8); row += CROWS) {
     const int m = m0 + row;
     if (m >= p.M) break;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
     for (int g = g0; g <= g1; ++g) {
-      const int slot = ((long)g * p.per >= a) ? 0 : 1;
+      const int slot = (sk0 + (long)g * p.per >= a) ? 0 : 1;
       const float4 t = ldg4(p.ws + ((size_t)g * 2 + slot) * (BM * BN) + row * BN + c_c4 * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
@@ -277,19 +294,30 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
 #define CONV_MAX_WG 512
 int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG * 2 * 128 * 128; }
 
-// returns the number of workgroups; fills a.per
+// returns the number of workgroups; fills a.dp_q / a.per / a.nwg.
+//   tiles >= 512: each workgroup takes dp_q = tiles/512 whole tiles (no workspace traffic) and
+//                 the tiles%512 leftover tiles are streamed over all workgroups in equal K runs;
+//   tiles <  512: everything is streamed (K split across workgroups).
 int conv_plan(ConvArgs& a) {
   const int bn = (a.N > 64) ? 128 : 64;
   const int T = a.KH * a.KW;
-  const int ksteps = T * ((a.Kc + 31) / 32);
+  const long ksteps = (long)T * ((a.Kc + 31) / 32);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
-  const long U = tiles * ksteps;
-  long nwg = CONV_MAX_WG;
-  // keep at least ~6 K-steps per workgroup (pipeline fill + epilogue amortisation)
-  if (U / nwg < 6) nwg = U / 6 > 0 ? U / 6 : 1;
-  long per = (U + nwg - 1) / nwg;
-  nwg = (U + per - 1) / per;
-  a.per = (int)per;
+  long nwg = CONV_MAX_WG, q = 0, per = 0;
+  if (tiles >= nwg) {
+    q = tiles / nwg;
+    const long rem = tiles - q * nwg;
+    if (rem > 0) {
+      per = (rem * ksteps + nwg - 1) / nwg;
+      if (per < 2) { per = 0; q = (tiles + nwg - 1) / nwg; nwg = (tiles + q - 1) / q; }  // tiny K: whole tiles only
+    }
+  } else {
+    const long U = tiles * ksteps;
+    if (U / nwg < 6) nwg = U / 6 > 0 ? U / 6 : 1;     // >= ~6 K-steps per workgroup
+    per = (U + nwg - 1) / nwg;
+    nwg = (U + per - 1) / per;
+  }
+  a.dp_q = (int)q; a.per = (int)per; a.nwg = (int)nwg;
   return (int)nwg;
 }
 
@@ -307,9 +335,10 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   }
   const int T = a.KH * a.KW;
   const long ksteps = (long)T * ((a.Kc + 31) / 32);
-  if (a.per % ksteps != 0) {   // some tile is shared between workgroups
-    if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)tiles), block, 0, s, a);
-    else hipLaunchKernelGGL((conv_fixup_kernel<64>), dim3((unsigned)tiles), block, 0, s, a);
+  const long sk_tiles = tiles - (long)a.dp_q * nwg;
+  if (a.per > 0 && sk_tiles > 0 && a.per % ksteps != 0) {   // some tile is shared between workgroups
+    if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);
+    else hipLaunchKernelGGL((conv_fixup_kernel<64>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);
   }
 }
 
@@ -468,4 +497,39 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, block, 0, s, a);
 }
 
+}  // namespace eosvos
+
+// ---------------------------------------------------------------------------------------
+// Calibration probe: back-to-back v_mfma_f32_32x32x2_f32 on register operands (no memory),
+// 2 workgroups x 4 waves per CU like the conv kernels -- the fp32 matrix rate this chip
+// actually sustains at the clock it holds under load (roofline cross-check for bench.py).
+// ---------------------------------------------------------------------------------------
+namespace eosvos {
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(float* out, int iters, float seed) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = MFMA32(a, b, acc[i]);
+    }
+    a += 1e-6f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.678f) out[0] = s;   // keep the chain live
+}
+double launch_mfma_probe(float* scratch, int iters, hipStream_t s) {
+  const int wgs = 512;
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(wgs), dim3(256), 0, s, scratch, iters, 0.5f);
+  return (double)wgs * 4 /*waves*/ * iters * 16.0 * (2.0 * 32 * 32 * 2);
+}
 }  // namespace eosvos

@@ -779,6 +779,24 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
   return 0;
 }
 
+int eosvos_mfma_probe(eosvos_engine* e, int iters, float* ms_host, double* flops_host) {
+  if (!e || !ms_host || !flops_host || iters < 1) return fail("bad argument");
+  hipEvent_t a, b;
+  HIPOK(hipEventCreate(&a));
+  HIPOK(hipEventCreate(&b));
+  launch_mfma_probe(e->loss_dev, iters, e->s);   // warm
+  HIPOK(hipEventRecord(a, e->s));
+  const double fl = launch_mfma_probe(e->loss_dev, iters, e->s);
+  HIPOK(hipEventRecord(b, e->s));
+  HIPOK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPOK(hipEventElapsedTime(&ms, a, b));
+  *ms_host = ms;
+  *flops_host = fl;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return 0;
+}
 int eosvos_debug_tensor(eosvos_engine* e, const char* name, float** ptr, int64_t* dims4) {
   if (!e || !name || !ptr || !dims4) return fail("null argument");
   const int B = e->lastB > 0 ? e->lastB : 1;

@@ -41,11 +41,13 @@ struct ConvArgs {
   int ldmask, mask_c0;
   int relu;
   int accum;            // dgrad: add the existing contents of y
-  int per;              // work units (tile x K-step) per workgroup, set by conv_plan
+  int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
 };
 // fills a.per, launches the stream-K kernel (+ the fix-up kernel when tiles are shared)
 void launch_conv(ConvArgs& a, hipStream_t s);
 int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
+// calibration: back-to-back fp32 MFMAs, returns the FLOPs the launch performs
+double launch_mfma_probe(float* scratch, int iters, hipStream_t s);
 int64_t conv_ws_floats();            // size of ConvArgs::ws the launch may use
 
 // Weight gradient: ws[z][cout][tap][cin] = sum over the z-th pixel chunk of

@@ -599,8 +599,43 @@ __global__ void sgd_update_kernel(float* __restrict__ w, const float* __restrict
     if (gout) gout[e] = g;
   }
 }
+// 16-byte version: rowlen, slab and every base pointer are multiples of 4 floats, n < 2^31
+__global__ __launch_bounds__(256) void sgd_update4_kernel(float* __restrict__ w, const float* __restrict__ ws,
+                                                           int splits, int slab, const float* __restrict__ rowscale,
+                                                           const float* __restrict__ lr, float* __restrict__ gsum,
+                                                           float* __restrict__ gout, int rowlen, int n4) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+    const int e = i * 4;
+    float4 g = *reinterpret_cast<const float4*>(ws + e);
+    for (int z = 1; z < splits; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(ws + (size_t)z * slab + e);
+      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+    }
+    const int row = e / rowlen;
+    if (rowscale) { const float a = rowscale[row]; g.x *= a; g.y *= a; g.z *= a; g.w *= a; }
+    if (lr) {
+      const float l = lr[row];
+      float4 p = *reinterpret_cast<const float4*>(w + e);
+      p.x -= l * g.x; p.y -= l * g.y; p.z -= l * g.z; p.w -= l * g.w;
+      *reinterpret_cast<float4*>(w + e) = p;
+    }
+    if (gsum) {
+      float4 q = *reinterpret_cast<const float4*>(gsum + e);
+      q.x += g.x; q.y += g.y; q.z += g.z; q.w += g.w;
+      *reinterpret_cast<float4*>(gsum + e) = q;
+    }
+    if (gout) *reinterpret_cast<float4*>(gout + e) = g;
+  }
+}
 void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, const float* rowscale,
                        const float* lr, float* gsum, float* gout, int64_t rowlen, int64_t n, hipStream_t s) {
+  auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+  if ((rowlen & 3) == 0 && (slab & 3) == 0 && (n & 3) == 0 && n < (1LL << 31) && al(w) && al(ws) && al(gsum) &&
+      al(gout)) {
+    hipLaunchKernelGGL(sgd_update4_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, s, w, ws, splits,
+                       (int)slab, rowscale, lr, gsum, gout, (int)rowlen, (int)(n / 4));
+    return;
+  }
   hipLaunchKernelGGL(sgd_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, ws, splits, (long)slab,
                      rowscale, lr, gsum, gout, (long)rowlen, (long)n);
 }

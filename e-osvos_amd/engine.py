@@ -191,6 +191,12 @@ class Engine:
         _ffi.check(self.lib.eosvos_time_hot_kernel(self.h, batch, reps, ctypes.byref(ms), ctypes.byref(fl)))
         return ms.value, fl.value
 
+    def mfma_probe(self, iters=20000):
+        """Sustained fp32 MFMA TFLOP/s of this device (register-only calibration kernel)."""
+        ms, fl = ctypes.c_float(), ctypes.c_double()
+        _ffi.check(self.lib.eosvos_mfma_probe(self.h, iters, ctypes.byref(ms), ctypes.byref(fl)))
+        return fl.value / (ms.value * 1e-3) / 1e12
+
     def debug_tensor(self, name):
         """Copy of a named internal NHWC buffer as a (B,C,H,W) tensor (parity tests)."""
         ptr = ctypes.c_void_p()

@@ -144,6 +144,10 @@ int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi);
  * average milliseconds in *ms_host and the algorithmic FLOPs per launch in *flops_host. */
 int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host,
                            double* flops_host);
+/* Calibration: time one launch of `iters` x 16 back-to-back v_mfma_f32_32x32x2_f32 per wave on
+ * register operands (2 workgroups x 4 waves on every CU, no memory traffic): the fp32 matrix
+ * rate this device sustains at the clock it holds, next to the 157.3 TFLOP/s nominal peak. */
+int eosvos_mfma_probe(eosvos_engine* e, int iters, float* ms_host, double* flops_host);
 /* Device pointer + {B,H,W,C} of a named internal NHWC activation / gradient buffer of the
  * last forward/backward ("c1","p1","blk<i>.out","cat","proj","dcat","d1","d2","lowlog",
  * "logits", "g_*" ...), for the per-stage parity tests. */
