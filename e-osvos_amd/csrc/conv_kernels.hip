@@ -32,6 +32,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// 16-byte buffer load; offsets past the descriptor's size return 0 (hardware range check)
+__device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return *reinterpret_cast<float4*>(&v);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
 
 // ---- fused epilogue on 4 consecutive output channels ---------------------------------------
 __device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, int m, int n) {
@@ -92,6 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
   const int b_c4 = tid % BF4, b_r = tid / BF4;
   const int up = 1 << p.upshift;
   constexpr int TN = BN / 64;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (long)p.wN * T * p.wK * 4);
 
   for (long u = u_begin;;) {
     int tile, ks_begin, ks_end = ksteps;
@@ -128,38 +138,61 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
       }
     }
     float4 ra[APASS], rb[BPASS];
+    // Gather offsets (in floats, without the channel-chunk term) are cached per filter tap
+    // and re-derived only when the tap changes; loads are buffer loads whose hardware range
+    // check returns 0 for the deliberately out-of-range offset of padded / masked elements,
+    // so the K loop carries no divergent branches and ~10x less address arithmetic.
+    constexpr unsigned OOB = 0x80000000u;
+    int a_off[APASS];
+    int b_off[BPASS];   // weight offset without the (tap, chunk) term, or -1
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      if (KMAJOR) {
+        const int n = n0 + b_c4 * 4;
+        b_off[i] = n < p.N ? (b_r + i * BROWS) * T * p.wK + n : -1;
+      } else {
+        const int n = n0 + b_r + i * BROWS;
+        b_off[i] = n < p.N ? n * T * p.wK + b_c4 * 4 : -1;
+      }
+    }
+    int cur_tap = -1;
     auto load_tiles = [&](int ks) {
       const int tap = ks / chunks;
       const int c0 = (ks - tap * chunks) * BK;
-      const int ky = tap / p.KW, kx = tap - ky * p.KW;
-      const int dy = ky * p.kstep, dx = kx * p.kstep;
+      if (tap != cur_tap) {          // wave-uniform
+        cur_tap = tap;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int dy = ky * p.kstep, dx = kx * p.kstep;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+          const int sy = a_sy0[i] + dy, sx = a_sx0[i] + dx;
+          bool ok = sy >= 0 && sx >= 0 && ((sy | sx) & (up - 1)) == 0;
+          const int iy = sy >> p.upshift, ix = sx >> p.upshift;
+          ok = ok && iy < p.Hi && ix < p.Wi;
+          a_off[i] = ok ? (a_img[i] + iy * p.Wi + ix) * p.ldx + a_c4 * 4 : -1;
+        }
+      }
       const bool cok = (c0 + a_c4 * 4) < p.Kc;
       float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
       if (KMAJOR && p.kscale && cok) ks4 = ldg4(p.kscale + c0 + a_c4 * 4);
 #pragma unroll
       for (int i = 0; i < APASS; ++i) {
-        const int sy = a_sy0[i] + dy, sx = a_sx0[i] + dx;
-        bool ok = cok && sy >= 0 && sx >= 0 && ((sy | sx) & (up - 1)) == 0;
-        const int iy = sy >> p.upshift, ix = sx >> p.upshift;
-        ok = ok && iy < p.Hi && ix < p.Wi;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = ldg4(p.x + (size_t)(a_img[i] + iy * p.Wi + ix) * p.ldx + c0 + a_c4 * 4);
+        const unsigned off = (cok && a_off[i] >= 0) ? (unsigned)(a_off[i] + c0) * 4u : OOB;
+        float4 v = bufld4(rx, off);
         if (KMAJOR) { v.x *= ks4.x; v.y *= ks4.y; v.z *= ks4.z; v.w *= ks4.w; }
         ra[i] = v;
       }
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned off;
         if (KMAJOR) {
           const int k = c0 + b_r + i * BROWS;
-          const int n = n0 + b_c4 * 4;
-          if (k < p.Kc && n < p.N) v = ldg4(p.w + ((size_t)k * T + tap) * p.wK + n);
+          off = (b_off[i] >= 0 && k < p.Kc) ? (unsigned)(b_off[i] + (c0 * T + tap) * p.wK) * 4u : OOB;
         } else {
-          const int n = n0 + b_r + i * BROWS;
           const int k = c0 + b_c4 * 4;
-          if (n < p.N && k < p.Kc) v = ldg4(p.w + ((size_t)n * T + tap) * p.wK + k);
+          off = (b_off[i] >= 0 && k < p.Kc) ? (unsigned)(b_off[i] + tap * p.wK + c0) * 4u : OOB;
         }
-        rb[i] = v;
+        rb[i] = bufld4(rw, off);
       }
     };
     auto store_tiles = [&](int buf) {
