@@ -416,28 +416,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   const bool b_cok = (ci0 + b_c4 * 4) < p.Cin;
 
   float4 ra[APASS], rb[BPASS];
-  auto load_tiles = [&](int st) {
+  // Each staging row follows one pixel per K step: its (image, y, x) advances by BKP pixels
+  // per step with carries instead of divisions; masked / padded rows use the out-of-range
+  // offset of a range-checked buffer load (returns 0), so the loop has no divergent branches.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.g, (long)P * p.ldg * 4);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
+  int b_img[BPASS], b_oy[BPASS], b_ox[BPASS];
+  {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int px = st_begin * BKP + b_r + i * BROWS;
+      const int bb = px / hw, rem = px - bb * hw;
+      b_img[i] = bb; b_oy[i] = rem / p.Wo; b_ox[i] = rem - b_oy[i] * p.Wo;
+    }
+  }
+  const int dyk = ky * p.dil - p.pad, dxk = kx * p.dil - p.pad;
+  auto load_tiles = [&](int st) {      // must be called with consecutive st
     const int p0 = st * BKP;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int px = p0 + a_r + i * AROWS;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_cok && px < P) v = ldg4(p.g + (size_t)px * p.ldg + co0 + a_c4 * 4);
-      ra[i] = v;
+      const unsigned off = (a_cok && px < P) ? (unsigned)(px * p.ldg + co0 + a_c4 * 4) * 4u : OOB;
+      ra[i] = bufld4(rg, off);
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-      const int px = p0 + b_r + i * BROWS;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b_cok && px < P) {
-        const int hw = p.Ho * p.Wo;
-        const int b = px / hw, rem = px - b * hw;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
-        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-          v = ldg4(p.x + (size_t)((b * p.Hi + iy) * p.Wi + ix) * p.ldx + ci0 + b_c4 * 4);
-      }
-      rb[i] = v;
+      const int iy = b_oy[i] * p.stride + dyk, ix = b_ox[i] * p.stride + dxk;
+      const bool ok = b_cok && b_img[i] < p.B && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      const unsigned off = ok ? (unsigned)(((b_img[i] * p.Hi + iy) * p.Wi + ix) * p.ldx + ci0 + b_c4 * 4) * 4u : OOB;
+      rb[i] = bufld4(rx, off);
+      b_ox[i] += BKP;
+      while (b_ox[i] >= p.Wo) { b_ox[i] -= p.Wo; ++b_oy[i]; }
+      while (b_oy[i] >= p.Ho) { b_oy[i] -= p.Ho; ++b_img[i]; }
     }
   };
   auto store_tiles = [&](int buf) {
@@ -502,8 +514,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// 128-wide tiles unless that pads the channel count by more than 15 % (e.g. 304 -> 384)
+static int wg_tile(int c) {
+  if (c <= 64) return 64;
+  const int padded = (c + 127) / 128 * 128;
+  return (padded - c) * 100 > 15 * c ? 64 : 128;
+}
 int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
-  const int bm = Cout > 64 ? 128 : 64, bn = Cin > 64 ? 128 : 64;
+  const int bm = wg_tile(Cout), bn = wg_tile(Cin);
   const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
   const int steps = (P + 31) / 32;
   // pick the K split so that tiles*S fills whole rounds of the 512 resident workgroups
@@ -520,7 +538,7 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-  const int bm = a.Cout > 64 ? 128 : 64, bn = a.Cin > 64 ? 128 : 64;
+  const int bm = wg_tile(a.Cout), bn = wg_tile(a.Cin);
   const int T = a.KH * a.KW;
   const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * T;
   const dim3 grid(tiles * a.splits), block(256);
