@@ -173,6 +173,10 @@ struct eosvos_engine {
   float *cat, *g_cat, *vec, *gvec, *poolout, *gp, *colscratch, *proj, *g_proj;
   float *dcat, *g_dcat, *d1, *g_d1, *d2, *g_d2, *lowlog, *g_low, *logits, *dlogits, *loss_dev, *bce_partial;
   float *ws_conv, *ws_wg;
+  std::vector<int64_t> ws_off;       // per conv: offset of its weight-gradient slabs in ws_wg
+  std::vector<int> upd_splits;       // per conv: slabs written by the current backward pass
+  std::vector<UpdEntry*> upd_tab;    // per batch size: device copy of the update table
+  std::vector<int> upd_blocks;
   int64_t ws_conv_n = 0, ws_wg_n = 0;
   ResizeTab up_h, up_w, fin_h, fin_w;  // decoder upsample (align_corners) and final resize
   int lastB = 0;
@@ -258,7 +262,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   const ConvL& c = e->t.convs[ci];
   WgradArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = g; a.x = x; a.ws = e->ws_wg;
+  a.g = g; a.x = x; a.ws = e->ws_wg + e->ws_off[ci];
   a.B = B; a.Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad); a.Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
   a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
@@ -268,12 +272,33 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   return a.splits;
 }
 // reduce slabs, scale by the frozen-norm a[cout], (optionally) theta <- theta - lr*g
-void apply_update(eosvos_engine* e, int ci, int splits, bool update, bool accumulate) {
-  const ConvL& c = e->t.convs[ci];
-  const int64_t n = c.wsize() + (c.bias ? c.cout : 0);
-  launch_sgd_update(e->W_(ci), e->ws_wg, splits, n, e->A_(ci), update ? e->lr + c.lroff : nullptr,
-                    accumulate ? e->gsum + c.poff : nullptr, e->keep_grads ? e->gout + c.poff : nullptr,
-                    (int64_t)c.T() * c.cin, n, e->s);
+void apply_update(eosvos_engine* e, int ci, int splits, bool /*update*/, bool /*accumulate*/) {
+  e->upd_splits[ci] = splits;     // the slabs stay parked; flush_updates() consumes them
+}
+// one launch: sum every layer's slabs, norm scale, theta <- theta - lr*g, optional gsum/gout
+int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate) {
+  const Topo& t = e->t;
+  if (!e->upd_tab[B]) {
+    std::vector<UpdEntry> tab(t.convs.size());
+    int blk = 0;
+    for (size_t ci = 0; ci < t.convs.size(); ++ci) {
+      const ConvL& c = t.convs[ci];
+      UpdEntry& u = tab[ci];
+      u.w_off = c.poff; u.ws_off = e->ws_off[ci];
+      u.n = (int)(c.wsize() + (c.bias ? c.cout : 0)); u.slab = u.n;
+      u.splits = e->upd_splits[ci]; u.rowlen = c.T() * c.cin;
+      u.lr_off = (int)c.lroff; u.norm_off = c.norm ? (int)c.noff : -1; u.blk0 = blk;
+      blk += (u.n + 1023) / 1024;
+    }
+    UpdEntry* d = (UpdEntry*)e->falloc((int64_t)(tab.size() * sizeof(UpdEntry) + 3) / 4);
+    if (!d) return fail("hipMalloc update table");
+    HIPOK(hipMemcpy(d, tab.data(), tab.size() * sizeof(UpdEntry), hipMemcpyHostToDevice));
+    e->upd_tab[B] = d; e->upd_blocks[B] = blk;
+  }
+  launch_sgd_update_all(e->upd_tab[B], (int)t.convs.size(), e->upd_blocks[B], e->Wp, e->ws_wg, e->na,
+                        update ? e->lr : nullptr, accumulate ? e->gsum : nullptr, e->keep_grads ? e->gout : nullptr,
+                        e->s);
+  return 0;
 }
 
 int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
@@ -339,13 +364,20 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   ALLOC(e->p1, n4 * 64); ALLOC(e->g_p1, n4 * 64);
   { float* t8; ALLOC(t8, (n4 * 64 + 3) / 4); e->p1idx = (uint8_t*)t8; }
 
-  int64_t wsc = conv_ws_floats(), wsw = 1;
+  int64_t wsc = conv_ws_floats(), wsw = 0;
+  e->ws_off.assign(t.convs.size(), 0);
+  e->upd_splits.assign(t.convs.size(), 1);
+  e->upd_tab.assign(B + 1, nullptr);
+  e->upd_blocks.assign(B + 1, 0);
+  std::vector<int64_t> slabs(t.convs.size(), 0);   // floats of slab space per conv (max over batch sizes)
   auto track = [&](int ci, int Hin, int Win) {
     const ConvL& c = t.convs[ci];
     const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
     const int Mf = B * Ho * Wo, Md = B * Hin * Win;
     (void)Md;
-    wsw = max64(wsw, (int64_t)wgrad_pick_splits(Mf, c.cout, c.cin, c.T()) * c.wsize());
+    for (int b = 1; b <= B; ++b)
+      slabs[ci] = max64(slabs[ci], (int64_t)wgrad_pick_splits(b * Ho * Wo, c.cout, c.cin, c.T()) * c.wsize());
+    (void)Mf;
   };
   // bottleneck buffers
   int Hc = e->h4, Wc = e->w4, Cc = 64;
@@ -384,9 +416,15 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   for (int i = 0; i < 4; ++i) track(t.aspp[i], e->h16, e->w16);
   track(t.project, e->h16, e->w16); track(t.dec1, e->h4, e->w4);
   track(t.dec_a, e->h4, e->w4); track(t.dec_b, e->h4, e->w4);
-  wsw = max64(wsw, (int64_t)stem_wgrad_chunks(B, e->h2, e->w2) * 64 * 147);
-  wsw = max64(wsw, (int64_t)last_bwd_chunks(n4) * 257);
-  wsw = max64(wsw, (int64_t)256 * 2048);
+  for (int b = 1; b <= B; ++b) {
+    slabs[0] = max64(slabs[0], (int64_t)stem_wgrad_chunks(b, e->h2, e->w2) * 64 * 147);
+    slabs[t.last] = max64(slabs[t.last], (int64_t)last_bwd_chunks((int64_t)b * e->h4 * e->w4) * 257);
+  }
+  slabs[t.pool] = (int64_t)256 * 2048;
+  for (size_t ci = 0; ci < t.convs.size(); ++ci) {
+    e->ws_off[ci] = wsw;
+    wsw += (slabs[ci] + 3) / 4 * 4;
+  }
   ALLOC(e->ws_conv, wsc); ALLOC(e->ws_wg, wsw);
   e->ws_conv_n = wsc; e->ws_wg_n = wsw;
 #undef ALLOC
@@ -534,7 +572,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   // classifier conv (Cout = 1)
   {
     const int chunks = last_bwd_chunks(P4);
-    launch_last_bwd(e->d2, e->W_(t.last), e->g_low, e->g_d2, e->ws_wg, P4, 256, chunks, s);
+    launch_last_bwd(e->d2, e->W_(t.last), e->g_low, e->g_d2, e->ws_wg + e->ws_off[t.last], P4, 256, chunks, s);
     apply_update(e, t.last, chunks, update, accumulate);
   }
   // decoder 3x3 convs
@@ -568,7 +606,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   // image-pooling branch: gp = sum_p g_cat[:,1024:1280]; g_l4 starts as the broadcast of its input gradient
   {
     launch_colsum(e->g_cat + 1024, 1280, e->gp, B, P16, 256, 1.f, e->colscratch, s);
-    launch_gemv_bwd(e->W_(t.pool), e->vec, e->gp, e->A_(t.pool), e->gvec, e->ws_wg, B, 256, 2048, s);
+    launch_gemv_bwd(e->W_(t.pool), e->vec, e->gp, e->A_(t.pool), e->gvec, e->ws_wg + e->ws_off[t.pool], B, 256, 2048, s);
     launch_bcast_pixels(e->gvec, g_l4, 2048, B, P16, 2048, 1.0f / (float)P16, s);
     apply_update(e, t.pool, 1, update, accumulate);
   }
@@ -614,9 +652,10 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   launch_maxpool_bwd(e->g_p1, e->p1idx, e->c1, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s);
   {
     const int chunks = stem_wgrad_chunks(B, e->h2, e->w2);
-    launch_stem_wgrad(e->xpad, e->g_c1, e->ws_wg, B, e->H, e->W, e->h2, e->w2, chunks, s);
+    launch_stem_wgrad(e->xpad, e->g_c1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, s);
     apply_update(e, 0, chunks, update, accumulate);
   }
+  if (flush_updates(e, B, update, accumulate)) return 1;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("backward launch: ") + hipGetErrorString(err));
   return 0;

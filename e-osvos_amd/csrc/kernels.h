@@ -134,6 +134,20 @@ void launch_merge_labels(const float* probs, int n_obj, int64_t n_pix, uint8_t* 
 void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, const float* rowscale,
                        const float* lr, float* gsum, float* gout, int64_t rowlen, int64_t n,
                        hipStream_t s);
+// Whole-network update in one launch: per-layer table over one slab arena.
+struct UpdEntry {
+  long w_off;      // offset of the tensor (weight [+ bias]) in the parameter / gsum / gout arenas
+  long ws_off;     // offset of its first slab in the slab arena (multiple of 4 floats)
+  long slab;       // floats per slab
+  int splits;      // number of slabs to sum
+  int rowlen;      // elements per output channel (per-neuron lr / norm-scale granularity)
+  int n;           // elements
+  int lr_off;      // offset of its per-neuron learning rates
+  int norm_off;    // offset of its frozen-norm scale, -1 if none
+  int blk0;        // first workgroup of this entry (1024 elements per workgroup)
+};
+void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
+                           const float* lr, float* gsum, float* gout, hipStream_t s);
 // g_lr[c] += -sum_row(gsum*G) ;  (G itself is exported by launch_ohwi_to_oihw with add=1)
 void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen,
                          hipStream_t s);

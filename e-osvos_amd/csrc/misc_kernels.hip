@@ -687,3 +687,49 @@ void launch_clamp(float* p, int64_t n, float lo, float hi, hipStream_t s) {
 }
 
 }  // namespace eosvos
+
+// ---- one launch for the whole network's update ----------------------------------------------------
+// All weight-gradient slabs of a backward pass stay parked in one arena; this kernel walks a
+// per-layer table and, for every parameter, sums its slabs in order, applies the frozen-norm
+// row scale and the per-neuron learning rate (theta <- theta - lr[cout] * g), and optionally
+// accumulates / exports g.  One launch instead of 64, every CU busy, weights read+written once.
+namespace eosvos {
+__global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __restrict__ tab, int nent,
+                                                              float* __restrict__ W, const float* __restrict__ ws,
+                                                              const float* __restrict__ na, const float* __restrict__ lr,
+                                                              float* __restrict__ gsum, float* __restrict__ gout) {
+  int ei = 0;
+  while (ei + 1 < nent && (int)blockIdx.x >= tab[ei + 1].blk0) ++ei;     // wave-uniform scan
+  const UpdEntry t = tab[ei];
+  const int e0 = ((int)blockIdx.x - t.blk0) * 1024 + threadIdx.x * 4;
+  if (e0 >= t.n) return;
+  const float* s0 = ws + t.ws_off + e0;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e0 + 3 < t.n && (t.slab & 3) == 0) {
+#pragma unroll 4
+    for (int z = 0; z < t.splits; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(s0 + (size_t)z * t.slab);
+      g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
+    }
+  } else {
+    for (int z = 0; z < t.splits; ++z)
+      for (int j = 0; j < 4 && e0 + j < t.n; ++j) g[j] += s0[(size_t)z * t.slab + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = e0 + j;
+    if (e >= t.n) break;
+    const int row = e / t.rowlen;
+    float gv = g[j];
+    if (t.norm_off >= 0) gv *= na[t.norm_off + row];
+    float* wp = W + t.w_off + e;
+    if (lr) *wp = *wp - lr[t.lr_off + row] * gv;
+    if (gsum) gsum[t.w_off + e] += gv;
+    if (gout) gout[t.w_off + e] = gv;
+  }
+}
+void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
+                           const float* lr, float* gsum, float* gout, hipStream_t s) {
+  hipLaunchKernelGGL(sgd_update_all_kernel, dim3(nblocks), dim3(256), 0, s, tab, nent, W, ws, na, lr, gsum, gout);
+}
+}  // namespace eosvos
