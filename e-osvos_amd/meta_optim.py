@@ -1,0 +1,181 @@
+"""Drop-in for `src/meta_optim/meta_optim.py::MetaOptimizer` (+ the `MetaModel` helper of
+`src/meta_optim/meta_model.py`) on the MI355X engine.
+
+Reference semantics kept:
+  * learned per-neuron lr tensors `log_init_lr_*` of shape (Cout,1,1,1) / (1,) initialised to
+    init_lr*(1+U(-.5,.5)) (`meta_optim.py:46-67`), learned init `model_init_*` aliasing the
+    model's parameters (`:71-78`); `state_dict()` = 128 tensors for ResNet-50 in that order;
+  * `reset()` re-points the model at the learned init and the state lr at the learned lr
+    (`:144-163`) -> `eosvos_reset`; `reset(keep_state=True)` detaches (`:145-151`) -> no-op for
+    first-order gradients;
+  * `set_train_loss` / `step(loss)`: autograd.grad + theta <- theta - lr (.) grad
+    (`:165-214`, `meta_model.py:78-80`) -> `eosvos_backward_step` on the gradient the fused
+    BCE kernel left behind; in `.train()` mode the step also accumulates sum_k g_k for the
+    closed-form meta-gradient;
+  * `meta_backward(meta_loss)` stands in for `bptt_loss.backward()` (`meta_run.py:214`): fills
+    `.grad` of `named_parameters()` (log_init_lr_* then model_init_*).
+Unsupported reference options raise NotImplementedError exactly like the reference does for
+unknown hierarchy levels (`meta_optim.py:68-69`).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from .networks import _Param
+from .topology import neuron_lr_shape
+
+
+class _MetaModelShim:
+    """`meta_optim.meta_model` of the reference; only the members the loops touch."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def detach_param_groups(self):      # meta_model.py:62-65 -- the engine keeps no autograd graph
+        pass
+
+    @property
+    def num_param_groups(self):
+        return len(self.model._names)
+
+
+class MetaOptimizer:
+    def __init__(self, model, init_lr, learn_model_init, second_order_gradients, lr_hierarchy_level,
+                 use_log_init_lr, max_lr):
+        if lr_hierarchy_level != 'NEURON':
+            raise NotImplementedError(f'lr_hierarchy_level={lr_hierarchy_level} (only NEURON, cfgs/meta.yaml:36)')
+        if use_log_init_lr:
+            raise NotImplementedError('use_log_init_lr=True')
+        if second_order_gradients:
+            raise NotImplementedError('second_order_gradients=True needs double backward')
+        if not learn_model_init:
+            raise NotImplementedError('learn_model_init=False')
+        self._max_lr = max_lr
+        self.training = True
+        self.only_box_head = False          # evaluate.py:270 sets it; no-op for DeepLab (meta_model.py:73-76)
+        self.model = model
+        self.meta_model = _MetaModelShim(model)
+        self.state = {'num_steps': 0}
+        self._train_loss = None
+        names, shapes = model._names, model._shapes
+        n_lr = sum(s[0] for s in shapes)
+        self._lr_flat = torch.zeros(n_lr)
+        self._lr_views = OrderedDict()
+        off = 0
+        for n, s in zip(names, shapes):
+            ls = neuron_lr_shape(s)
+            k = s[0]
+            v = self._lr_flat[off:off + k].view(ls)
+            v.copy_(init_lr * (1.0 + (torch.rand(ls) - 0.5)))          # meta_optim.py:57-58
+            self._lr_views['log_init_lr_' + n.replace('.', '-')] = v
+            off += k
+        self._init_views = OrderedDict(('model_init_' + n.replace('.', '-'), model._views[n]) for n in names)
+        self._params = OrderedDict()
+        for k, v in list(self._lr_views.items()) + list(self._init_views.items()):
+            self._params[k] = _Param(k, v, True)
+        self._grad_flat = None
+        model._lr_flat = self._lr_flat
+        model._dirty = True
+
+    # ---- nn.Module-like surface ---------------------------------------------------------------
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        self.model.to(device)
+        return self
+
+    def share_memory(self):
+        return self
+
+    def named_parameters(self):
+        return iter(self._params.items())
+
+    def parameters(self):
+        return iter(self._params.values())
+
+    def state_dict(self):
+        out = OrderedDict()
+        for k, p in self._params.items():
+            out[k] = p.data.clone()
+        return out
+
+    def load_state_dict(self, sd):
+        missing = [k for k in self._params if k not in sd]
+        if missing:
+            raise KeyError(f'missing keys: {missing[:4]}...')
+        for k, p in self._params.items():
+            p.data.copy_(sd[k].reshape(p.data.shape))
+        self.model._lr_flat = self._lr_flat
+        self.model._dirty = True
+
+    def zero_grad(self):
+        if self._grad_flat is not None:
+            self._grad_flat.zero_()
+
+    def init_zero_grad(self):
+        eng = self.model.engine
+        dev = eng.device if eng is not None else self.model.device
+        n = self._lr_flat.numel() + self.model._flat.numel()
+        self._grad_flat = torch.zeros(n, device=dev)
+        off = 0
+        for p in self._params.values():
+            k = p.data.numel()
+            p.grad = self._grad_flat[off:off + k].view(p.data.shape)
+            off += k
+
+    @property
+    def init_lr(self):
+        return torch.tensor([float(v.mean()) for v in self._lr_views.values()])
+
+    @property
+    def state_lr(self):
+        return self.init_lr
+
+    def clamp_init_lr(self):
+        self._lr_flat.clamp_(0, self._max_lr)           # meta_optim.py:116-133, use_log_init_lr False
+        self.model._lr_flat = self._lr_flat
+        self.model._dirty = True
+
+    # ---- inner loop ------------------------------------------------------------------------------
+    def reset(self, keep_state=False):
+        if keep_state:
+            return
+        m = self.model
+        if m.engine is not None:
+            if m._dirty:
+                m.push_state()
+            if self.training:
+                m.engine.meta_task_begin()          # theta <- init, sum_k g_k <- 0
+            else:
+                m.engine.reset()
+        else:
+            m._pending_task_begin = self.training   # engine is created at the first forward
+        self.state['num_steps'] = 0
+
+    def set_train_loss(self, train_loss):
+        self._train_loss = train_loss
+
+    def step(self, train_loss):
+        eng = getattr(train_loss, '_eosvos_engine', None)
+        if eng is None:
+            raise RuntimeError('step() needs the loss returned by eosvos_amd.helper_func.compute_loss')
+        eng.backward_step(accumulate=self.training)
+        self.state['num_steps'] += 1
+
+    def meta_backward(self, meta_inputs, meta_gts):
+        """`bptt_loss.backward()` for one meta frame batch: returns the meta loss (float) and ADDS the
+        task's meta-gradient into `.grad` of named_parameters()."""
+        if self._grad_flat is None:
+            self.init_zero_grad()
+        eng = self.model._ensure_engine(meta_inputs.shape[2], meta_inputs.shape[3], meta_inputs.shape[0])
+        task = torch.zeros_like(self._grad_flat)
+        loss = eng.meta_grad(meta_inputs.contiguous(), meta_gts.contiguous(), task)
+        if not math.isnan(loss):
+            self._grad_flat.add_(task)
+        return loss

@@ -1,0 +1,188 @@
+"""Drop-in for `src/networks/deeplabv3plus.py::DeepLabV3Plus` on the MI355X engine.
+
+Same constructor arguments and call surface as the reference class (`deeplabv3plus.py:104-178,
+259-301`): `model(inputs) -> [logits]`, `train_without_dropout()`, `eval()`, `train()`,
+`to(device)`, `state_dict()/load_state_dict()` with the torchvision key names (374 keys),
+`named_parameters()`, `parameters()`, `zero_grad()`.  The arithmetic runs in libeosvos.so; the
+tensors kept here are the reference-layout (OIHW) *initial* weights and the frozen norm
+statistics.  The engine is created lazily at the first forward (it needs the frame size) and
+re-created when the frame size changes (DAVIS 480p frames are not all 854 wide).
+
+Only the mode the fine-tuning loops use is implemented: BatchNorm in eval mode with frozen
+affine (`batch_norm.accum_stats False`, `cfgs/meta.yaml:72-75`) and Dropout off; anything
+else raises NotImplementedError (no silent fallback).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import _ffi
+from .engine import Engine
+from .topology import conv_infos, model_state_keys, norm_layers, trainable
+
+
+class _Param:
+    """Minimal stand-in for torch.nn.Parameter as the reference loops use it: a tensor view with
+    `.requires_grad`, `.grad`, `.data`."""
+
+    def __init__(self, name, tensor, requires_grad):
+        self.name, self.data, self.requires_grad, self.grad = name, tensor, requires_grad, None
+
+    def numel(self):
+        return self.data.numel()
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+class DeepLabV3Plus:
+    def __init__(self, backbone, num_classes, batch_norm=None, train_encoder=True,
+                 replace_batch_with_group_norms=False, max_batch=3, device='cuda:0'):
+        if backbone not in ('resnet50', 'resnet101'):
+            raise NotImplementedError(backbone)
+        if num_classes != 1:
+            raise NotImplementedError('num_classes != 1')
+        if replace_batch_with_group_norms:
+            raise NotImplementedError('GroupNorm mode is not implemented yet (SURVEY.md 8f.1)')
+        if not train_encoder:
+            raise NotImplementedError('train_encoder=False')
+        if batch_norm is not None and (batch_norm.get('accum_stats') or batch_norm.get('learn_weight')
+                                       or batch_norm.get('learn_bias')):
+            raise NotImplementedError('only frozen BatchNorm (accum_stats/learn_* False) is implemented')
+        self.encoder = backbone
+        self.device = torch.device(device)
+        self.max_batch = max_batch
+        self.training = True
+        self._dropout_off = False
+        self.engine = None
+        self._dirty = True                     # python-side state newer than the engine's
+        self._lr_flat = None
+        tr = trainable(backbone)
+        self._names = [n for n, _ in tr]
+        self._shapes = [s for _, s in tr]
+        n_param = sum(int(torch.Size(s).numel()) for s in self._shapes)
+        self._flat = torch.zeros(n_param)     # learned init, reference layout
+        self._views = OrderedDict()
+        off = 0
+        for n, s in tr:
+            k = int(torch.Size(s).numel())
+            self._views[n] = self._flat[off:off + k].view(s)
+            off += k
+        self._norm = OrderedDict()
+        for p, c in norm_layers(backbone):
+            self._norm[p + '.weight'] = torch.ones(c)
+            self._norm[p + '.bias'] = torch.zeros(c)
+            self._norm[p + '.running_mean'] = torch.zeros(c)
+            self._norm[p + '.running_var'] = torch.ones(c)
+            self._norm[p + '.num_batches_tracked'] = torch.zeros((), dtype=torch.long)
+        self._params = OrderedDict((n, _Param(n, v, True)) for n, v in self._views.items())
+
+    # ---- nn.Module-like surface ---------------------------------------------------------
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def train_without_dropout(self):
+        self.train()
+        self._dropout_off = True
+
+    def zero_grad(self):
+        for p in self._params.values():
+            p.grad = None
+
+    def named_parameters(self):
+        for n, p in self._params.items():
+            yield n, p
+        for k, v in self._norm.items():
+            if k.endswith('.weight') or k.endswith('.bias'):
+                yield k, _Param(k, v, False)
+
+    def parameters(self):
+        return (p for _, p in self.named_parameters())
+
+    def state_dict(self):
+        """Current (possibly fine-tuned) weights in the reference key order."""
+        cur = self._flat
+        if self.engine is not None and not self._dirty:
+            cur = self.engine.get_params().cpu()
+        out = OrderedDict()
+        off = 0
+        views = {}
+        for n, s in zip(self._names, self._shapes):
+            k = int(torch.Size(s).numel())
+            views[n] = cur[off:off + k].view(s).clone()
+            off += k
+        for k in model_state_keys(self.encoder, 'bn'):
+            out[k] = views[k] if k in views else self._norm[k].clone()
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        keys = model_state_keys(self.encoder, 'bn')
+        if strict:
+            missing = [k for k in keys if k not in sd]
+            if missing:
+                raise KeyError(f'missing keys in state_dict: {missing[:5]}...')
+        for k in keys:
+            if k not in sd:
+                continue
+            if k in self._views:
+                self._views[k].copy_(sd[k])
+            else:
+                self._norm[k] = sd[k].detach().clone().cpu()
+        self._dirty = True
+
+    # ---- engine plumbing --------------------------------------------------------------------
+    def _ensure_engine(self, height, width, batch):
+        e = self.engine
+        if e is None or e.height != height or e.width != width or batch > e.max_batch:
+            if e is not None:
+                e.close()
+            self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device))
+            self._dirty = True
+        if self._dirty:
+            self.push_state()
+        if getattr(self, '_pending_task_begin', False):
+            self.engine.meta_task_begin()
+            self._pending_task_begin = False
+        return self.engine
+
+    def push_state(self):
+        """Upload init weights / norm statistics (/ learning rates) to the engine; theta <- init."""
+        e = self.engine
+        e.set_init(self._flat)
+        nl = norm_layers(self.encoder)
+        cat = lambda suf: torch.cat([self._norm[p + suf].reshape(-1).float() for p, _ in nl])
+        e.set_norm(cat('.weight'), cat('.bias'), cat('.running_mean'), cat('.running_var'))
+        if self._lr_flat is not None:
+            e.set_lr(self._lr_flat)
+        self._dirty = False
+
+    def __call__(self, inputs):
+        if self.training and not self._dropout_off:
+            raise NotImplementedError('training-mode Dropout is not implemented: call train_without_dropout() '
+                                      '(evaluate.py:213, meta_run.py:130) or eval()')
+        if not inputs.is_cuda:
+            raise _ffi.EosvosError('inputs must live on the GPU (no CPU path)')
+        b, _, h, w = inputs.shape
+        e = self._ensure_engine(h, w, b)
+        logits = e.forward(inputs.contiguous().float())
+        logits._eosvos_engine = e          # lets compute_loss / MetaOptimizer.step find the engine
+        return [logits]
+
+    forward = __call__
+
+
+def conv_names(encoder='resnet50'):
+    return [c.name for c in conv_infos(encoder)]

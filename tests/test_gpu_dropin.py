@@ -1,0 +1,178 @@
+"""The reference-mirroring Python surface (networks / meta_optim / helper_func / evaluate /
+train_meta) driven exactly like the reference's loops, checked against the golden fixtures and the
+CPU oracle.  Needs an MI355X: pytest -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from eosvos_amd import synthetic, topology
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SMALL = (96, 160)
+BN_CFG = {'accum_stats': False, 'learn_weight': False, 'learn_bias': False}
+MO_CFG = dict(init_lr=1e-3, learn_model_init=True, second_order_gradients=False, lr_hierarchy_level='NEURON',
+              use_log_init_lr=False, max_lr=None)
+
+
+def _meta_state():
+    sd = synthetic.synthetic_state('resnet50')
+    lrs = synthetic.synthetic_lrs('resnet50')
+    out = {}
+    for (n, _), lr in zip(topology.trainable('resnet50'), lrs):
+        out['log_init_lr_' + n.replace('.', '-')] = lr.clone()
+    for n, _ in topology.trainable('resnet50'):
+        out['model_init_' + n.replace('.', '-')] = sd[n].clone()
+    return sd, out
+
+
+@pytest.fixture(scope='module')
+def model_and_optim():
+    from eosvos_amd.helper_func import init_parent_model
+    from eosvos_amd.meta_optim import MetaOptimizer
+    model, parent_states = init_parent_model(architecture='DeepLabV3Plus', encoder='resnet50', train_encoder=True,
+                                             decoder_norm_layer='BatchNorm2d', replace_batch_with_group_norms=False,
+                                             batch_norm=BN_CFG, roi_pool_output_sizes=None,
+                                             eval_augment_rpn_proposals_mode=None, box_nms_thresh=None,
+                                             maskrcnn_loss=None)
+    assert parent_states == {}
+    sd, msd = _meta_state()
+    model.load_state_dict(sd)
+    mo = MetaOptimizer(model, **MO_CFG)
+    return model, mo, msd
+
+
+def test_reference_style_finetune_loop(model_and_optim, golden_dir):
+    """The loop of evaluate.py:196-274, verbatim call sequence."""
+    from eosvos_amd.helper_func import compute_loss
+    model, mo, msd = model_and_optim
+    g = np.load(os.path.join(golden_dir, 'g45_finetune.npz'))
+    mo.load_state_dict(msd)
+    mo.reset()
+    mo.eval()
+    model.train_without_dropout()
+    losses = []
+    for it in range(5):
+        x, y = synthetic.synthetic_frames(3, *SMALL, seed=7 + it)
+        outputs = model(x.to(DEV))
+        train_loss = compute_loss('cross_entropy', outputs[-1], y.to(DEV))
+        losses.append(train_loss.item())
+        model.zero_grad()
+        mo.set_train_loss(train_loss)
+        mo.only_box_head = False
+        mo.step(train_loss)
+        mo.meta_model.detach_param_groups()
+    np.testing.assert_allclose(losses, g['small_losses'], rtol=5e-4, atol=1e-5)
+    sd = model.state_dict()
+    assert list(sd) == topology.model_state_keys('resnet50') and len(sd) == 374
+    tr = topology.trainable('resnet50')
+    for i in g['small_ids']:
+        ref = g[f'small_param_{i}']
+        assert np.abs(sd[tr[i][0]].numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    model.eval()
+    out = model(synthetic.synthetic_frames(3, *SMALL, seed=7)[0].to(DEV))[-1]
+    assert np.abs(out.cpu().numpy() - g['small_final_logits']).max() < 5e-3
+    per = compute_loss('cross_entropy', out, synthetic.synthetic_frames(3, *SMALL, seed=7)[1].to(DEV),
+                       {'batch_average': False})
+    assert per.shape == (3,)
+    with pytest.raises(NotImplementedError):
+        compute_loss('dice', out, out)
+
+
+def test_reference_style_meta_task(model_and_optim, golden_dir):
+    """meta_run.py:121-214 call sequence (K=2), `.grad` of named_parameters() vs the golden."""
+    from eosvos_amd.helper_func import compute_loss
+    model, mo, msd = model_and_optim
+    g = np.load(os.path.join(golden_dir, 'g7_meta_task.npz'))
+    K = 2
+    mo.load_state_dict(msd)
+    mo.init_zero_grad()
+    mo.zero_grad()
+    mo.train()
+    mo.reset()
+    model.train_without_dropout()
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1000 + K)
+    xg, yg = x.to(DEV), y.to(DEV)
+    for _ in range(K):
+        loss = compute_loss('cross_entropy', model(xg)[-1], yg)
+        mo.set_train_loss(loss)
+        mo.step(loss)
+    meta_loss = mo.meta_backward(torch.flip(xg, dims=[3]), torch.flip(yg, dims=[3]))
+    assert abs(meta_loss - g[f'k{K}_meta_loss'][0]) <= 5e-4 * abs(g[f'k{K}_meta_loss'][0])
+    names = [n for n, _ in mo.named_parameters()]
+    assert names == list(g[f'k{K}_names'])
+    lr_g = torch.cat([p.grad.flatten() for n, p in mo.named_parameters() if n.startswith('log_init_lr_')]).cpu().numpy()
+    ref = g[f'k{K}_lr_grad']
+    assert np.abs(lr_g - ref).max() <= 5e-3 * np.abs(ref).max()
+    mo.reset()
+    mo.eval()
+
+
+def test_online_adaptation_sequence(model_and_optim):
+    """Config e-OSVOS-OnA on a short synthetic 2-object sequence: schedule, FIRST_STEP restore,
+    pseudo-label batches and the merged label maps, against the same loop run on the CPU oracle."""
+    from eosvos_amd import config
+    from eosvos_amd.evaluate import evaluate_sequence, online_adapt_schedule
+    from oracle import deeplab, meta
+    model, mo, msd = model_and_optim
+    cfg = config.parse_cli(['with', 'DAVIS-2017', 'e-OSVOS-OnA', 'num_epochs.eval=3', 'eval_online_adapt.num_epochs=2',
+                            'eval_online_adapt.step=3'])
+    H, W, N = SMALL[0], SMALL[1], 6
+    frames, gt = synthetic.synthetic_frames(1, H, W, seed=3, second_object=True)
+    seq = torch.cat([torch.roll(frames, shifts=4 * i, dims=3) for i in range(N)])
+    rows = torch.arange(H).view(-1, 1)
+    objs = [(gt[0] * (rows < H // 2)).float(), (gt[0] * (rows >= H // 2)).float()]
+    assert [(r['eval_min'], r['eval_max'], r['propagate_frames']) for r in online_adapt_schedule(N, 0, 3, 3)] == \
+        [(1, 4, []), (4, 6, [3, 2])]
+    assert online_adapt_schedule(N, 0, 3, 3) == meta.online_adapt_schedule(N, 0, 3, 3)
+    labels, probs, hist = evaluate_sequence(model, mo, msd, seq.to(DEV), objs, cfg)
+    assert labels.shape == (N, H, W) and labels.dtype == torch.uint8
+    assert [len(h) for h in hist[0]] == [3, 2]
+
+    # the same procedure on the CPU oracle
+    sd = synthetic.synthetic_state('resnet50')
+    lrs = synthetic.synthetic_lrs('resnet50')
+    o_probs = []
+    for gto in objs:
+        y0 = gto.view(1, 1, H, W)
+        masks = torch.zeros(N, 1, H, W)
+        masks[0] = 2 * y0[0]
+        x0 = seq[0:1]
+        _, P = meta.finetune(sd, lrs, [(x0.expand(3, -1, -1, -1), y0.expand(3, -1, -1, -1))] * 3)
+        P_first = P
+        with torch.no_grad():
+            for f in range(1, 4):
+                masks[f] = torch.sigmoid(deeplab.forward(P, seq[f:f + 1]))[0]
+        xs, ys = [x0], [y0]
+        for f in (3, 2):
+            pg = masks[f:f + 1].ge(0.5).float()
+            if pg.sum() != 0:
+                xs.append(seq[f:f + 1]); ys.append(pg)
+        _, P = meta.finetune(P_first, lrs, [(torch.cat(xs), torch.cat(ys))] * 2)
+        with torch.no_grad():
+            for f in range(4, 6):
+                masks[f] = torch.sigmoid(deeplab.forward(P, seq[f:f + 1]))[0]
+        o_probs.append(masks[:, 0])
+    o_stack = torch.stack(o_probs, dim=1)
+    o_labels = torch.stack([meta.merge_labels(o_stack[f]) for f in range(N)])
+    for o in range(2):
+        assert float((probs[o].cpu() - o_probs[o]).abs().max()) < 5e-3
+    near = ((o_stack - 0.5).abs() < 5e-3).any(dim=1)
+    assert bool((labels.cpu() == o_labels)[~near].all())
+    assert int((labels.cpu() != o_labels).sum()) <= int(near.sum())
+    assert set(labels.unique().tolist()) <= {0, 1, 2}
+
+
+def test_train_meta_entry_points(tmp_path):
+    from eosvos_amd import train_meta
+    from eosvos_amd.checkpoint import load_meta_checkpoint
+    labels = train_meta.main(['with', 'DAVIS-2017', 'e-OSVOS', 'num_epochs.eval=2'], height=96, width=160, num_frames=3)
+    assert labels.shape == (3, 96, 160)
+    mt = train_meta.main(['with', 'YouTube-VOS', 'meta_batch_size=2', 'num_epochs.train=2', f'save_dir={tmp_path}',
+                          'env_suffix=t'], height=96, width=160, num_meta_iters=1)
+    sd, info = load_meta_checkpoint(os.path.join(str(tmp_path), 't', 'last_meta_iter.model'))
+    assert info['meta_iter'] == 1 and len(sd) == 128
+    assert list(sd)[0] == 'log_init_lr_backbone-conv1-weight' and list(sd)[64] == 'model_init_backbone-conv1-weight'
+    assert mt.step == 1
