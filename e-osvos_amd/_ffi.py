@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libeosvos.so')
+LIB_PATH = os.environ.get('EOSVOS_LIB') or os.path.join(_HERE, 'libeosvos.so')   # EOSVOS_LIB: A/B-test builds
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 _E = ctypes.c_void_p
@@ -53,6 +53,8 @@ _SIGNATURES = {
     'eosvos_clamp': (ctypes.c_int, [_E, c_float_p, ctypes.c_int64, ctypes.c_float, ctypes.c_float]),
     'eosvos_time_hot_kernel': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                               ctypes.POINTER(ctypes.c_double)]),
+    'eosvos_bench_conv': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]),
     'eosvos_mfma_probe': (ctypes.c_int, [_E, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_double)]),
     'eosvos_debug_tensor': (ctypes.c_int, [_E, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p),

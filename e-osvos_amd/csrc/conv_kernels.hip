@@ -21,6 +21,12 @@ namespace eosvos {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef EOSVOS_BK
+#define EOSVOS_BK 32
+#endif
+#ifndef EOSVOS_OCC
+#define EOSVOS_OCC 2
+#endif
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of tiles
@@ -41,15 +47,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
 }
 
+// destination pixel of GEMM row m: dense, or (1x1 stride-2 data gradient) the even pixels of
+// the finer destination grid -- the odd ones receive no contribution and are never touched
+__device__ __forceinline__ size_t dst_pixel(const ConvArgs& p, int m) {
+  if (!p.dst_up) return (size_t)m;
+  const int hw = p.Ho * p.Wo;
+  const int b = m / hw, rem = m - b * hw;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  return ((size_t)b * p.Hf + (oy << 1)) * p.Wf + (ox << 1);
+}
+
 // ---- fused epilogue on 4 consecutive output channels ---------------------------------------
-__device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, int m, int n) {
+__device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, size_t m, int n) {
   if (p.scale) { const float4 s = ldg4(p.scale + n); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
   if (p.bias) { const float4 s = ldg4(p.bias + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
-  if (p.res) { const float4 s = ldg4(p.res + (size_t)m * p.ldres + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
-  if (p.accum) { const float4 s = ldg4(p.y + (size_t)m * p.ldy + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+  if (p.res) { const float4 s = ldg4(p.res + m * p.ldres + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+  if (p.accum) { const float4 s = ldg4(p.y + m * p.ldy + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
   if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
   if (p.mask && n >= p.mask_c0) {
-    const float4 s = ldg4(p.mask + (size_t)m * p.ldmask + n);
+    const float4 s = ldg4(p.mask + m * p.ldmask + n);
     v.x = s.x > 0.f ? v.x : 0.f; v.y = s.y > 0.f ? v.y : 0.f; v.z = s.z > 0.f ? v.z : 0.f; v.w = s.w > 0.f ? v.w : 0.f;
   }
   return v;
@@ -63,8 +79,8 @@ __device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, in
 // (deterministic) and applies the epilogue.  This removes the 59-78 % wave-quantisation loss
 // a tile-per-workgroup grid has on 256 CUs for this network's shapes.
 template <int BN, bool KMAJOR>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
-  constexpr int BM = 128, BK = 32;
+__global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int BM = 128, BK = EOSVOS_BK;
   constexpr int LDA = BK + 4;
   constexpr int LDB = KMAJOR ? BN + 4 : BK + 4;
   constexpr int A_EL = BM * LDA;
@@ -222,7 +238,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       const int buf = (ks - ks_begin) & 1;
       const bool more = (ks + 1) < ks_end;
+#ifndef EOSVOS_LOAD_AT
       if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
+#endif
       const float* As = smem + buf * STAGE;
       const float* Bs = As + A_EL;
 #pragma unroll
@@ -252,8 +270,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(av, bv[tn][j], acc[tm][tn]);
           }
         }
+#ifdef EOSVOS_LOAD_AT
+        if (kk == EOSVOS_LOAD_AT && more) load_tiles(ks + 1);
+#endif
+#ifdef EOSVOS_STORE_AT
+        if (kk == EOSVOS_STORE_AT && more) store_tiles(buf ^ 1);
+#endif
       }
+#ifndef EOSVOS_STORE_AT
       if (more) store_tiles(buf ^ 1);
+#endif
       __syncthreads();
     }
 
@@ -278,7 +304,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
           const int m = m0 + row;
           if (m >= p.M) break;
           const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c_c4 * 4);
-          *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + n) = conv_epilogue4(p, v, m, n);
+          const size_t md = dst_pixel(p, m);
+          *reinterpret_cast<float4*>(p.y + md * p.ldy + n) = conv_epilogue4(p, v, md, n);
         }
       }
     } else {
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 // Sum the parked partial tiles in workgroup order and apply the fused epilogue.
 template <int BN>
 __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
-  constexpr int BM = 128, BK = 32;
+  constexpr int BM = 128, BK = EOSVOS_BK;
   const int T = p.KH * p.KW;
   const int ksteps = T * ((p.Kc + BK - 1) / BK);
   const int nt = (p.N + BN - 1) / BN;
@@ -320,7 +347,8 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
       const float4 t = ldg4(p.ws + ((size_t)g * 2 + slot) * (BM * BN) + row * BN + c_c4 * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + n) = conv_epilogue4(p, s, m, n);
+    const size_t md = dst_pixel(p, m);
+    *reinterpret_cast<float4*>(p.y + md * p.ldy + n) = conv_epilogue4(p, s, md, n);
   }
 }
 
@@ -334,7 +362,7 @@ int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG * 2 * 128 * 128; }
 int conv_plan(ConvArgs& a) {
   const int bn = (a.N > 64) ? 128 : 64;
   const int T = a.KH * a.KW;
-  const long ksteps = (long)T * ((a.Kc + 31) / 32);
+  const long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   long nwg = CONV_MAX_WG, q = 0, per = 0;
   if (tiles >= nwg) {
@@ -367,7 +395,7 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, block, 0, s, a);
   }
   const int T = a.KH * a.KW;
-  const long ksteps = (long)T * ((a.Kc + 31) / 32);
+  const long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long sk_tiles = tiles - (long)a.dp_q * nwg;
   if (a.per > 0 && sk_tiles > 0 && a.per % ksteps != 0) {   // some tile is shared between workgroups
     if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);

@@ -254,6 +254,13 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.kscale = e->A_(ci);
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
   a.res = add; a.ldres = ldadd;
+  if (c.k == 1 && c.stride == 2 && !add) {
+    // only the even pixels of the finer grid receive a contribution: run the GEMM on the
+    // coarse grid (4x less MFMA work) and scatter; untouched pixels are zero (or keep their sum)
+    if (!accum) (void)hipMemsetAsync(gx, 0, (size_t)B * Hin * Win * ldgx * sizeof(float), e->s);
+    a.Ho = a.Hi; a.Wo = a.Wi; a.mul = 1; a.off0 = 0; a.kstep = 0; a.upshift = 0;
+    a.M = B * a.Ho * a.Wo; a.dst_up = 1; a.Hf = Hin; a.Wf = Win;
+  }
   trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
   launch_conv(a, e->s);
 }
@@ -815,6 +822,60 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
   *flops_host = 2.0 * (double)batch * e->h4 * e->w4 * 256.0 * 304.0 * 9.0;
   hipEventDestroy(a);
   hipEventDestroy(b);
+  return 0;
+}
+
+// Time one layer's forward (kind 0), data-gradient (1) or weight-gradient (2) launch in place,
+// on the engine's own buffers (tuning aid; outputs are overwritten with whatever the buffers hold).
+int eosvos_bench_conv(eosvos_engine* e, int ci, int kind, int batch, int reps, float* ms_host, double* flops_host) {
+  if (!e || !ms_host || !flops_host || batch < 1 || batch > e->maxB || reps < 1) return fail("bad argument");
+  const Topo& t = e->t;
+  if (ci < 1 || ci >= (int)t.convs.size()) return fail("conv index out of range");
+  const ConvL& c = t.convs[ci];
+  const float *x = nullptr, *g = nullptr;
+  float *y = nullptr, *gx = nullptr;
+  int ldx = c.cin, ldy = c.cout, Hi = 0, Wi = 0;
+  for (size_t i = 0; i < t.blocks.size() && !x; ++i) {
+    const Block& b = t.blocks[i];
+    auto& f = e->bb[i];
+    if (ci == b.c1) { x = f.xin; gx = f.g_xin; y = f.t1; g = f.g_t1; Hi = f.Hi; Wi = f.Wi; }
+    else if (ci == b.c2) { x = f.t1; gx = f.g_t1; y = f.t2; g = f.g_t2; Hi = f.Hm; Wi = f.Wm; }
+    else if (ci == b.c3) { x = f.t2; gx = f.g_t2; y = f.out; g = f.g_out; Hi = f.Ho; Wi = f.Wo; }
+    else if (ci == b.ds) { x = f.xin; gx = f.g_xin; y = f.dsb; g = f.g_out; Hi = f.Hi; Wi = f.Wi; }
+  }
+  if (!x) {
+    if (ci == t.dec_a) { x = e->dcat; gx = e->g_dcat; y = e->d1; g = e->g_d1; Hi = e->h4; Wi = e->w4; }
+    else if (ci == t.dec_b) { x = e->d1; gx = e->g_d1; y = e->d2; g = e->g_d2; Hi = e->h4; Wi = e->w4; }
+    else if (ci == t.project) { x = e->cat; gx = e->g_cat; y = e->proj; g = e->g_proj; Hi = e->h16; Wi = e->w16; }
+    else {
+      for (int i = 0; i < 4; ++i)
+        if (ci == t.aspp[i]) {
+          x = e->bb.back().out; gx = e->bb.back().g_out; y = e->cat + 256 * i; g = e->g_cat + 256 * i;
+          ldy = 1280; Hi = e->h16; Wi = e->w16;
+        }
+    }
+  }
+  if (!x) return fail("conv not benchable");
+  const int Ho = conv_out(Hi, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Wi, c.k, c.stride, c.dil, c.pad);
+  auto run = [&]() {
+    if (kind == 0) conv_fwd(e, ci, x, ldx, Hi, Wi, y, ldy, batch, nullptr, 0, true);
+    else if (kind == 1) conv_dgrad(e, ci, g, ldy, Hi, Wi, gx, ldx, batch, false, x, ldx, 0);
+    else conv_wgrad(e, ci, g, ldy, x, ldx, Hi, Wi, batch);
+  };
+  hipEvent_t a, b;
+  HIPOK(hipEventCreate(&a));
+  HIPOK(hipEventCreate(&b));
+  run();
+  HIPOK(hipEventRecord(a, e->s));
+  for (int i = 0; i < reps; ++i) run();
+  HIPOK(hipEventRecord(b, e->s));
+  HIPOK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPOK(hipEventElapsedTime(&ms, a, b));
+  *ms_host = ms / reps;
+  *flops_host = 2.0 * batch * Ho * Wo * (double)c.cout * c.cin * c.T();
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
   return 0;
 }
 

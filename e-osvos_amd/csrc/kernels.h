@@ -41,6 +41,7 @@ struct ConvArgs {
   int ldmask, mask_c0;
   int relu;
   int accum;            // dgrad: add the existing contents of y
+  int dst_up, Hf, Wf;   // dst_up=1: GEMM row (b,oy,ox) is written to pixel (b,2oy,2ox) of an Hf x Wf grid
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
 };
 // fills a.per, launches the stream-K kernel (+ the fix-up kernel when tiles are shared)

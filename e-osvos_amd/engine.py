@@ -191,6 +191,12 @@ class Engine:
         _ffi.check(self.lib.eosvos_time_hot_kernel(self.h, batch, reps, ctypes.byref(ms), ctypes.byref(fl)))
         return ms.value, fl.value
 
+    def bench_conv(self, conv_idx, kind, batch, reps=10):
+        """(ms, TFLOP/s) of one layer's fwd (0) / dgrad (1) / wgrad (2) launch."""
+        ms, fl = ctypes.c_float(), ctypes.c_double()
+        _ffi.check(self.lib.eosvos_bench_conv(self.h, conv_idx, kind, batch, reps, ctypes.byref(ms), ctypes.byref(fl)))
+        return ms.value, fl.value / (ms.value * 1e-3) / 1e12
+
     def mfma_probe(self, iters=20000):
         """Sustained fp32 MFMA TFLOP/s of this device (register-only calibration kernel)."""
         ms, fl = ctypes.c_float(), ctypes.c_double()

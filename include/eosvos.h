@@ -144,6 +144,10 @@ int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi);
  * average milliseconds in *ms_host and the algorithmic FLOPs per launch in *flops_host. */
 int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host,
                            double* flops_host);
+/* Tuning aid: average milliseconds of `reps` launches of conv `conv_idx`'s forward (kind 0), data
+ * gradient (1) or weight gradient (2) on the engine's own buffers, and its algorithmic FLOPs. */
+int eosvos_bench_conv(eosvos_engine* e, int conv_idx, int kind, int batch, int reps, float* ms_host,
+                      double* flops_host);
 /* Calibration: time one launch of `iters` x 16 back-to-back v_mfma_f32_32x32x2_f32 per wave on
  * register operands (2 workgroups x 4 waves on every CU, no memory traffic): the fp32 matrix
  * rate this device sustains at the clock it holds, next to the 157.3 TFLOP/s nominal peak. */
