@@ -698,22 +698,30 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
                                                               float* __restrict__ W, const float* __restrict__ ws,
                                                               const float* __restrict__ na, const float* __restrict__ lr,
                                                               float* __restrict__ gsum, float* __restrict__ gout) {
-  int ei = 0;
-  while (ei + 1 < nent && (int)blockIdx.x >= tab[ei + 1].blk0) ++ei;     // wave-uniform scan
-  const UpdEntry t = tab[ei];
+  // locate this workgroup's table entry: first-block offsets to LDS, then a binary search
+  __shared__ int blk0s[256];
+  for (int i = threadIdx.x; i < nent; i += 256) blk0s[i] = tab[i].blk0;
+  __syncthreads();
+  int lo = 0, hi = nent - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= blk0s[mid]) lo = mid; else hi = mid - 1;
+  }
+  const UpdEntry t = tab[lo];
   const int e0 = ((int)blockIdx.x - t.blk0) * 1024 + threadIdx.x * 4;
   if (e0 >= t.n) return;
-  const float* s0 = ws + t.ws_off + e0;
+  const size_t zstride = t.interleave ? 1024 : (size_t)t.slab;
+  const float* s0 = ws + t.ws_off + (t.interleave ? ((size_t)(e0 >> 10) * t.splits << 10) + (e0 & 1023) : (size_t)e0);
   float g[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e0 + 3 < t.n && (t.slab & 3) == 0) {
-#pragma unroll 4
+  if (e0 + 3 < t.n && ((t.slab & 3) == 0 || t.interleave)) {
+#pragma unroll 8
     for (int z = 0; z < t.splits; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(s0 + (size_t)z * t.slab);
+      const float4 v = *reinterpret_cast<const float4*>(s0 + z * zstride);
       g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
     }
   } else {
     for (int z = 0; z < t.splits; ++z)
-      for (int j = 0; j < 4 && e0 + j < t.n; ++j) g[j] += s0[(size_t)z * t.slab + j];
+      for (int j = 0; j < 4 && e0 + j < t.n; ++j) g[j] += s0[z * zstride + j];
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
