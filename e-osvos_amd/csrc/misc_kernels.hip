@@ -710,10 +710,10 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
   const UpdEntry t = tab[lo];
   const int e0 = ((int)blockIdx.x - t.blk0) * 1024 + threadIdx.x * 4;
   if (e0 >= t.n) return;
-  const size_t zstride = t.interleave ? 1024 : (size_t)t.slab;
-  const float* s0 = ws + t.ws_off + (t.interleave ? ((size_t)(e0 >> 10) * t.splits << 10) + (e0 & 1023) : (size_t)e0);
+  const size_t zstride = (size_t)t.slab;
+  const float* s0 = ws + t.ws_off + e0;
   float g[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e0 + 3 < t.n && ((t.slab & 3) == 0 || t.interleave)) {
+  if (e0 + 3 < t.n && (t.slab & 3) == 0) {
 #pragma unroll 8
     for (int z = 0; z < t.splits; ++z) {
       const float4 v = *reinterpret_cast<const float4*>(s0 + z * zstride);
