@@ -158,42 +158,109 @@ void launch_stem_fwd(const float* xpad, const float* w, const float* a, const fl
                      B, H, W, Ho, Wo);
 }
 
-// Stem weight gradient: each workgroup reduces one chunk of output pixels into a
-// [64][147] slab.  Thread t owns cout = t & 63 and 37 consecutive k of wave-uniform group
-// t >> 6, so the patch values are wave-uniform (scalar) operands.
+// Stem weight gradient on the matrix cores: dW[64][147] = sum_p G[p][64]^T * patch[p][147].
+// Each workgroup reduces one chunk of output pixels into a [64][147] slab.  Per 32-pixel K step
+// the G rows are staged with float4 loads and the 7x21 input patch of every pixel with scalar
+// loads (the 84-byte patch rows of the NHWC3 frame are only 4-byte aligned) by one thread per k,
+// which walks the pixels with carries; 2 x 5 accumulators of 32x32 cover 64 x 160 (147 padded).
+typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ xpad,
                                                           const float* __restrict__ g, float* __restrict__ ws,
                                                           int B, int H, int W, int Ho, int Wo, int chunks) {
+  constexpr int LDA = 68, LDB = 164;
+  __shared__ __attribute__((aligned(16))) float As[2][32 * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * LDB];
   const long P = (long)B * Ho * Wo;
-  const long per = (P + chunks - 1) / chunks;
+  const long per = ((P + chunks - 1) / chunks + 31) / 32 * 32;
   const long p0 = (long)blockIdx.x * per;
   long p1 = p0 + per;
   if (p1 > P) p1 = P;
-  const int co = threadIdx.x & 63;
-  const int kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int kbase = kg * 37;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
   const int Wp = W + 6, Hp = H + 6;
-  int koff[37];
+  const int k = tid;                                  // B staging: one thread per patch element k
+  const int koff = k < 147 ? (k / 21) * Wp * 3 + (k % 21) : 0;
+  const int a_row = tid >> 4, a_c4 = tid & 15;        // A staging: rows a_row, a_row+16
+  const int mt = wave & 1, nt0 = wave >> 1;           // accumulator tiles: (mt, nt0 + 2j), j = 0..2
+  stem_f32x16 acc[3];
 #pragma unroll
-  for (int i = 0; i < 37; ++i) {
-    int k = kbase + i;
-    if (k > 146) k = 146;
-    koff[i] = (k / 21) * Wp * 3 + (k % 21);
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  // zero the padded columns 147..163 of both B buffers once (they feed the unused part of tile 4)
+  for (int i = tid; i < 2 * 32 * (LDB - 147); i += 256) {
+    const int bb = i / (32 * (LDB - 147)), rem = i % (32 * (LDB - 147));
+    Bs[bb][(rem / (LDB - 147)) * LDB + 147 + rem % (LDB - 147)] = 0.f;
   }
-  float acc[37];
+  const int nsteps = p1 > p0 ? (int)((p1 - p0 + 31) / 32) : 0;
+  float4 ra[2];
+  float rb[32];
+  auto load_step = [&](int st) {
+    const long ps = p0 + (long)st * 32;
 #pragma unroll
-  for (int i = 0; i < 37; ++i) acc[i] = 0.f;
-  for (long p = p0; p < p1; ++p) {
-    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
-    const float gv = g[p * 64 + co];
-    const float* xr = xpad + (((long)b * Hp + oy * 2) * Wp + ox * 2) * 3;
+    for (int i = 0; i < 2; ++i) {
+      const long px = ps + a_row + i * 16;
+      ra[i] = px < p1 ? *reinterpret_cast<const float4*>(g + px * 64 + a_c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (k < 147) {
+      int ox = (int)(ps % Wo), oy = (int)((ps / Wo) % Ho), b = (int)(ps / ((long)Wo * Ho));
+      long base = (((long)b * Hp + oy * 2) * Wp + ox * 2) * 3 + koff;
 #pragma unroll
-    for (int i = 0; i < 37; ++i) acc[i] = fmaf(gv, xr[koff[i]], acc[i]);
+      for (int i = 0; i < 32; ++i) {
+        rb[i] = (ps + i) < p1 ? xpad[base] : 0.f;
+        base += 6;
+        if (++ox == Wo) {
+          ox = 0;
+          base += (long)(2 * Wp - 2 * Wo) * 3;
+          if (++oy == Ho) { oy = 0; base += (long)(Hp - 2 * Ho) * Wp * 3; }
+        }
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&As[buf][(a_row + i * 16) * LDA + a_c4 * 4]) = ra[i];
+    if (k < 147) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) Bs[buf][i * LDB + k] = rb[i];
+    }
+  };
+  if (nsteps > 0) { load_step(0); }
+  __syncthreads();
+  if (nsteps > 0) store_step(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    const bool more = st + 1 < nsteps;
+    if (more) load_step(st + 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float av = As[buf][(s2 * 2 + h) * LDA + mt * 32 + r];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int nt = nt0 + 2 * j;
+        if (nt < 5) {
+          const float bv = Bs[buf][(s2 * 2 + h) * LDB + nt * 32 + r];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
   }
-  float* out = ws + (long)blockIdx.x * (64 * 147) + co * 147;
+  float* out = ws + (long)blockIdx.x * (64 * 147);
 #pragma unroll
-  for (int i = 0; i < 37; ++i)
-    if (kbase + i < 147) out[kbase + i] = acc[i];
+  for (int j = 0; j < 3; ++j) {
+    const int nt = nt0 + 2 * j;
+    const int kk = nt * 32 + r;
+    if (nt < 5 && kk < 147) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        out[co * 147 + kk] = acc[j][e];
+      }
+    }
+  }
 }
 int stem_wgrad_chunks(int B, int Ho, int Wo) {
   const long P = (long)B * Ho * Wo;
