@@ -374,9 +374,16 @@ int conv_plan(ConvArgs& a) {
     }
   } else {
     const long U = tiles * ksteps;
-    if (U / nwg < 6) nwg = U / 6 > 0 ? U / 6 : 1;     // >= ~6 K-steps per workgroup
-    per = (U + nwg - 1) / nwg;
-    nwg = (U + per - 1) / per;
+#ifndef EOSVOS_MINK
+#define EOSVOS_MINK 3
+#endif
+    if (ksteps <= EOSVOS_MINK + 1) {
+      per = ksteps; nwg = tiles;                       // short K: one whole tile per workgroup, no fix-up
+    } else {
+      if (U / nwg < EOSVOS_MINK) nwg = U / EOSVOS_MINK > 0 ? U / EOSVOS_MINK : 1;   // >= MINK K-steps per workgroup
+      per = (U + nwg - 1) / nwg;
+      nwg = (U + per - 1) / per;
+    }
   }
   a.dp_q = (int)q; a.per = (int)per; a.nwg = (int)nwg;
   return (int)nwg;
