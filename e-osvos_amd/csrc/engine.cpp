@@ -157,6 +157,9 @@ struct eosvos_engine {
   Topo t;
   int arch, H, W, maxB, dev;
   hipStream_t s;
+  hipStream_t s2 = nullptr;            // side stream: weight-gradient kernels run beside the dgrad chain
+  std::vector<hipEvent_t> ev;          // one fork event per conv + a join event
+  bool side_used = false;
   int h2, w2, h4, w4, h8, w8, h16, w16;
   std::vector<void*> allocs;
 
@@ -275,7 +278,15 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
   a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T());
   trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits);
-  launch_wgrad(a, e->s);
+  if (e->s2) {
+    // fork: everything this wgrad reads (g, x) is complete at this point of stream s
+    (void)hipEventRecord(e->ev[ci], e->s);
+    (void)hipStreamWaitEvent(e->s2, e->ev[ci], 0);
+    launch_wgrad(a, e->s2);
+    e->side_used = true;
+  } else {
+    launch_wgrad(a, e->s);
+  }
   return a.splits;
 }
 // reduce slabs, scale by the frozen-norm a[cout], (optionally) theta <- theta - lr*g
@@ -439,6 +450,14 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   if (upload_resize(e, make_resize(e->w16, e->w4, true), e->w16, e->w4, e->up_w)) { eosvos_destroy(e); return 1; }
   if (upload_resize(e, make_resize(e->h4, H, false), e->h4, H, e->fin_h)) { eosvos_destroy(e); return 1; }
   if (upload_resize(e, make_resize(e->w4, W, false), e->w4, W, e->fin_w)) { eosvos_destroy(e); return 1; }
+  {
+    const char* v = getenv("EOSVOS_NO_SIDE_STREAM");
+    if (!(v && v[0] == '1')) {
+      HIPOK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+      e->ev.resize(t.convs.size() + 1);
+      for (auto& evt : e->ev) HIPOK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
+    }
+  }
   // identity norm until eosvos_set_norm
   launch_fill(e->na, t.nnorm, 1.f, e->s);
   launch_fill(e->nb, t.nnorm, 0.f, e->s);
@@ -449,8 +468,10 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
 
 int eosvos_destroy(eosvos_engine* e) {
   if (!e) return 0;
-  hipStreamSynchronize(e->s);
-  for (void* p : e->allocs) hipFree(p);
+  (void)hipStreamSynchronize(e->s);
+  if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
+  for (auto& evt : e->ev) (void)hipEventDestroy(evt);
+  for (void* p : e->allocs) (void)hipFree(p);
   delete e;
   return 0;
 }
@@ -662,6 +683,11 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     launch_stem_wgrad(e->xpad, e->g_c1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, s);
     apply_update(e, 0, chunks, update, accumulate);
   }
+  if (e->s2 && e->side_used) {           // join: the update reads every slab
+    (void)hipEventRecord(e->ev.back(), e->s2);
+    (void)hipStreamWaitEvent(e->s, e->ev.back(), 0);
+    e->side_used = false;
+  }
   if (flush_updates(e, B, update, accumulate)) return 1;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("backward launch: ") + hipGetErrorString(err));
@@ -865,11 +891,14 @@ int eosvos_bench_conv(eosvos_engine* e, int ci, int kind, int batch, int reps, f
   hipEvent_t a, b;
   HIPOK(hipEventCreate(&a));
   HIPOK(hipEventCreate(&b));
+  hipStream_t side = e->s2;
+  e->s2 = nullptr;                 // time everything on the main stream
   run();
   HIPOK(hipEventRecord(a, e->s));
   for (int i = 0; i < reps; ++i) run();
   HIPOK(hipEventRecord(b, e->s));
   HIPOK(hipEventSynchronize(b));
+  e->s2 = side;
   float ms = 0.f;
   HIPOK(hipEventElapsedTime(&ms, a, b));
   *ms_host = ms / reps;
