@@ -294,14 +294,20 @@ void apply_update(eosvos_engine* e, int ci, int splits, bool /*update*/, bool /*
   e->upd_splits[ci] = splits;     // the slabs stay parked; flush_updates() consumes them
 }
 // one launch: sum every layer's slabs, norm scale, theta <- theta - lr*g, optional gsum/gout
-int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate) {
+// part 0: convs [split, nconv) = layer4 + ASPP + decoder (90 % of the parameters), whose backward
+// finishes first; part 1: convs [0, split).  With a side stream part 0 is launched there as soon
+// as layer4's backward is queued and hides under the layer3..1 backward.
+int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int part, hipStream_t stream) {
   const Topo& t = e->t;
-  if (!e->upd_tab[B]) {
-    std::vector<UpdEntry> tab(t.convs.size());
+  const int split = t.blocks[t.blocks.size() - 3].c1;   // first conv of layer4
+  const int lo = part == 0 ? split : 0, hi = part == 0 ? (int)t.convs.size() : split;
+  const int slot = 2 * B + part;
+  if (!e->upd_tab[slot]) {
+    std::vector<UpdEntry> tab(hi - lo);
     int blk = 0;
-    for (size_t ci = 0; ci < t.convs.size(); ++ci) {
+    for (int ci = lo; ci < hi; ++ci) {
       const ConvL& c = t.convs[ci];
-      UpdEntry& u = tab[ci];
+      UpdEntry& u = tab[ci - lo];
       u.w_off = c.poff; u.ws_off = e->ws_off[ci];
       u.n = (int)(c.wsize() + (c.bias ? c.cout : 0)); u.slab = u.n;
       u.splits = e->upd_splits[ci]; u.rowlen = c.T() * c.cin;
@@ -311,11 +317,11 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate) {
     UpdEntry* d = (UpdEntry*)e->falloc((int64_t)(tab.size() * sizeof(UpdEntry) + 3) / 4);
     if (!d) return fail("hipMalloc update table");
     HIPOK(hipMemcpy(d, tab.data(), tab.size() * sizeof(UpdEntry), hipMemcpyHostToDevice));
-    e->upd_tab[B] = d; e->upd_blocks[B] = blk;
+    e->upd_tab[slot] = d; e->upd_blocks[slot] = blk;
   }
-  launch_sgd_update_all(e->upd_tab[B], (int)t.convs.size(), e->upd_blocks[B], e->Wp, e->ws_wg, e->na,
+  launch_sgd_update_all(e->upd_tab[slot], hi - lo, e->upd_blocks[slot], e->Wp, e->ws_wg, e->na,
                         update ? e->lr : nullptr, accumulate ? e->gsum : nullptr, e->keep_grads ? e->gout : nullptr,
-                        e->s);
+                        stream);
   return 0;
 }
 
@@ -385,8 +391,8 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   int64_t wsc = conv_ws_floats(), wsw = 0;
   e->ws_off.assign(t.convs.size(), 0);
   e->upd_splits.assign(t.convs.size(), 1);
-  e->upd_tab.assign(B + 1, nullptr);
-  e->upd_blocks.assign(B + 1, 0);
+  e->upd_tab.assign(2 * B + 2, nullptr);
+  e->upd_blocks.assign(2 * B + 2, 0);
   std::vector<int64_t> slabs(t.convs.size(), 0);   // floats of slab space per conv (max over batch sizes)
   auto track = [&](int ci, int Hin, int Win) {
     const ConvL& c = t.convs[ci];
@@ -454,7 +460,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     const char* v = getenv("EOSVOS_NO_SIDE_STREAM");
     if (!(v && v[0] == '1')) {
       HIPOK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
-      e->ev.resize(t.convs.size() + 1);
+      e->ev.resize(t.convs.size() + 2);
       for (auto& evt : e->ev) HIPOK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
     }
   }
@@ -646,7 +652,17 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     apply_update(e, t.aspp[i], sp, update, accumulate);
   }
   // bottlenecks, last to first.  g_out of each block = dL/d(pre-ReLU block output).
+  const int first_l4_block = (int)t.blocks.size() - 3;
   for (int i = (int)t.blocks.size() - 1; i >= 0; --i) {
+    if (i == first_l4_block - 1) {
+      // layer4, ASPP and decoder are done: update them now (on the side stream if there is one)
+      if (e->s2) {
+        (void)hipEventRecord(e->ev[t.convs.size()], e->s);      // their dgrads were the last readers of W
+        (void)hipStreamWaitEvent(e->s2, e->ev[t.convs.size()], 0);
+        if (flush_updates(e, B, update, accumulate, 0, e->s2)) return 1;
+        e->side_used = true;
+      } else if (flush_updates(e, B, update, accumulate, 0, e->s)) return 1;
+    }
     const Block& b = t.blocks[i];
     auto& f = e->bb[i];
     const int cmid = t.convs[b.c1].cout, cout = t.convs[b.c3].cout;
@@ -688,7 +704,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     (void)hipStreamWaitEvent(e->s, e->ev.back(), 0);
     e->side_used = false;
   }
-  if (flush_updates(e, B, update, accumulate)) return 1;
+  if (flush_updates(e, B, update, accumulate, 1, e->s)) return 1;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("backward launch: ") + hipGetErrorString(err));
   return 0;
