@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 H, W, BATCH = 480, 854, 3
 FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HOT_KERNEL_TRAFFIC_BYTES = (2 * 801.7e3 + 108.7e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
 
 
 def cpu_baseline(sd, lrs, x, y, seconds_budget=25.0):
@@ -115,7 +116,11 @@ def main():
     achieved = k_flops / (k_ms * 1e-3) / 1e12
     roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false> (decoder.last_conv.0 forward, 3x3 304->256 '
                 '@120x214, batch 3)', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MATRIX_PEAK, 'traffic': None, 'kernel_ms': k_ms,
+                'frac': achieved / FP32_MATRIX_PEAK,
+                # bytes per launch from the rocprofv3 --pmc passes of this kernel (separate runs,
+                # profiles/r01_pmc_hot_kernel.txt): 2*FETCH_SIZE (gfx950 half-count correction) +
+                # WRITE_SIZE; counts Infinity-Cache-served re-reads, algorithmic bytes are 175 MB
+                'traffic': HOT_KERNEL_TRAFFIC_BYTES if BATCH == 3 else None, 'kernel_ms': k_ms,
                 'flops_per_launch': k_flops,
                 'whole_step_tflops': BATCH * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12}
 
