@@ -289,3 +289,49 @@ def test_meta_trainer_single_rank(small_engine, weights):
     sd = mt.state_dict()
     assert list(sd)[0] == 'log_init_lr_backbone-conv1-weight' and len(sd) == 128
     eng.load_model_state(*weights)
+
+
+@pytest.mark.parametrize('shape', [(1, 97, 161), (2, 130, 182), (1, 480, 910)])
+def test_shape_polymorphism_vs_oracle(weights, shape):
+    """Odd / non-multiple-of-16 frame sizes (DAVIS 480p frames are not all 854 wide): forward logits and
+    one fine-tune step against the CPU oracle."""
+    from eosvos_amd.engine import Engine
+    from oracle import deeplab, meta
+    B, H, W = shape
+    sd, lrs = weights
+    x, y = synthetic.synthetic_frames(B, H, W, seed=21)
+    eng = Engine('resnet50', H, W, max_batch=B, device=DEV)
+    eng.load_model_state(sd, lrs)
+    with torch.no_grad():
+        ref = deeplab.forward(sd, x)
+    out = eng.forward(x.to(DEV)).cpu()
+    assert float((out - ref).abs().max()) < LOGIT_TOL
+    if H * W < 100000:
+        loss_ref, _, P = meta.finetune_step(sd, lrs, x, y)
+        loss = eng.finetune_step(x.to(DEV), y.to(DEV))
+        assert abs(loss - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
+        with torch.no_grad():
+            ref2 = deeplab.forward(P, x)
+        out2 = eng.forward(x.to(DEV)).cpu()
+        assert float((out2 - ref2).abs().max()) < 2e-3
+    eng.close()
+
+
+def test_resnet101_vs_oracle():
+    """The second encoder of the reference (`parent_model.encoder: resnet101`): 114 convs, 115 trainables."""
+    from eosvos_amd.engine import Engine
+    from oracle import deeplab, meta
+    sd = synthetic.synthetic_state('resnet101')
+    lrs = synthetic.synthetic_lrs('resnet101')
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=4)
+    eng = Engine('resnet101', *SMALL, max_batch=1, device=DEV)
+    assert eng.n_param == 59229633
+    eng.load_model_state(sd, lrs)
+    with torch.no_grad():
+        ref = deeplab.forward(sd, x, encoder='resnet101')
+    out = eng.forward(x.to(DEV)).cpu()
+    assert float((out - ref).abs().max()) < LOGIT_TOL
+    losses = [eng.finetune_step(x.to(DEV), y.to(DEV)) for _ in range(2)]
+    ref_losses, _ = meta.finetune(sd, lrs, [(x, y)] * 2, encoder='resnet101')
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-3)
+    eng.close()
