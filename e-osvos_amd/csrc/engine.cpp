@@ -176,6 +176,10 @@ struct eosvos_engine {
   float *cat, *g_cat, *vec, *gvec, *poolout, *gp, *colscratch, *proj, *g_proj;
   float *dcat, *g_dcat, *d1, *g_d1, *d2, *g_d2, *lowlog, *g_low, *logits, *dlogits, *loss_dev, *bce_partial;
   float *ws_conv, *ws_wg;
+  int norm_mode = 0;                  // EOSVOS_NORM_BN_FROZEN / EOSVOS_NORM_GN16
+  std::vector<float*> zbuf;           // GN: raw conv outputs (then, in backward, their gradients), dense [B*Ho*Wo][cout]
+  std::vector<float*> gn_stats;       // GN: per conv {mean, rstd} per (image, group)
+  float *gn_sums = nullptr, *gn_partial = nullptr;
   std::vector<int64_t> ws_off;       // per conv: offset of its weight-gradient slabs in ws_wg
   std::vector<int> upd_splits;       // per conv: slabs written by the current backward pass
   std::vector<UpdEntry*> upd_tab;    // per batch size: device copy of the update table
@@ -193,7 +197,10 @@ struct eosvos_engine {
     return (float*)p;
   }
   float* W_(int ci) { return Wp + t.convs[ci].poff; }
-  const float* A_(int ci) const { return t.convs[ci].norm ? na + t.convs[ci].noff : nullptr; }
+  bool gn() const { return norm_mode == EOSVOS_NORM_GN16; }
+  // BN: folded scale a (multiplies conv outputs / gradients); GN: none (gamma is applied by the GN kernels)
+  const float* A_(int ci) const { return (t.convs[ci].norm && !gn()) ? na + t.convs[ci].noff : nullptr; }
+  const float* G_(int ci) const { return na + t.convs[ci].noff; }   // GN: gamma
   const float* B_(int ci) const { return t.convs[ci].norm ? nb + t.convs[ci].noff : nullptr; }
 };
 
@@ -237,10 +244,18 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   a.N = c.cout; a.ldy = ldy; a.KH = a.KW = c.k;
   a.mul = c.stride; a.off0 = -c.pad; a.kstep = c.dil; a.upshift = 0;
   a.M = B * a.Ho * a.Wo; a.wN = c.cout; a.wK = c.cin; a.kmajor = 0;
-  a.scale = e->A_(ci); a.bias = e->B_(ci);
-  a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
+  const bool gn = e->gn() && c.norm;
+  if (gn) {                       // raw conv output -> GroupNorm kernels (statistics are data dependent)
+    a.y = e->zbuf[ci]; a.ldy = c.cout;
+  } else {
+    a.scale = e->A_(ci); a.bias = e->B_(ci);
+    a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
+  }
   trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a));
   launch_conv(a, e->s);
+  if (gn)
+    launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
+                      a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, e->s);
 }
 // gx[B,Hin,Win,cin] (ld ldgx) (+)= dgrad of conv ci applied to g[B,Ho,Wo,cout] (ld ldg)
 void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int Win, float* gx, int ldgx, int B,
@@ -248,6 +263,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
+  if (e->gn() && c.norm) { g = e->zbuf[ci]; ldg = c.cout; }   // gradient w.r.t. the raw conv output (conv_wgrad made it)
   a.x = g; a.w = e->W_(ci); a.y = gx; a.ws = e->ws_conv;
   a.B = B; a.Hi = conv_out(Hin, c.k, c.stride, c.dil, c.pad); a.Wi = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   a.ldx = ldg; a.Kc = c.cout;
@@ -270,6 +286,12 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
 // slabs of dW into ws_wg; returns the number of slabs
 int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x, int ldx, int Hin, int Win, int B) {
   const ConvL& c = e->t.convs[ci];
+  if (e->gn() && c.norm) {        // dz = GroupNorm backward of G_u, written over the stored raw output
+    const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
+    launch_gn_backward(e->zbuf[ci], c.cout, g, ldg, e->G_(ci), e->gn_stats[ci], e->gn_sums, e->gn_partial, B, Ho * Wo, c.cout,
+                       e->s);
+    g = e->zbuf[ci]; ldg = c.cout;
+  }
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.g = g; a.x = x; a.ws = e->ws_wg + e->ws_off[ci];
@@ -311,7 +333,7 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
       u.w_off = c.poff; u.ws_off = e->ws_off[ci];
       u.n = (int)(c.wsize() + (c.bias ? c.cout : 0)); u.slab = u.n;
       u.splits = e->upd_splits[ci]; u.rowlen = c.T() * c.cin;
-      u.lr_off = (int)c.lroff; u.norm_off = c.norm ? (int)c.noff : -1; u.blk0 = blk;
+      u.lr_off = (int)c.lroff; u.norm_off = (c.norm && !e->gn()) ? (int)c.noff : -1; u.blk0 = blk;
       blk += (u.n + 1023) / 1024;
     }
     UpdEntry* d = (UpdEntry*)e->falloc((int64_t)(tab.size() * sizeof(UpdEntry) + 3) / 4);
@@ -355,10 +377,11 @@ int64_t eosvos_norm_count(int arch) { Topo t; return build_topo(arch, t) ? t.nno
 int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int width, int max_batch,
                   int device_id, void* stream) {
   if (!out) return fail("null out");
-  if (norm_mode != EOSVOS_NORM_BN_FROZEN) return fail("only EOSVOS_NORM_BN_FROZEN is implemented");
+  if (norm_mode != EOSVOS_NORM_BN_FROZEN && norm_mode != EOSVOS_NORM_GN16) return fail("unknown norm mode");
   if (height < 32 || width < 32 || max_batch < 1) return fail("bad geometry");
   eosvos_engine* e = new eosvos_engine();
   if (!build_topo(arch, e->t)) { delete e; return fail("bad arch"); }
+  e->norm_mode = norm_mode;
   e->arch = arch; e->H = height; e->W = width; e->maxB = max_batch; e->dev = device_id;
   e->s = (hipStream_t)stream;
   HIPOK(hipSetDevice(device_id));
@@ -389,6 +412,16 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   { float* t8; ALLOC(t8, (n4 * 64 + 3) / 4); e->p1idx = (uint8_t*)t8; }
 
   int64_t wsc = conv_ws_floats(), wsw = 0;
+  e->zbuf.assign(t.convs.size(), nullptr);
+  e->gn_stats.assign(t.convs.size(), nullptr);
+  if (e->gn()) {
+    e->gn_sums = e->falloc((int64_t)B * 32);
+    e->gn_partial = e->falloc((int64_t)B * 16 * 64 * 2);
+    e->zbuf[0] = e->falloc((int64_t)B * e->h2 * e->w2 * 64);
+    e->gn_stats[0] = e->falloc((int64_t)B * 32);
+    e->zbuf[t.pool] = e->falloc((int64_t)B * 256);
+    e->gn_stats[t.pool] = e->falloc((int64_t)B * 32);
+  }
   e->ws_off.assign(t.convs.size(), 0);
   e->upd_splits.assign(t.convs.size(), 1);
   e->upd_tab.assign(2 * B + 2, nullptr);
@@ -402,6 +435,10 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     for (int b = 1; b <= B; ++b)
       slabs[ci] = max64(slabs[ci], (int64_t)wgrad_pick_splits(b * Ho * Wo, c.cout, c.cin, c.T()) * c.wsize());
     (void)Mf;
+    if (e->gn() && c.norm) {
+      e->zbuf[ci] = e->falloc((int64_t)B * Ho * Wo * c.cout);
+      e->gn_stats[ci] = e->falloc((int64_t)B * 32);
+    }
   };
   // bottleneck buffers
   int Hc = e->h4, Wc = e->w4, Cc = 64;
@@ -516,6 +553,11 @@ int eosvos_set_lr(eosvos_engine* e, const float* flat_lr) {
 int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, const float* mean,
                     const float* var, float eps) {
   if (!e || !gamma || !beta || !mean || !var) return fail("null argument");
+  if (e->gn()) {                  // GroupNorm shares the (frozen) affine only (deeplabv3plus.py:186-188)
+    HIPOK(hipMemcpyAsync(e->na, gamma, (size_t)e->t.nnorm * 4, hipMemcpyDeviceToDevice, e->s));
+    HIPOK(hipMemcpyAsync(e->nb, beta, (size_t)e->t.nnorm * 4, hipMemcpyDeviceToDevice, e->s));
+    return 0;
+  }
   launch_fold_norm(gamma, beta, mean, var, eps, e->na, e->nb, e->t.nnorm, e->s);
   HIPOK(hipGetLastError());
   return 0;
@@ -553,7 +595,13 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   const Topo& t = e->t;
   hipStream_t s = e->s;
   launch_nchw_to_nhwc_pad(images, e->xpad, B, 3, e->H, e->W, 3, s);
-  launch_stem_fwd(e->xpad, e->W_(0), e->A_(0), e->B_(0), e->c1, B, e->H, e->W, e->h2, e->w2, s);
+  if (e->gn()) {
+    launch_stem_fwd(e->xpad, e->W_(0), nullptr, nullptr, e->zbuf[0], B, e->H, e->W, e->h2, e->w2, s);
+    launch_gn_forward(e->zbuf[0], 64, e->G_(0), e->nb, nullptr, 0, e->c1, 64, e->gn_stats[0], e->gn_partial, B, e->h2 * e->w2, 64,
+                      1e-5f, 1, s);
+  } else {
+    launch_stem_fwd(e->xpad, e->W_(0), e->A_(0), e->B_(0), e->c1, B, e->H, e->W, e->h2, e->w2, s);
+  }
   launch_maxpool_fwd(e->c1, e->p1, e->p1idx, B, e->h2, e->w2, 64, e->h4, e->w4, s);
   for (size_t i = 0; i < t.blocks.size(); ++i) {
     const Block& b = t.blocks[i];
@@ -574,7 +622,13 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   for (int i = 0; i < 4; ++i)
     conv_fwd(e, t.aspp[i], l4, 2048, e->h16, e->w16, e->cat + 256 * i, 1280, B, nullptr, 0, true);
   launch_colsum(l4, 2048, e->vec, B, P16, 2048, 1.0f / (float)P16, e->colscratch, s);
-  launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, s);
+  if (e->gn()) {
+    launch_gemv_fwd(e->W_(t.pool), e->vec, nullptr, nullptr, e->zbuf[t.pool], B, 256, 2048, s);
+    launch_gn_forward(e->zbuf[t.pool], 256, e->G_(t.pool), e->nb + t.convs[t.pool].noff, nullptr, 0, e->poolout, 256,
+                      e->gn_stats[t.pool], e->gn_partial, B, 1, 256, 1e-5f, 1, s);
+  } else {
+    launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, s);
+  }
   launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s);
   conv_fwd(e, t.project, e->cat, 1280, e->h16, e->w16, e->proj, 256, B, nullptr, 0, true);
   const float* low = e->bb[t.layer1_last_block].out;
@@ -640,7 +694,12 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   // image-pooling branch: gp = sum_p g_cat[:,1024:1280]; g_l4 starts as the broadcast of its input gradient
   {
     launch_colsum(e->g_cat + 1024, 1280, e->gp, B, P16, 256, 1.f, e->colscratch, s);
-    launch_gemv_bwd(e->W_(t.pool), e->vec, e->gp, e->A_(t.pool), e->gvec, e->ws_wg + e->ws_off[t.pool], B, 256, 2048, s);
+    const float* gpz = e->gp;
+    if (e->gn()) {
+      launch_gn_backward(e->zbuf[t.pool], 256, e->gp, 256, e->G_(t.pool), e->gn_stats[t.pool], e->gn_sums, e->gn_partial, B, 1, 256, s);
+      gpz = e->zbuf[t.pool];
+    }
+    launch_gemv_bwd(e->W_(t.pool), e->vec, gpz, e->A_(t.pool), e->gvec, e->ws_wg + e->ws_off[t.pool], B, 256, 2048, s);
     launch_bcast_pixels(e->gvec, g_l4, 2048, B, P16, 2048, 1.0f / (float)P16, s);
     apply_update(e, t.pool, 1, update, accumulate);
   }
@@ -696,7 +755,12 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   launch_maxpool_bwd(e->g_p1, e->p1idx, e->c1, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s);
   {
     const int chunks = stem_wgrad_chunks(B, e->h2, e->w2);
-    launch_stem_wgrad(e->xpad, e->g_c1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, s);
+    const float* gc1 = e->g_c1;
+    if (e->gn()) {
+      launch_gn_backward(e->zbuf[0], 64, e->g_c1, 64, e->G_(0), e->gn_stats[0], e->gn_sums, e->gn_partial, B, e->h2 * e->w2, 64, s);
+      gc1 = e->zbuf[0];
+    }
+    launch_stem_wgrad(e->xpad, gc1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, s);
     apply_update(e, 0, chunks, update, accumulate);
   }
   if (e->s2 && e->side_used) {           // join: the update reads every slab

@@ -135,6 +135,12 @@ void launch_merge_labels(const float* probs, int n_obj, int64_t n_pix, uint8_t* 
 void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, const float* rowscale,
                        const float* lr, float* gsum, float* gout, int64_t rowlen, int64_t n,
                        hipStream_t s);
+// GroupNorm(16, C), frozen affine.  forward: stats + y = relu?(gn(z) (+res)); backward: z <- dL/dz.
+void launch_gn_forward(const float* z, int ldz, const float* gamma, const float* beta, const float* res, int ldres,
+                       float* y, int ldy, float* stats, float* partial, int B, int P, int C, float eps, int relu,
+                       hipStream_t s);
+void launch_gn_backward(float* z, int ldz, const float* g, int ldg, const float* gamma, const float* stats,
+                        float* sums, float* partial, int B, int P, int C, hipStream_t s);
 // Whole-network update in one launch: per-layer table over one slab arena.
 struct UpdEntry {
   long w_off;      // offset of the tensor (weight [+ bias]) in the parameter / gsum / gout arenas

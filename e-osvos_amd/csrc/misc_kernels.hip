@@ -144,10 +144,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int c4 = 0; c4 < 16; ++c4) {
     float4 v;
-    v.x = fmaxf(acc[c4 * 4 + 0] * a[c4 * 4 + 0] + bb[c4 * 4 + 0], 0.f);
-    v.y = fmaxf(acc[c4 * 4 + 1] * a[c4 * 4 + 1] + bb[c4 * 4 + 1], 0.f);
-    v.z = fmaxf(acc[c4 * 4 + 2] * a[c4 * 4 + 2] + bb[c4 * 4 + 2], 0.f);
-    v.w = fmaxf(acc[c4 * 4 + 3] * a[c4 * 4 + 3] + bb[c4 * 4 + 3], 0.f);
+    if (a) {
+      v.x = fmaxf(acc[c4 * 4 + 0] * a[c4 * 4 + 0] + bb[c4 * 4 + 0], 0.f);
+      v.y = fmaxf(acc[c4 * 4 + 1] * a[c4 * 4 + 1] + bb[c4 * 4 + 1], 0.f);
+      v.z = fmaxf(acc[c4 * 4 + 2] * a[c4 * 4 + 2] + bb[c4 * 4 + 2], 0.f);
+      v.w = fmaxf(acc[c4 * 4 + 3] * a[c4 * 4 + 3] + bb[c4 * 4 + 3], 0.f);
+    } else {        // raw conv output (GroupNorm mode)
+      v.x = acc[c4 * 4 + 0]; v.y = acc[c4 * 4 + 1]; v.z = acc[c4 * 4 + 2]; v.w = acc[c4 * 4 + 3];
+    }
     out[c4] = v;
   }
 }
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__
     s = fmaf(w4.x, v4.x, s); s = fmaf(w4.y, v4.y, s); s = fmaf(w4.z, v4.z, s); s = fmaf(w4.w, v4.w, s);
   }
   s = wave_sum(s);
-  if (lane == 0) y[wid] = fmaxf(s * a[n] + bb[n], 0.f);
+  if (lane == 0) y[wid] = a ? fmaxf(s * a[n] + bb[n], 0.f) : s;
 }
 void launch_gemv_fwd(const float* W, const float* v, const float* a, const float* b, float* y, int B, int N,
                      int K, hipStream_t s) {
@@ -502,7 +506,7 @@ __global__ void gemv_bwd_kernel(const float* __restrict__ W, const float* __rest
     if (e < nv) {
       const int k = (int)(e % K), b = (int)(e / K);
       float s = 0.f;
-      for (int n = 0; n < N; ++n) s = fmaf(gp[b * N + n] * a[n], W[(long)n * K + k], s);
+      for (int n = 0; n < N; ++n) s = fmaf(gp[b * N + n] * (a ? a[n] : 1.f), W[(long)n * K + k], s);
       gv[e] = s;
     } else {
       const long f = e - nv;
@@ -806,5 +810,117 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
 void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
                            const float* lr, float* gsum, float* gout, hipStream_t s) {
   hipLaunchKernelGGL(sgd_update_all_kernel, dim3(nblocks), dim3(256), 0, s, tab, nent, W, ws, na, lr, gsum, gout);
+}
+}  // namespace eosvos
+
+// ---- GroupNorm(16, C) with frozen affine (deeplabv3plus.py:180-191) ---------------------------------
+// NHWC tensors / channel slices (ld = floats per pixel).  Statistics per (image, group) over
+// P pixels x C/16 channels, two-stage deterministic reduction (float partials, double final).
+namespace eosvos {
+#define GN_CHUNKS 64
+// partial[(b*16+g)*GN_CHUNKS + chunk] = {sum u, sum u*v}   with (u,v) = (z, z)  or  (gamma*G, zhat)
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ z, int ldz,
+                                                          const float* __restrict__ g, int ldg,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ stats, float2* __restrict__ partial,
+                                                          int P, int C) {
+  __shared__ float sh[4];
+  const int bg = blockIdx.y, b = bg >> 4, grp = bg & 15, ch = blockIdx.x;
+  const int cg = C >> 4;
+  const int per = (P + GN_CHUNKS - 1) / GN_CHUNKS;
+  const int p0 = ch * per;
+  int p1 = p0 + per;
+  if (p1 > P) p1 = P;
+  const int n = (p1 > p0 ? p1 - p0 : 0) * cg;
+  float mu = 0.f, rs = 0.f;
+  if (BWD) { mu = stats[bg * 2]; rs = stats[bg * 2 + 1]; }
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int p = p0 + i / cg, c = grp * cg + i % cg;
+    const float zv = z[((size_t)b * P + p) * ldz + c];
+    if (BWD) {
+      const float u = gamma[c] * g[((size_t)b * P + p) * ldg + c];
+      s1 += u;
+      s2 += u * ((zv - mu) * rs);
+    } else {
+      s1 += zv;
+      s2 += zv * zv;
+    }
+  }
+  s1 = block_sum_256(s1, sh);
+  s2 = block_sum_256(s2, sh);
+  if (threadIdx.x == 0) partial[(size_t)bg * GN_CHUNKS + ch] = make_float2(s1, s2);
+}
+// forward: stats[bg] = {mean, rstd};  backward: sums[bg] = {S1/n, S2/n}
+__global__ void gn_final_kernel(const float2* __restrict__ partial, float* __restrict__ out, int nbg, double inv_n,
+                                float eps, int bwd) {
+  const int bg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bg >= nbg) return;
+  double a = 0.0, b = 0.0;
+  for (int c = 0; c < GN_CHUNKS; ++c) { const float2 v = partial[(size_t)bg * GN_CHUNKS + c]; a += v.x; b += v.y; }
+  if (bwd) { out[bg * 2] = (float)(a * inv_n); out[bg * 2 + 1] = (float)(b * inv_n); }
+  else {
+    const double mean = a * inv_n;
+    double var = b * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out[bg * 2] = (float)mean;
+    out[bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+// y = relu?( (z-mean)*rstd*gamma + beta (+ res) )
+__global__ void gn_apply_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy, int B, int P,
+                                int C, int relu) {
+  const int cg = C >> 4;
+  const long n = (long)B * P * C;
+  GRID_STRIDE(e, n) {
+    const int c = (int)(e % C);
+    const long pix = e / C;
+    const int b = (int)(pix / P);
+    const int bg = b * 16 + c / cg;
+    float v = (z[pix * ldz + c] - stats[bg * 2]) * stats[bg * 2 + 1] * gamma[c] + beta[c];
+    if (res) v += res[pix * ldres + c];
+    if (relu) v = fmaxf(v, 0.f);
+    y[pix * ldy + c] = v;
+  }
+}
+// dz = rstd * (gamma*G - S1/n - zhat*S2/n), written over z
+__global__ void gn_bwd_apply_kernel(float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg,
+                                    const float* __restrict__ stats, const float* __restrict__ sums,
+                                    const float* __restrict__ gamma, int B, int P, int C) {
+  const int cg = C >> 4;
+  const long n = (long)B * P * C;
+  GRID_STRIDE(e, n) {
+    const int c = (int)(e % C);
+    const long pix = e / C;
+    const int b = (int)(pix / P);
+    const int bg = b * 16 + c / cg;
+    const float rs = stats[bg * 2 + 1];
+    const float zh = (z[pix * ldz + c] - stats[bg * 2]) * rs;
+    z[pix * ldz + c] = rs * (gamma[c] * g[pix * ldg + c] - sums[bg * 2] - zh * sums[bg * 2 + 1]);
+  }
+}
+void launch_gn_forward(const float* z, int ldz, const float* gamma, const float* beta, const float* res, int ldres,
+                       float* y, int ldy, float* stats, float* partial, int B, int P, int C, float eps, int relu,
+                       hipStream_t s) {
+  hipLaunchKernelGGL((gn_partial_kernel<false>), dim3(GN_CHUNKS, B * 16), dim3(256), 0, s, z, ldz, nullptr, 0, nullptr,
+                     nullptr, (float2*)partial, P, C);
+  hipLaunchKernelGGL(gn_final_kernel, dim3((B * 16 + 63) / 64), dim3(64), 0, s, (const float2*)partial, stats, B * 16,
+                     1.0 / ((double)P * (C / 16)), eps, 0);
+  const long n = (long)B * P * C;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, z, ldz, stats, gamma, beta, res,
+                     ldres, y, ldy, B, P, C, relu);
+}
+void launch_gn_backward(float* z, int ldz, const float* g, int ldg, const float* gamma, const float* stats,
+                        float* sums, float* partial, int B, int P, int C, hipStream_t s) {
+  hipLaunchKernelGGL((gn_partial_kernel<true>), dim3(GN_CHUNKS, B * 16), dim3(256), 0, s, z, ldz, g, ldg, gamma, stats,
+                     (float2*)partial, P, C);
+  hipLaunchKernelGGL(gn_final_kernel, dim3((B * 16 + 63) / 64), dim3(64), 0, s, (const float2*)partial, sums, B * 16,
+                     1.0 / ((double)P * (C / 16)), 0.f, 1);
+  const long n = (long)B * P * C;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, z, ldz, g, ldg, stats, sums,
+                     gamma, B, P, C);
 }
 }  // namespace eosvos

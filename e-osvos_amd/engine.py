@@ -21,11 +21,14 @@ def _dev_f32(t, device):
 
 
 class Engine:
-    def __init__(self, encoder='resnet50', height=480, width=854, max_batch=3, device='cuda:0'):
+    def __init__(self, encoder='resnet50', height=480, width=854, max_batch=3, device='cuda:0', norm='bn'):
         if not torch.cuda.is_available():
             raise _ffi.EosvosError('no GPU visible: the e-osvos_amd engine has no CPU path')
         self.lib = _ffi.load()
         self.encoder = encoder
+        self.norm = norm
+        if norm not in ('bn', 'gn'):
+            raise NotImplementedError(norm)
         self.arch = ARCH_ID[encoder]
         self.device = torch.device(device)
         self.height, self.width, self.max_batch = height, width, max_batch
@@ -35,7 +38,7 @@ class Engine:
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.current_stream(self.device)
         h = ctypes.c_void_p()
-        _ffi.check(self.lib.eosvos_create(ctypes.byref(h), self.arch, 0, height, width, max_batch,
+        _ffi.check(self.lib.eosvos_create(ctypes.byref(h), self.arch, 1 if norm == 'gn' else 0, height, width, max_batch,
                                           self.device.index or 0, ctypes.c_void_p(self.stream.cuda_stream)))
         self.h = h
         self._loss = torch.zeros(1, device=self.device)
@@ -76,7 +79,11 @@ class Engine:
         self.set_init(torch.cat([state_dict[n].reshape(-1).float() for n in names]))
         nl = norm_layers(self.encoder)
         cat = lambda suf: torch.cat([state_dict[p + suf].reshape(-1).float() for p, _ in nl])
-        self.set_norm(cat('.weight'), cat('.bias'), cat('.running_mean'), cat('.running_var'))
+        if self.norm == 'gn':       # GroupNorm shares only the affine (no running statistics in the state dict)
+            g = cat('.weight')
+            self.set_norm(g, cat('.bias'), torch.zeros_like(g), torch.ones_like(g))
+        else:
+            self.set_norm(cat('.weight'), cat('.bias'), cat('.running_mean'), cat('.running_var'))
         if lrs is not None:
             self.set_lr(torch.cat([l.reshape(-1).float() for l in lrs]))
 

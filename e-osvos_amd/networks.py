@@ -47,14 +47,13 @@ class DeepLabV3Plus:
             raise NotImplementedError(backbone)
         if num_classes != 1:
             raise NotImplementedError('num_classes != 1')
-        if replace_batch_with_group_norms:
-            raise NotImplementedError('GroupNorm mode is not implemented yet (SURVEY.md 8f.1)')
         if not train_encoder:
             raise NotImplementedError('train_encoder=False')
         if batch_norm is not None and (batch_norm.get('accum_stats') or batch_norm.get('learn_weight')
                                        or batch_norm.get('learn_bias')):
             raise NotImplementedError('only frozen BatchNorm (accum_stats/learn_* False) is implemented')
         self.encoder = backbone
+        self.norm = 'gn' if replace_batch_with_group_norms else 'bn'
         self.device = torch.device(device)
         self.max_batch = max_batch
         self.training = True
@@ -77,9 +76,10 @@ class DeepLabV3Plus:
         for p, c in norm_layers(backbone):
             self._norm[p + '.weight'] = torch.ones(c)
             self._norm[p + '.bias'] = torch.zeros(c)
-            self._norm[p + '.running_mean'] = torch.zeros(c)
-            self._norm[p + '.running_var'] = torch.ones(c)
-            self._norm[p + '.num_batches_tracked'] = torch.zeros((), dtype=torch.long)
+            if self.norm == 'bn':
+                self._norm[p + '.running_mean'] = torch.zeros(c)
+                self._norm[p + '.running_var'] = torch.ones(c)
+                self._norm[p + '.num_batches_tracked'] = torch.zeros((), dtype=torch.long)
         self._params = OrderedDict((n, _Param(n, v, True)) for n, v in self._views.items())
 
     # ---- nn.Module-like surface ---------------------------------------------------------
@@ -124,12 +124,12 @@ class DeepLabV3Plus:
             k = int(torch.Size(s).numel())
             views[n] = cur[off:off + k].view(s).clone()
             off += k
-        for k in model_state_keys(self.encoder, 'bn'):
+        for k in model_state_keys(self.encoder, self.norm):
             out[k] = views[k] if k in views else self._norm[k].clone()
         return out
 
     def load_state_dict(self, sd, strict=True):
-        keys = model_state_keys(self.encoder, 'bn')
+        keys = model_state_keys(self.encoder, self.norm)
         if strict:
             missing = [k for k in keys if k not in sd]
             if missing:
@@ -149,7 +149,7 @@ class DeepLabV3Plus:
         if e is None or e.height != height or e.width != width or batch > e.max_batch:
             if e is not None:
                 e.close()
-            self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device))
+            self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm)
             self._dirty = True
         if self._dirty:
             self.push_state()
@@ -164,7 +164,11 @@ class DeepLabV3Plus:
         e.set_init(self._flat)
         nl = norm_layers(self.encoder)
         cat = lambda suf: torch.cat([self._norm[p + suf].reshape(-1).float() for p, _ in nl])
-        e.set_norm(cat('.weight'), cat('.bias'), cat('.running_mean'), cat('.running_var'))
+        if self.norm == 'gn':
+            g = cat('.weight')
+            e.set_norm(g, cat('.bias'), torch.zeros_like(g), torch.ones_like(g))
+        else:
+            e.set_norm(cat('.weight'), cat('.bias'), cat('.running_mean'), cat('.running_var'))
         if self._lr_flat is not None:
             e.set_lr(self._lr_flat)
         self._dirty = False

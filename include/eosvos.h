@@ -37,6 +37,7 @@ typedef struct eosvos_engine eosvos_engine;
 #define EOSVOS_ARCH_RESNET50 50
 #define EOSVOS_ARCH_RESNET101 101
 #define EOSVOS_NORM_BN_FROZEN 0 /* BatchNorm in eval mode, frozen affine (deeplabv3plus.py:148-155,259-265) */
+#define EOSVOS_NORM_GN16 1      /* GroupNorm(16, C) sharing the frozen BN affine (deeplabv3plus.py:180-191) */
 
 /* ---- library / topology (host only, no GPU needed) ------------------------------ */
 const char* eosvos_version(void);

@@ -335,3 +335,38 @@ def test_resnet101_vs_oracle():
     ref_losses, _ = meta.finetune(sd, lrs, [(x, y)] * 2, encoder='resnet101')
     np.testing.assert_allclose(losses, ref_losses, rtol=1e-3)
     eng.close()
+
+
+def test_groupnorm_mode_vs_golden_and_oracle(weights, golden_dir):
+    """`replace_batch_with_group_norms: True` (the shipped default, cfgs/meta.yaml:76): GroupNorm(16, C) with the
+    frozen BN affine.  Forward vs the reference-generated golden logits, gradients / fine-tune steps vs the
+    CPU oracle."""
+    from eosvos_amd.engine import Engine
+    from oracle import meta
+    g = np.load(os.path.join(golden_dir, 'g2_forward.npz'))
+    sd, lrs = weights
+    x, y = synthetic.synthetic_frames(2, *SMALL, seed=7)
+    eng = Engine('resnet50', *SMALL, max_batch=2, device=DEV, norm='gn')
+    eng.load_model_state(sd, lrs)
+    out = eng.forward(x.to(DEV)).cpu().numpy()
+    assert np.abs(out - g['small_gn_logits']).max() < LOGIT_TOL
+    eng.keep_grads(True)
+    eng.reset()
+    loss_ref, grads_ref, _ = meta.loss_and_grads(sd, x, y, norm='gn')
+    eng.forward(x.to(DEV), want_logits=False)
+    loss = eng.loss_bce(y.to(DEV))
+    eng.backward_step()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    gflat = eng.get_grads().cpu()
+    off = 0
+    for (n, shape), gr in zip(topology.trainable('resnet50'), grads_ref):
+        k = gr.numel()
+        assert relerr(gflat[off:off + k].view(shape), gr) < 2e-2, n
+        assert abs(float(gflat[off:off + k].double().norm()) - float(gr.double().norm())) <= 1e-2 * float(gr.norm()) + 1e-9, n
+        off += k
+    eng.keep_grads(False)
+    eng.reset()
+    losses = [eng.finetune_step(x.to(DEV), y.to(DEV)) for _ in range(3)]
+    ref_losses, _ = meta.finetune(sd, lrs, [(x, y)] * 3, norm='gn')
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-3)
+    eng.close()
