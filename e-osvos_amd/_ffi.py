@@ -36,6 +36,7 @@ _SIGNATURES = {
     'eosvos_restore_params': (ctypes.c_int, [_E]),
     'eosvos_forward': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, c_float_p]),
     'eosvos_loss_bce': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, c_float_p]),
+    'eosvos_loss': (ctypes.c_int, [_E, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p]),
     'eosvos_bce': (ctypes.c_int, [_E, c_float_p, c_float_p, ctypes.c_int64, c_float_p, c_float_p]),
     'eosvos_backward_step': (ctypes.c_int, [_E, ctypes.c_int]),
     'eosvos_finetune_step': (ctypes.c_int, [_E, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,

@@ -473,7 +473,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   ALLOC(e->d2, n4 * 256); ALLOC(e->g_d2, n4 * 256);
   ALLOC(e->lowlog, n4); ALLOC(e->g_low, n4);
   ALLOC(e->logits, (int64_t)B * H * W); ALLOC(e->dlogits, (int64_t)B * H * W);
-  ALLOC(e->loss_dev, 4); ALLOC(e->bce_partial, 1024);
+  ALLOC(e->loss_dev, 4); ALLOC(e->bce_partial, 4 * 1024 + 16);
   for (int i = 0; i < 4; ++i) track(t.aspp[i], e->h16, e->w16);
   track(t.project, e->h16, e->w16); track(t.dec1, e->h4, e->w4);
   track(t.dec_a, e->h4, e->w4); track(t.dec_b, e->h4, e->w4);
@@ -786,6 +786,17 @@ int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss
   if (!e || !masks) return fail("null argument");
   if (batch != e->lastB) return fail("loss batch differs from the last forward");
   launch_bce(e->logits, masks, e->dlogits, e->loss_dev, e->bce_partial, (int64_t)batch * e->H * e->W, e->s);
+  e->have_loss_grad = true;
+  if (loss_out) HIPOK(hipMemcpyAsync(loss_out, e->loss_dev, 4, hipMemcpyDeviceToDevice, e->s));
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_loss(eosvos_engine* e, int kind, const float* masks, int batch, float* loss_out) {
+  if (kind == EOSVOS_LOSS_BCE) return eosvos_loss_bce(e, masks, batch, loss_out);
+  if (!e || !masks) return fail("null argument");
+  if (kind != EOSVOS_LOSS_DICE && kind != EOSVOS_LOSS_BCE_DICE) return fail("unknown loss kind");
+  if (batch != e->lastB) return fail("loss batch differs from the last forward");
+  launch_dice(e->logits, masks, e->dlogits, e->loss_dev, e->bce_partial, (int64_t)batch * e->H * e->W, kind, e->s);
   e->have_loss_grad = true;
   if (loss_out) HIPOK(hipMemcpyAsync(loss_out, e->loss_dev, 4, hipMemcpyDeviceToDevice, e->s));
   HIPOK(hipGetLastError());

@@ -128,6 +128,9 @@ int last_bwd_chunks(int64_t P);
 // BCE-with-logits mean + gradient; loss accumulates deterministically through `partial`
 void launch_bce(const float* logits, const float* gt, float* dlogits, float* loss, float* partial,
                 int64_t n, hipStream_t s);
+// dice (kind 1) / BCE - log(1 - dice) (kind 2), whole batch flattened; partial >= 4*1024+4 floats
+void launch_dice(const float* logits, const float* gt, float* dlogits, float* loss, float* partial, int64_t n, int kind,
+                 hipStream_t s);
 void launch_sigmoid(const float* x, float* y, int64_t n, hipStream_t s);
 void launch_merge_labels(const float* probs, int n_obj, int64_t n_pix, uint8_t* labels, hipStream_t s);
 

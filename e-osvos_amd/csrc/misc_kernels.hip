@@ -924,3 +924,66 @@ void launch_gn_backward(float* z, int ldz, const float* g, int ldg, const float*
                      gamma, B, P, C);
 }
 }  // namespace eosvos
+
+// ---- dice / BCE+dice losses (loss_dice.py:4-40, helper_func.py:43-54), batch_average=True ------------
+// stage 1: per-block partials {sum p*y, sum p, sum y, sum bce}; stage 2: scalars; stage 3: dlogits
+namespace eosvos {
+__global__ __launch_bounds__(256) void dice_partial_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            float4* __restrict__ partial, long n) {
+  __shared__ float sh[4];
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  GRID_STRIDE(i, n) {
+    const float xv = x[i], tv = t[i];
+    const float e = expf(-fabsf(xv));
+    const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    a += p * tv; b += p; c += tv;
+    d += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
+  }
+  a = block_sum_256(a, sh); b = block_sum_256(b, sh); c = block_sum_256(c, sh); d = block_sum_256(d, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = make_float4(a, b, c, d);
+}
+// scal = {loss, c_y, c_1, bce_w}:  dL/dx = bce_w*(p - y) + (c_y*y + c_1)*p*(1-p)
+__global__ __launch_bounds__(256) void dice_final_kernel(const float4* __restrict__ partial, int nb, long n, int kind,
+                                                          float* __restrict__ loss, float* __restrict__ scal) {
+  __shared__ double sh[4][4];
+  double a = 0, b = 0, c = 0, d = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) { const float4 v = partial[i]; a += v.x; b += v.y; c += v.z; d += v.w; }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = a; sh[w][1] = b; sh[w][2] = c; sh[w][3] = d; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double I = 0, Sp = 0, Sy = 0, Sb = 0;
+    for (int k = 0; k < 4; ++k) { I += sh[k][0]; Sp += sh[k][1]; Sy += sh[k][2]; Sb += sh[k][3]; }
+    const double num = 2.0 * I + 1.0, D = Sp + Sy + 1.0;
+    const double dice = 1.0 - num / D;
+    if (kind == 1) {            // dice:  dL/dp = -(2y*D - num)/D^2
+      loss[0] = (float)dice;
+      scal[1] = (float)(-2.0 / D); scal[2] = (float)(num / (D * D)); scal[3] = 0.f;
+    } else {                    // BCE - log(1 - dice) = BCE - log(num/D):  dL/dp = -2y/num + 1/D
+      loss[0] = (float)(Sb / (double)n - log(num / D));
+      scal[1] = (float)(-2.0 / num); scal[2] = (float)(1.0 / D); scal[3] = (float)(1.0 / (double)n);
+    }
+    scal[0] = loss[0];
+  }
+}
+__global__ void dice_grad_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ scal,
+                                 float* __restrict__ dx, long n) {
+  const float cy = scal[1], c1 = scal[2], bw = scal[3];
+  GRID_STRIDE(i, n) {
+    const float xv = x[i], tv = t[i];
+    const float e = expf(-fabsf(xv));
+    const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[i] = bw * (p - tv) + (cy * tv + c1) * p * (1.f - p);
+  }
+}
+void launch_dice(const float* logits, const float* gt, float* dlogits, float* loss, float* partial /*>=4*1024+4*/, int64_t n,
+                 int kind, hipStream_t s) {
+  const int nb = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(dice_partial_kernel, dim3(nb), dim3(256), 0, s, logits, gt, (float4*)partial, (long)n);
+  hipLaunchKernelGGL(dice_final_kernel, dim3(1), dim3(256), 0, s, (const float4*)partial, nb, (long)n, kind, loss,
+                     partial + 4 * 1024);
+  hipLaunchKernelGGL(dice_grad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, logits, gt, partial + 4 * 1024, dlogits,
+                     (long)n);
+}
+}  // namespace eosvos

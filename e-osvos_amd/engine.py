@@ -125,6 +125,14 @@ class Engine:
         _ffi.check(self.lib.eosvos_loss_bce(self.h, _ptr(masks), masks.shape[0], _ptr(loss)))
         return loss
 
+    def loss(self, kind, masks):
+        """kind: 'cross_entropy' | 'dice' | 'cross_entropy_and_dice' (compute_loss names); leaves dL/dlogits."""
+        k = {'cross_entropy': 0, 'dice': 1, 'cross_entropy_and_dice': 2}[kind]
+        assert masks.is_cuda and masks.dtype == torch.float32 and masks.is_contiguous()
+        out = torch.empty(1, device=self.device)
+        _ffi.check(self.lib.eosvos_loss(self.h, k, _ptr(masks), masks.shape[0], _ptr(out)))
+        return out
+
     def bce(self, logits, masks):
         """Mean BCE-with-logits of arbitrary device tensors (no gradient kept)."""
         logits, masks = logits.contiguous(), masks.contiguous()

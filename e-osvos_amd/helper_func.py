@@ -7,9 +7,9 @@
   early_stopping      `helper_func.py:388-397`
   EpochSampler        `helper_func.py:521-545`
   set_random_seeds    `helper_func.py:515-518`
-Losses the north_star does not name (`dice`, `cross_entropy_and_dice`,
-`class_balanced_cross_entropy`) raise NotImplementedError -- same error type the reference
-raises for unknown names (`:55-56`).
+`dice` (`networks/loss_dice.py:4-40`) and `cross_entropy_and_dice` (`:45-54`) run as fused HIP
+kernels too; `class_balanced_cross_entropy` raises NotImplementedError -- the error type the
+reference raises for unknown names (`:55-56`).
 """
 import random
 
@@ -23,17 +23,19 @@ def compute_loss(loss_func, outputs, gts, loss_kwargs=None):
     """`compute_loss(loss_func, outputs, gts, loss_kwargs=None)`, helper_func.py:28-56.  The returned
     0-dim loss carries the engine handle so `MetaOptimizer.step(loss)` can run the backward."""
     loss_kwargs = loss_kwargs or {}
-    if loss_func != 'cross_entropy':
-        raise NotImplementedError(f"loss_func='{loss_func}': only 'cross_entropy' (BCE) is on the MI355X hot path")
+    if loss_func not in ('cross_entropy', 'dice', 'cross_entropy_and_dice'):
+        raise NotImplementedError(f"loss_func='{loss_func}'")
     eng = getattr(outputs, '_eosvos_engine', None)
     if eng is None:
         raise RuntimeError('compute_loss needs logits produced by eosvos_amd.networks.DeepLabV3Plus '
                            '(there is no CPU/eager path)')
     gts = gts.contiguous().float()
     if loss_kwargs.get('batch_average', True):
-        loss = eng.loss_bce(gts).view(())             # also leaves dL/dlogits in the engine
+        loss = eng.loss(loss_func, gts).view(())      # also leaves dL/dlogits in the engine
         loss._eosvos_engine = eng
         return loss
+    if loss_func != 'cross_entropy':
+        raise NotImplementedError('per-sample (batch_average=False) values are implemented for cross_entropy only')
     return torch.cat([eng.bce(outputs[b], gts[b]) for b in range(outputs.shape[0])])
 
 

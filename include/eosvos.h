@@ -91,6 +91,13 @@ int eosvos_forward(eosvos_engine* e, const float* images, int batch, float* logi
 /* Fused BCE-with-logits (mean over B*H*W, helper_func.py:32-37) of the last forward and
  * its gradient.  loss_out: one device float (may be NULL). */
 int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss_out);
+/* Same for the other losses of compute_loss (helper_func.py:28-56), batch_average=True:
+ * EOSVOS_LOSS_DICE = `dice` (networks/loss_dice.py:4-40, the config default cfgs/meta.yaml:68),
+ * EOSVOS_LOSS_BCE_DICE = `cross_entropy_and_dice` (helper_func.py:45-54). */
+#define EOSVOS_LOSS_BCE 0
+#define EOSVOS_LOSS_DICE 1
+#define EOSVOS_LOSS_BCE_DICE 2
+int eosvos_loss(eosvos_engine* e, int kind, const float* masks, int batch, float* loss_out);
 /* Stand-alone BCE-with-logits mean over n elements of caller tensors (compute_loss with
  * `batch_average: False` per sample, helper_func.py:36-39; run_loader metrics :131-134).
  * dlogits_out may be NULL (engine scratch is used; a pending eosvos_loss_bce gradient is

@@ -99,3 +99,21 @@ def bce_loss(logits, gt, batch_average=True):
         return F.binary_cross_entropy_with_logits(logits, gt)
     l = F.binary_cross_entropy_with_logits(logits, gt, reduction='none')
     return l.view(l.shape[0], -1).mean(dim=1)
+
+
+def dice_loss(logits, gt):
+    """`dice_loss(output, label, batch_average=True)`, `src/networks/loss_dice.py:4-31`."""
+    pred = torch.sigmoid(logits).reshape(-1)
+    lab = gt.reshape(-1)
+    return 1 - (2.0 * (pred * lab).sum() + 1.0) / (pred.sum() + lab.sum() + 1.0)
+
+
+def loss_fn(name, logits, gt):
+    """`compute_loss` names, `src/util/helper_func.py:28-56` (batch_average=True)."""
+    if name == 'cross_entropy':
+        return bce_loss(logits, gt)
+    if name == 'dice':
+        return dice_loss(logits, gt)
+    if name == 'cross_entropy_and_dice':
+        return bce_loss(logits, gt) - (1 - dice_loss(logits, gt)).log()
+    raise NotImplementedError(name)

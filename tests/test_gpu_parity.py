@@ -370,3 +370,25 @@ def test_groupnorm_mode_vs_golden_and_oracle(weights, golden_dir):
     ref_losses, _ = meta.finetune(sd, lrs, [(x, y)] * 3, norm='gn')
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-3)
     eng.close()
+
+
+@pytest.mark.parametrize('name', ['dice', 'cross_entropy_and_dice'])
+def test_dice_losses_vs_oracle(small_engine, weights, name):
+    """The other `compute_loss` losses (dice is the reference's config default): value, dL/dlogits and one
+    fine-tune step against the CPU oracle (which test_oracle_golden pins to the reference's functions)."""
+    from oracle import deeplab
+    eng = small_engine
+    eng.load_model_state(*weights)
+    x, y = synthetic.synthetic_frames(2, *SMALL, seed=9)
+    logits = eng.forward(x.to(DEV))
+    loss = eng.loss(name, y.to(DEV))
+    lg = logits.cpu().clone().requires_grad_(True)
+    ref = deeplab.loss_fn(name, lg, y)
+    (dref,) = torch.autograd.grad(ref, lg)
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    d = eng.debug_tensor('dlogits').cpu()
+    assert float((d - dref).abs().max()) <= 1e-4 * float(dref.abs().max()) + 1e-10
+    eng.backward_step()          # the step runs on that gradient
+    out2 = eng.forward(x.to(DEV))
+    assert bool(torch.isfinite(out2).all()) and float((out2 - logits).abs().max()) > 0
+    eng.load_model_state(*weights)

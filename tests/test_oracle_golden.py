@@ -97,6 +97,12 @@ def test_g3_loss(golden_dir):
     lg, gt = torch.from_numpy(g['logits']), torch.from_numpy(g['gt'])
     assert abs(float(deeplab.bce_loss(lg, gt)) - g['mean'][0]) < 1e-6
     np.testing.assert_allclose(deeplab.bce_loss(lg, gt, False).numpy(), g['per_sample'], rtol=1e-6)
+    for name, key in (('dice', 'dice'), ('cross_entropy_and_dice', 'ce_dice')):
+        x = lg.clone().requires_grad_(True)
+        l = deeplab.loss_fn(name, x, gt)
+        assert abs(float(l) - g[key][0]) < 2e-6 * max(1.0, abs(g[key][0]))
+        (d,) = torch.autograd.grad(l, x)
+        np.testing.assert_allclose(d.numpy(), g[key + '_dlogits'], rtol=1e-4, atol=1e-9)
 
 
 def _meta_inputs():
