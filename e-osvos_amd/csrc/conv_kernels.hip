@@ -365,7 +365,12 @@ int conv_plan(ConvArgs& a) {
   const long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   long nwg = CONV_MAX_WG, q = 0, per = 0;
-  if (tiles >= nwg) {
+#ifndef EOSVOS_DPK
+#define EOSVOS_DPK 0
+#endif
+  if (tiles >= nwg && ksteps <= EOSVOS_DPK) {
+    q = 1; nwg = tiles;                                  // short K, many tiles: one tile per workgroup, no fix-up
+  } else if (tiles >= nwg) {
     q = tiles / nwg;
     const long rem = tiles - q * nwg;
     if (rem > 0) {
@@ -438,7 +443,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   const int co0 = (tile / it) * BMO, ci0 = (tile % it) * BNI;
   const int ky = tap / p.KW, kx = tap - ky * p.KW;
 
-  const int P = p.B * p.Ho * p.Wo;
+  // Only the output pixels whose tap lands inside the input contribute: a rectangle
+  // [oy_lo, oy_hi] x [ox_lo, ox_hi] per image (for the dilated 3x3 convs of layer4 / ASPP on the
+  // 30x54 map the corner taps of d = 18 see 27 % of the pixels).  K runs over that rectangle only.
+  const int dyk = ky * p.dil - p.pad, dxk = kx * p.dil - p.pad;
+  auto cdiv = [](int a, int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };      // ceil, b > 0
+  auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };        // floor, b > 0
+  int oy_lo = cdiv(-dyk, p.stride), oy_hi = fdiv(p.Hi - 1 - dyk, p.stride);
+  int ox_lo = cdiv(-dxk, p.stride), ox_hi = fdiv(p.Wi - 1 - dxk, p.stride);
+  if (oy_lo < 0) oy_lo = 0;
+  if (ox_lo < 0) ox_lo = 0;
+  if (oy_hi > p.Ho - 1) oy_hi = p.Ho - 1;
+  if (ox_hi > p.Wo - 1) ox_hi = p.Wo - 1;
+  const int hv = oy_hi - oy_lo + 1 > 0 ? oy_hi - oy_lo + 1 : 0;
+  const int wv = ox_hi - ox_lo + 1 > 0 ? ox_hi - ox_lo + 1 : 0;
+  const int P = p.B * hv * wv;                         // contributing pixels
   const int steps = (P + BKP - 1) / BKP;
   const int st_begin = (int)(((long)steps * z) / p.splits);
   const int st_end = (int)(((long)steps * (z + 1)) / p.splits);
@@ -451,40 +470,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   const bool b_cok = (ci0 + b_c4 * 4) < p.Cin;
 
   float4 ra[APASS], rb[BPASS];
-  // Each staging row follows one pixel per K step: its (image, y, x) advances by BKP pixels
-  // per step with carries instead of divisions; masked / padded rows use the out-of-range
-  // offset of a range-checked buffer load (returns 0), so the loop has no divergent branches.
+  // Each staging row follows one pixel per K step: its (image, y, x) inside the rectangle
+  // advances by BKP pixels per step with carries instead of divisions; rows past the end use
+  // the out-of-range offset of a range-checked buffer load (returns 0): no divergent branches.
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.g, (long)P * p.ldg * 4);
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.g, (long)p.B * p.Ho * p.Wo * p.ldg * 4);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
-  int b_img[BPASS], b_oy[BPASS], b_ox[BPASS];
+  int a_img[APASS], a_ry[APASS], a_rx[APASS];
+  int b_img[BPASS], b_ry[BPASS], b_rx[BPASS];
   {
-    const int hw = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      const int px = st_begin * BKP + b_r + i * BROWS;
-      const int bb = px / hw, rem = px - bb * hw;
-      b_img[i] = bb; b_oy[i] = rem / p.Wo; b_ox[i] = rem - b_oy[i] * p.Wo;
-    }
-  }
-  const int dyk = ky * p.dil - p.pad, dxk = kx * p.dil - p.pad;
-  auto load_tiles = [&](int st) {      // must be called with consecutive st
-    const int p0 = st * BKP;
+    const int hw = hv * wv > 0 ? hv * wv : 1, wv1 = wv > 0 ? wv : 1;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      const int px = p0 + a_r + i * AROWS;
-      const unsigned off = (a_cok && px < P) ? (unsigned)(px * p.ldg + co0 + a_c4 * 4) * 4u : OOB;
-      ra[i] = bufld4(rg, off);
+      const int q = st_begin * BKP + a_r + i * AROWS;
+      const int bb = q / hw, rem = q - bb * hw;
+      a_img[i] = bb; a_ry[i] = rem / wv1; a_rx[i] = rem - a_ry[i] * wv1;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-      const int iy = b_oy[i] * p.stride + dyk, ix = b_ox[i] * p.stride + dxk;
-      const bool ok = b_cok && b_img[i] < p.B && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      const int q = st_begin * BKP + b_r + i * BROWS;
+      const int bb = q / hw, rem = q - bb * hw;
+      b_img[i] = bb; b_ry[i] = rem / wv1; b_rx[i] = rem - b_ry[i] * wv1;
+    }
+  }
+  auto load_tiles = [&](int st) {      // must be called with consecutive st
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const bool ok = a_cok && a_img[i] < p.B;
+      const unsigned off = ok ? (unsigned)(((a_img[i] * p.Ho + oy_lo + a_ry[i]) * p.Wo + ox_lo + a_rx[i]) * p.ldg + co0 + a_c4 * 4) * 4u : OOB;
+      ra[i] = bufld4(rg, off);
+      a_rx[i] += BKP;
+      while (a_rx[i] >= wv && wv > 0) { a_rx[i] -= wv; ++a_ry[i]; }
+      while (a_ry[i] >= hv && hv > 0) { a_ry[i] -= hv; ++a_img[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int iy = (oy_lo + b_ry[i]) * p.stride + dyk, ix = (ox_lo + b_rx[i]) * p.stride + dxk;
+      const bool ok = b_cok && b_img[i] < p.B;
       const unsigned off = ok ? (unsigned)(((b_img[i] * p.Hi + iy) * p.Wi + ix) * p.ldx + ci0 + b_c4 * 4) * 4u : OOB;
       rb[i] = bufld4(rx, off);
-      b_ox[i] += BKP;
-      while (b_ox[i] >= p.Wo) { b_ox[i] -= p.Wo; ++b_oy[i]; }
-      while (b_oy[i] >= p.Ho) { b_oy[i] -= p.Ho; ++b_img[i]; }
+      b_rx[i] += BKP;
+      while (b_rx[i] >= wv && wv > 0) { b_rx[i] -= wv; ++b_ry[i]; }
+      while (b_ry[i] >= hv && hv > 0) { b_ry[i] -= hv; ++b_img[i]; }
     }
   };
   auto store_tiles = [&](int buf) {

@@ -78,7 +78,7 @@ def test_reference_style_finetune_loop(model_and_optim, golden_dir):
                        {'batch_average': False})
     assert per.shape == (3,)
     with pytest.raises(NotImplementedError):
-        compute_loss('dice', out, out)
+        compute_loss('class_balanced_cross_entropy', out, out)
 
 
 def test_reference_style_meta_task(model_and_optim, golden_dir):
