@@ -17,6 +17,8 @@
 // gather) are the same kernel.
 #include "kernels.h"
 
+#include <vector>
+
 namespace eosvos {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -99,7 +101,10 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
   const int ksteps = T * chunks;
   const int nt = (p.N + BN - 1) / BN;
   const int tiles = ((p.M + BM - 1) / BM) * nt;
-  const long U = (long)tiles * ksteps;
+  // tprefix != null: per-tile list of the K steps that can contribute (filter taps that fall wholly
+  // into the padding for every pixel of the tile are dropped -- dilated 3x3 convs on the 30x54 map);
+  // units are then counted in that compacted space
+  const long U = p.tprefix ? (long)p.tprefix[tiles] : (long)tiles * ksteps;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   // data-parallel part: dp_q whole tiles per workgroup; stream-K part: `per` units of the rest
   const long sk0 = (long)p.dp_q * gridDim.x * ksteps;
@@ -128,11 +133,32 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
       ++dp_i;
       if (tile >= tiles) continue;
     } else if (u < u_end) {
-      tile = (int)(u / ksteps);
-      ks_begin = (int)(u - (long)tile * ksteps);
+      if (p.tprefix) {
+        int lo = 0, hi = tiles - 1;                 // last tile with tprefix[tile] <= u
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if ((long)p.tprefix[mid] <= u) lo = mid; else hi = mid - 1;
+        }
+        tile = lo;
+        ks_begin = (int)(u - p.tprefix[tile]);
+        ks_end = p.tprefix[tile + 1] - p.tprefix[tile];
+      } else {
+        tile = (int)(u / ksteps);
+        ks_begin = (int)(u - (long)tile * ksteps);
+      }
       if ((long)ks_end - ks_begin > u_end - u) ks_end = ks_begin + (int)(u_end - u);
     } else {
       break;
+    }
+    const int ks_total = p.tprefix ? p.tprefix[tile + 1] - p.tprefix[tile] : ksteps;
+    // valid taps of this tile packed 4 bits each (tap-major K order inside a tile)
+    unsigned long long tappack = 0x876543210ULL;
+    if (p.tprefix) {
+      const int mask = p.tmask[tile];
+      tappack = 0;
+      int nv = 0;
+      for (int t2 = 0; t2 < T; ++t2)
+        if ((mask >> t2) & 1) { tappack |= (unsigned long long)t2 << (4 * nv); ++nv; }
     }
     const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
 
@@ -173,8 +199,9 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
     }
     int cur_tap = -1;
     auto load_tiles = [&](int ks) {
-      const int tap = ks / chunks;
-      const int c0 = (ks - tap * chunks) * BK;
+      const int vt = ks / chunks;
+      const int c0 = (ks - vt * chunks) * BK;
+      const int tap = p.tprefix ? (int)((tappack >> (4 * vt)) & 15) : vt;
       if (tap != cur_tap) {          // wave-uniform
         cur_tap = tap;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -293,7 +320,7 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
         for (int e = 0; e < 16; ++e)
           Cs[(wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (BN / 2) + tn * 32 + r] = acc[tm][tn][e];
     __syncthreads();
-    const bool full = (ks_begin == 0 && ks_end == ksteps);
+    const bool full = (ks_begin == 0 && ks_end == ks_total);
     constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
     const int c_c4 = tid % CF4, c_r = tid / CF4;
     if (full) {
@@ -327,7 +354,8 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   const int nt = (p.N + BN - 1) / BN;
   const int tile = p.dp_q * p.nwg + blockIdx.x;
   const long sk0 = (long)p.dp_q * p.nwg * ksteps;
-  const long a = (long)tile * ksteps, b = a + ksteps;
+  const long a = p.tprefix ? (long)p.tprefix[tile] : (long)tile * ksteps;
+  const long b = p.tprefix ? (long)p.tprefix[tile + 1] : a + ksteps;
   const int g0 = (int)((a - sk0) / p.per), g1 = (int)((b - 1 - sk0) / p.per);
   if (g0 == g1) return;                       // computed whole by one workgroup
   const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
@@ -350,6 +378,40 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
     const size_t md = dst_pixel(p, m);
     *reinterpret_cast<float4*>(p.y + md * p.ldy + n) = conv_epilogue4(p, s, md, n);
   }
+}
+
+// Host: per-tile compacted K-step prefix and valid-tap masks for a unit-stride gather (upshift 0).
+// Returns the total number of valid K steps.  prefix has tiles+1 entries, mask tiles entries.
+long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vector<int>& mask) {
+  const int bn = (a.N > 64) ? 128 : 64;
+  const int T = a.KH * a.KW;
+  const int chunks = (a.Kc + EOSVOS_BK - 1) / EOSVOS_BK;
+  const int nt = (a.N + bn - 1) / bn, mt = (a.M + 127) / 128;
+  prefix.assign((size_t)mt * nt + 1, 0);
+  mask.assign((size_t)mt * nt, 0);
+  long total = 0;
+  for (int tm = 0; tm < mt; ++tm) {
+    int mk = 0;
+    for (int m = tm * 128; m < a.M && m < tm * 128 + 128; ++m) {
+      const int hw = a.Ho * a.Wo, rem = m % hw;
+      const int oy = rem / a.Wo, ox = rem % a.Wo;
+      for (int t2 = 0; t2 < T; ++t2) {
+        const int ky = t2 / a.KW, kx = t2 % a.KW;
+        const int sy = oy * a.mul + a.off0 + ky * a.kstep, sx = ox * a.mul + a.off0 + kx * a.kstep;
+        if (sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi) mk |= 1 << t2;
+      }
+    }
+    int nv = 0;
+    for (int t2 = 0; t2 < T; ++t2) nv += (mk >> t2) & 1;
+    for (int tn = 0; tn < nt; ++tn) {
+      const size_t tile = (size_t)tm * nt + tn;
+      prefix[tile] = (int)total;
+      mask[tile] = mk;
+      total += (long)nv * chunks;
+    }
+  }
+  prefix.back() = (int)total;
+  return total;
 }
 
 #define CONV_MAX_WG 512
@@ -378,11 +440,11 @@ int conv_plan(ConvArgs& a) {
       if (per < 2) { per = 0; q = (tiles + nwg - 1) / nwg; nwg = (tiles + q - 1) / q; }  // tiny K: whole tiles only
     }
   } else {
-    const long U = tiles * ksteps;
+    const long U = a.total_units > 0 ? a.total_units : tiles * ksteps;
 #ifndef EOSVOS_MINK
 #define EOSVOS_MINK 3
 #endif
-    if (ksteps <= EOSVOS_MINK + 1) {
+    if (ksteps <= EOSVOS_MINK + 1 && a.total_units <= 0) {
       per = ksteps; nwg = tiles;                       // short K: one whole tile per workgroup, no fix-up
     } else {
       if (U / nwg < EOSVOS_MINK) nwg = U / EOSVOS_MINK > 0 ? U / EOSVOS_MINK : 1;   // >= MINK K-steps per workgroup
@@ -409,7 +471,7 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const int T = a.KH * a.KW;
   const long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long sk_tiles = tiles - (long)a.dp_q * nwg;
-  if (a.per > 0 && sk_tiles > 0 && a.per % ksteps != 0) {   // some tile is shared between workgroups
+  if (a.per > 0 && sk_tiles > 0 && (a.per % ksteps != 0 || a.tprefix)) {   // some tile is shared between workgroups
     if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);
     else hipLaunchKernelGGL((conv_fixup_kernel<64>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);
   }

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -180,6 +181,8 @@ struct eosvos_engine {
   std::vector<float*> zbuf;           // GN: raw conv outputs (then, in backward, their gradients), dense [B*Ho*Wo][cout]
   std::vector<float*> gn_stats;       // GN: per conv {mean, rstd} per (image, group)
   float *gn_sums = nullptr, *gn_partial = nullptr;
+  struct TapTab { int* prefix; int* mask; long total; };
+  std::map<long, TapTab> tap_tabs;    // (conv, fwd/dgrad, batch) -> compacted K-step table of a dilated conv
   std::vector<int64_t> ws_off;       // per conv: offset of its weight-gradient slabs in ws_wg
   std::vector<int> upd_splits;       // per conv: slabs written by the current backward pass
   std::vector<UpdEntry*> upd_tab;    // per batch size: device copy of the update table
@@ -221,6 +224,31 @@ int upload_resize(eosvos_engine* e, const HostResize& h, int in, int out, Resize
 }
 
 // ---- conv helpers -----------------------------------------------------------------------------
+// Dilated 3x3 convs on the stride-16 map: drop the (tile, tap) K steps whose tap falls into the
+// padding for every pixel of the tile.  Tables are built once per (conv, pass, batch).
+void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
+  const ConvL& c = e->t.convs[ci];
+  if (c.k != 3 || c.dil < 2 || a.upshift != 0) return;
+  const int bn = (a.N > 64) ? 128 : 64;
+  const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  if (tiles >= 512) return;                       // the data-parallel plan keeps whole tiles
+  const long key = ((long)ci * 2 + kind) * 64 + B;
+  auto it = e->tap_tabs.find(key);
+  if (it == e->tap_tabs.end()) {
+    std::vector<int> prefix, mask;
+    const long total = conv_build_tap_table(a, prefix, mask);
+    eosvos_engine::TapTab tt{nullptr, nullptr, total};
+    tt.prefix = (int*)e->falloc((int64_t)prefix.size());
+    tt.mask = (int*)e->falloc((int64_t)mask.size());
+    if (!tt.prefix || !tt.mask) return;
+    if (hipMemcpy(tt.prefix, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+    if (hipMemcpy(tt.mask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+    it = e->tap_tabs.emplace(key, tt).first;
+  }
+  if (it->second.total >= tiles * (long)c.T() * ((a.Kc + 31) / 32)) return;   // nothing to skip
+  a.tprefix = it->second.prefix; a.tmask = it->second.mask; a.total_units = it->second.total;
+}
+
 int ksteps_of(int T, int kc) { return T * ((kc + 31) / 32); }
 // EOSVOS_TRACE=1: one stderr line per MFMA launch (joined with rocprofv3's kernel trace by
 // tools/layer_report.py to get per-layer TFLOP/s)
@@ -251,6 +279,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     a.scale = e->A_(ci); a.bias = e->B_(ci);
     a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
   }
+  attach_tap_table(e, ci, 0, B, a);
   trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a));
   launch_conv(a, e->s);
   if (gn)
@@ -280,6 +309,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     a.Ho = a.Hi; a.Wo = a.Wi; a.mul = 1; a.off0 = 0; a.kstep = 0; a.upshift = 0;
     a.M = B * a.Ho * a.Wo; a.dst_up = 1; a.Hf = Hin; a.Wf = Win;
   }
+  attach_tap_table(e, ci, 1, B, a);
   trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
   launch_conv(a, e->s);
 }

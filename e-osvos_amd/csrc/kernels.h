@@ -42,6 +42,9 @@ struct ConvArgs {
   int relu;
   int accum;            // dgrad: add the existing contents of y
   int dst_up, Hf, Wf;   // dst_up=1: GEMM row (b,oy,ox) is written to pixel (b,2oy,2ox) of an Hf x Wf grid
+  const int* tprefix;   // optional (device): compacted K-step prefix per tile (tiles+1), see conv_build_tap_table
+  const int* tmask;     // optional (device): valid-tap bit mask per tile
+  long total_units;     // sum of valid K steps when tprefix is set, else 0
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
 };
 // fills a.per, launches the stream-K kernel (+ the fix-up kernel when tiles are shared)
@@ -49,7 +52,11 @@ void launch_conv(ConvArgs& a, hipStream_t s);
 int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
 // calibration: back-to-back fp32 MFMAs, returns the FLOPs the launch performs
 double launch_mfma_probe(float* scratch, int iters, hipStream_t s);
-int64_t conv_ws_floats();            // size of ConvArgs::ws the launch may use
+int64_t conv_ws_floats();
+}  // namespace eosvos
+#include <vector>
+namespace eosvos {
+long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vector<int>& mask);            // size of ConvArgs::ws the launch may use
 
 // Weight gradient: ws[z][cout][tap][cin] = sum over the z-th pixel chunk of
 //   G[p][cout] * X[src(p,tap)][cin]
