@@ -430,9 +430,9 @@ int conv_plan(ConvArgs& a) {
 #ifndef EOSVOS_DPK
 #define EOSVOS_DPK 0
 #endif
-  if (tiles >= nwg && ksteps <= EOSVOS_DPK) {
+  if (tiles >= nwg && ksteps <= EOSVOS_DPK && a.total_units <= 0) {
     q = 1; nwg = tiles;                                  // short K, many tiles: one tile per workgroup, no fix-up
-  } else if (tiles >= nwg) {
+  } else if (tiles >= nwg && a.total_units <= 0) {
     q = tiles / nwg;
     const long rem = tiles - q * nwg;
     if (rem > 0) {

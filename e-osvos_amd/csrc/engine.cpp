@@ -231,7 +231,7 @@ void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
   if (c.k != 3 || c.dil < 2 || a.upshift != 0) return;
   const int bn = (a.N > 64) ? 128 : 64;
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
-  if (tiles >= 512) return;                       // the data-parallel plan keeps whole tiles
+  if (tiles > 1024) return;                       // keep the partial-tile slab count bounded
   const long key = ((long)ci * 2 + kind) * 64 + B;
   auto it = e->tap_tabs.find(key);
   if (it == e->tap_tabs.end()) {
