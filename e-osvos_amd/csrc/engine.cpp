@@ -168,6 +168,12 @@ struct eosvos_engine {
   float *Wp = nullptr, *Winit = nullptr, *Wsnap = nullptr, *lr = nullptr, *na = nullptr, *nb = nullptr;
   float *gsum = nullptr, *gout = nullptr, *stage = nullptr;
   bool keep_grads = false;
+  // learned-lr storage level (meta_optim.py:27-67): the update consumes `lr` (per neuron) or `lr_elem`
+  int loss_kind = EOSVOS_LOSS_BCE;      // loss of the fused entry points (eosvos_set_loss)
+  int lr_level = EOSVOS_LR_NEURON, lr_log = 0;
+  float *lr_elem = nullptr, *glr_tmp = nullptr, *ptmp = nullptr;
+  int *row_tensor = nullptr, *tensor_row0 = nullptr, *all_row0 = nullptr;
+  int ntensors = 0;
   // activations
   float *xpad, *c1, *p1;
   uint8_t* p1idx;
@@ -372,8 +378,8 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
     e->upd_tab[slot] = d; e->upd_blocks[slot] = blk;
   }
   launch_sgd_update_all(e->upd_tab[slot], hi - lo, e->upd_blocks[slot], e->Wp, e->ws_wg, e->na,
-                        update ? e->lr : nullptr, accumulate ? e->gsum : nullptr, e->keep_grads ? e->gout : nullptr,
-                        stream);
+                        update ? e->lr : nullptr, (update && e->lr_level == EOSVOS_LR_PARAM) ? e->lr_elem : nullptr,
+                        accumulate ? e->gsum : nullptr, e->keep_grads ? e->gout : nullptr, stream);
   return 0;
 }
 
@@ -578,6 +584,70 @@ int eosvos_set_init(eosvos_engine* e, const float* flat_params) {
 int eosvos_set_lr(eosvos_engine* e, const float* flat_lr) {
   if (!e || !flat_lr) return fail("null argument");
   HIPOK(hipMemcpyAsync(e->lr, flat_lr, (size_t)e->t.nlr * 4, hipMemcpyDeviceToDevice, e->s));
+  e->lr_level = EOSVOS_LR_NEURON; e->lr_log = 0;
+  return 0;
+}
+static int64_t lr_store_count(const Topo& t, int level) {
+  int ntens = 0;
+  for (const ConvL& c : t.convs) ntens += c.bias ? 2 : 1;
+  switch (level) {
+    case EOSVOS_LR_NEURON: return t.nlr;
+    case EOSVOS_LR_TENSOR: return ntens;
+    case EOSVOS_LR_SINGLE: return 1;
+    case EOSVOS_LR_PARAM: return t.nparam;
+  }
+  return -1;
+}
+int64_t eosvos_lr_store_count(int arch, int level) {
+  Topo t;
+  if (!build_topo(arch, t)) return -1;
+  return lr_store_count(t, level);
+}
+static int ensure_lr_maps(eosvos_engine* e) {
+  if (e->row_tensor) return 0;
+  const Topo& t = e->t;
+  std::vector<int> rt((size_t)t.nlr), r0;
+  int ti = 0;
+  for (const ConvL& c : t.convs) {      // trainable tensors in named_parameters() order: weight [, bias]
+    r0.push_back((int)c.lroff);
+    for (int r = 0; r < c.cout; ++r) rt[c.lroff + r] = ti;
+    ++ti;
+    if (c.bias) {
+      r0.push_back((int)c.lroff + c.cout);
+      for (int r = 0; r < c.cout; ++r) rt[c.lroff + c.cout + r] = ti;
+      ++ti;
+    }
+  }
+  r0.push_back((int)t.nlr);
+  e->ntensors = ti;
+  e->row_tensor = (int*)e->falloc(t.nlr);
+  e->tensor_row0 = (int*)e->falloc(ti + 1);
+  e->all_row0 = (int*)e->falloc(2);
+  e->glr_tmp = e->falloc(t.nlr);
+  if (!e->row_tensor || !e->tensor_row0 || !e->all_row0 || !e->glr_tmp) return fail("hipMalloc lr maps");
+  const int all[2] = {0, (int)t.nlr};
+  HIPOK(hipMemcpy(e->row_tensor, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->tensor_row0, r0.data(), r0.size() * 4, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->all_row0, all, 8, hipMemcpyHostToDevice));
+  return 0;
+}
+int eosvos_set_lr_state(eosvos_engine* e, int level, int use_log, const float* store) {
+  if (!e || !store) return fail("null argument");
+  if (lr_store_count(e->t, level) < 0) return fail("unknown lr hierarchy level");
+  if (ensure_lr_maps(e)) return 1;
+  if (level == EOSVOS_LR_PARAM) {
+    if (!e->lr_elem) {
+      e->lr_elem = e->falloc(e->t.nparam);
+      e->ptmp = e->falloc(e->t.nparam);
+      if (!e->lr_elem || !e->ptmp) return fail("hipMalloc per-parameter lr");
+    }
+    import_params(e, store, e->lr_elem);
+    if (use_log) launch_exp_inplace(e->lr_elem, e->t.nparam, e->s);
+  } else {
+    launch_lr_expand(store, e->row_tensor, e->lr, (int)e->t.nlr, level, use_log, e->s);
+  }
+  HIPOK(hipGetLastError());
+  e->lr_level = level; e->lr_log = use_log ? 1 : 0;
   return 0;
 }
 int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, const float* mean,
@@ -824,12 +894,19 @@ int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss
 int eosvos_loss(eosvos_engine* e, int kind, const float* masks, int batch, float* loss_out) {
   if (kind == EOSVOS_LOSS_BCE) return eosvos_loss_bce(e, masks, batch, loss_out);
   if (!e || !masks) return fail("null argument");
-  if (kind != EOSVOS_LOSS_DICE && kind != EOSVOS_LOSS_BCE_DICE) return fail("unknown loss kind");
+  if (kind != EOSVOS_LOSS_DICE && kind != EOSVOS_LOSS_BCE_DICE && kind != EOSVOS_LOSS_CLASS_BALANCED_BCE)
+    return fail("unknown loss kind");
   if (batch != e->lastB) return fail("loss batch differs from the last forward");
   launch_dice(e->logits, masks, e->dlogits, e->loss_dev, e->bce_partial, (int64_t)batch * e->H * e->W, kind, e->s);
   e->have_loss_grad = true;
   if (loss_out) HIPOK(hipMemcpyAsync(loss_out, e->loss_dev, 4, hipMemcpyDeviceToDevice, e->s));
   HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_set_loss(eosvos_engine* e, int kind) {
+  if (!e) return fail("null engine");
+  if (kind < EOSVOS_LOSS_BCE || kind > EOSVOS_LOSS_CLASS_BALANCED_BCE) return fail("unknown loss kind");
+  e->loss_kind = kind;
   return 0;
 }
 int eosvos_bce(eosvos_engine* e, const float* logits, const float* masks, int64_t n, float* loss_out,
@@ -850,7 +927,7 @@ int eosvos_backward_step(eosvos_engine* e, int accumulate) {
 int eosvos_finetune_step(eosvos_engine* e, const float* images, const float* masks, int batch, int accumulate,
                          float* loss_host) {
   if (eosvos_forward(e, images, batch, nullptr)) return 1;
-  if (eosvos_loss_bce(e, masks, batch, nullptr)) return 1;
+  if (eosvos_loss(e, e->loss_kind, masks, batch, nullptr)) return 1;
   if (backward_impl(e, true, accumulate != 0)) return 1;
   if (loss_host) {
     HIPOK(hipMemcpyAsync(loss_host, e->loss_dev, 4, hipMemcpyDeviceToHost, e->s));
@@ -900,20 +977,40 @@ int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, 
   if (!e || !images || !masks || !flat_meta_grad) return fail("null argument");
   if (!e->gsum) return fail("eosvos_meta_grad without eosvos_meta_task_begin");
   if (eosvos_forward(e, images, batch, nullptr)) return 1;
-  if (eosvos_loss_bce(e, masks, batch, nullptr)) return 1;
+  if (eosvos_loss(e, e->loss_kind, masks, batch, nullptr)) return 1;
   const bool keep = e->keep_grads;
   e->keep_grads = true;
   const int rc = backward_impl(e, false, false);
   e->keep_grads = keep;
   if (rc) return 1;
   const Topo& t = e->t;
-  for (const ConvL& c : t.convs) {
-    launch_meta_lr_grad(e->gsum + c.poff, e->gout + c.poff, flat_meta_grad + c.lroff, c.cout, (int64_t)c.T() * c.cin, e->s);
-    if (c.bias)
-      launch_meta_lr_grad(e->gsum + c.poff + c.wsize(), e->gout + c.poff + c.wsize(), flat_meta_grad + c.lroff + c.cout,
-                          c.cout, 1, e->s);
+  const int64_t nstore = lr_store_count(t, e->lr_level);
+  if (e->lr_level == EOSVOS_LR_PARAM) {
+    launch_meta_lr_grad_elem(e->gsum, e->gout, e->lr_log ? e->lr_elem : nullptr, e->ptmp, t.nparam, e->s);
+    export_params(e, e->ptmp, flat_meta_grad, 1.f, 1);
+  } else {
+    // per-neuron d/d lr first (into the caller's buffer directly when that is the stored level)
+    const bool direct = e->lr_level == EOSVOS_LR_NEURON && !e->lr_log;
+    float* gl = direct ? flat_meta_grad : e->glr_tmp;
+    if (!direct) {
+      if (ensure_lr_maps(e)) return 1;
+      HIPOK(hipMemsetAsync(e->glr_tmp, 0, (size_t)t.nlr * 4, e->s));
+    }
+    for (const ConvL& c : t.convs) {
+      launch_meta_lr_grad(e->gsum + c.poff, e->gout + c.poff, gl + c.lroff, c.cout, (int64_t)c.T() * c.cin, e->s);
+      if (c.bias)
+        launch_meta_lr_grad(e->gsum + c.poff + c.wsize(), e->gout + c.poff + c.wsize(), gl + c.lroff + c.cout,
+                            c.cout, 1, e->s);
+    }
+    if (e->lr_level == EOSVOS_LR_NEURON) {
+      if (!direct) launch_lr_grad_neuron(gl, e->lr, flat_meta_grad, (int)t.nlr, e->lr_log, e->s);
+    } else if (e->lr_level == EOSVOS_LR_TENSOR) {
+      launch_lr_grad_reduce(gl, e->lr, e->tensor_row0, flat_meta_grad, e->ntensors, e->lr_log, e->s);
+    } else {
+      launch_lr_grad_reduce(gl, e->lr, e->all_row0, flat_meta_grad, 1, e->lr_log, e->s);
+    }
   }
-  export_params(e, e->gout, flat_meta_grad + t.nlr, 1.f, 1);
+  export_params(e, e->gout, flat_meta_grad + nstore, 1.f, 1);
   HIPOK(hipGetLastError());
   if (meta_loss_host) {
     HIPOK(hipMemcpyAsync(meta_loss_host, e->loss_dev, 4, hipMemcpyDeviceToHost, e->s));

@@ -164,7 +164,16 @@ struct UpdEntry {
   int blk0;        // first workgroup of this entry (1024 elements per workgroup)
 };
 void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
-                           const float* lr, float* gsum, float* gout, hipStream_t s);
+                           const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s);
+// learning-rate hierarchy (meta_optim.py:27-67): stored lr state -> effective per-neuron lr, and back
+void launch_lr_expand(const float* store, const int* row_tensor, float* lr, int nlr, int level, int use_log,
+                      hipStream_t s);
+void launch_exp_inplace(float* p, int64_t n, hipStream_t s);
+void launch_lr_grad_reduce(const float* g, const float* lr, const int* row0, float* out, int ngroups, int use_log,
+                           hipStream_t s);
+void launch_lr_grad_neuron(const float* g, const float* lr, float* out, int n, int use_log, hipStream_t s);
+void launch_meta_lr_grad_elem(const float* gsum, const float* G, const float* lr_elem, float* out, int64_t n,
+                              hipStream_t s);
 // g_lr[c] += -sum_row(gsum*G) ;  (G itself is exported by launch_ohwi_to_oihw with add=1)
 void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen,
                          hipStream_t s);

@@ -757,6 +757,67 @@ void launch_clamp(float* p, int64_t n, float lo, float hi, hipStream_t s) {
   hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, (long)n, lo, hi);
 }
 
+// ---- learning-rate hierarchy levels (meta_optim.py:27-67,157-163,180-185) -------------------------
+// The update always consumes a per-neuron (or per-element) EFFECTIVE lr; the learned state is stored
+// per tensor (TENSOR), once (SINGLE), per neuron or per element, possibly as log(lr).
+// level: 0 NEURON, 1 TENSOR, 2 SINGLE
+__global__ void lr_expand_kernel(const float* __restrict__ store, const int* __restrict__ row_tensor,
+                                 float* __restrict__ lr, int nlr, int level, int use_log) {
+  GRID_STRIDE(r, nlr) {
+    const float v = store[level == 0 ? r : (level == 1 ? row_tensor[r] : 0)];
+    lr[r] = use_log ? expf(v) : v;
+  }
+}
+void launch_lr_expand(const float* store, const int* row_tensor, float* lr, int nlr, int level, int use_log,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(lr_expand_kernel, dim3(grid_for(nlr, 256)), dim3(256), 0, s, store, row_tensor, lr, nlr, level,
+                     use_log);
+}
+__global__ void exp_inplace_kernel(float* p, long n) {
+  GRID_STRIDE(i, n) p[i] = expf(p[i]);
+}
+void launch_exp_inplace(float* p, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(exp_inplace_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, (long)n);
+}
+// d/d store from the per-neuron d/d lr: chain rule of exp() for log storage, then the sum over the
+// neurons that share a stored value (autograd of `repeat` / broadcasting).  One block per stored value
+// group: block t reduces rows [row0[t], row0[t+1]).
+__global__ __launch_bounds__(256) void lr_grad_reduce_kernel(const float* __restrict__ g, const float* __restrict__ lr,
+                                                              const int* __restrict__ row0, float* __restrict__ out,
+                                                              int use_log) {
+  __shared__ float sh[4];
+  const int lo = row0[blockIdx.x], hi = row0[blockIdx.x + 1];
+  float s = 0.f;
+  for (int r = lo + threadIdx.x; r < hi; r += 256) s += use_log ? g[r] * lr[r] : g[r];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] += s;
+}
+void launch_lr_grad_reduce(const float* g, const float* lr, const int* row0, float* out, int ngroups, int use_log,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(lr_grad_reduce_kernel, dim3(ngroups), dim3(256), 0, s, g, lr, row0, out, use_log);
+}
+__global__ void lr_grad_neuron_kernel(const float* __restrict__ g, const float* __restrict__ lr,
+                                      float* __restrict__ out, int n, int use_log) {
+  GRID_STRIDE(r, n) out[r] += use_log ? g[r] * lr[r] : g[r];
+}
+void launch_lr_grad_neuron(const float* g, const float* lr, float* out, int n, int use_log, hipStream_t s) {
+  hipLaunchKernelGGL(lr_grad_neuron_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g, lr, out, n, use_log);
+}
+// PARAM level: out[e] = -gsum[e] * G[e] (* lr_elem[e] for log storage), engine layout
+__global__ void meta_lr_grad_elem_kernel(const float* __restrict__ gsum, const float* __restrict__ G,
+                                         const float* __restrict__ lr_elem, float* __restrict__ out, long n) {
+  GRID_STRIDE(i, n) {
+    float v = -gsum[i] * G[i];
+    if (lr_elem) v *= lr_elem[i];
+    out[i] = v;
+  }
+}
+void launch_meta_lr_grad_elem(const float* gsum, const float* G, const float* lr_elem, float* out, int64_t n,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(meta_lr_grad_elem_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, gsum, G, lr_elem, out,
+                     (long)n);
+}
+
 }  // namespace eosvos
 
 // ---- one launch for the whole network's update ----------------------------------------------------
@@ -768,6 +829,7 @@ namespace eosvos {
 __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __restrict__ tab, int nent,
                                                               float* __restrict__ W, const float* __restrict__ ws,
                                                               const float* __restrict__ na, const float* __restrict__ lr,
+                                                              const float* __restrict__ lr_elem,
                                                               float* __restrict__ gsum, float* __restrict__ gout) {
   // locate this workgroup's table entry: first-block offsets to LDS, then a binary search
   __shared__ int blk0s[256];
@@ -802,14 +864,16 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
     float gv = g[j];
     if (t.norm_off >= 0) gv *= na[t.norm_off + row];
     float* wp = W + t.w_off + e;
-    if (lr) *wp = *wp - lr[t.lr_off + row] * gv;
+    if (lr_elem) *wp = *wp - lr_elem[t.w_off + e] * gv;      // lr_hierarchy_level PARAM
+    else if (lr) *wp = *wp - lr[t.lr_off + row] * gv;
     if (gsum) gsum[t.w_off + e] += gv;
     if (gout) gout[t.w_off + e] = gv;
   }
 }
 void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
-                           const float* lr, float* gsum, float* gout, hipStream_t s) {
-  hipLaunchKernelGGL(sgd_update_all_kernel, dim3(nblocks), dim3(256), 0, s, tab, nent, W, ws, na, lr, gsum, gout);
+                           const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s) {
+  hipLaunchKernelGGL(sgd_update_all_kernel, dim3(nblocks), dim3(256), 0, s, tab, nent, W, ws, na, lr, lr_elem, gsum,
+                     gout);
 }
 }  // namespace eosvos
 
@@ -977,9 +1041,60 @@ __global__ void dice_grad_kernel(const float* __restrict__ x, const float* __res
     dx[i] = bw * (p - tv) + (cy * tv + c1) * p * (1.f - p);
   }
 }
+// class-balanced cross entropy (loss_ce.py:15-60, batch_average = size_average = True):
+//   labels = gt >= .5;  L = (N_neg * sum_pos bce + N_pos * sum_neg bce) / N^2
+__global__ __launch_bounds__(256) void cbce_partial_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            float4* __restrict__ partial, long n) {
+  __shared__ float sh[4];
+  float a = 0.f, b = 0.f, c = 0.f;
+  GRID_STRIDE(i, n) {
+    const float xv = x[i];
+    const float l = t[i] >= 0.5f ? 1.f : 0.f;
+    const float v = fmaxf(xv, 0.f) - xv * l + log1pf(expf(-fabsf(xv)));
+    a += l; b += l * v; c += (1.f - l) * v;
+  }
+  a = block_sum_256(a, sh); b = block_sum_256(b, sh); c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = make_float4(a, b, c, 0.f);
+}
+__global__ __launch_bounds__(256) void cbce_final_kernel(const float4* __restrict__ partial, int nb, long n,
+                                                          float* __restrict__ loss, float* __restrict__ scal) {
+  __shared__ double sh[4][3];
+  double a = 0, b = 0, c = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) { const float4 v = partial[i]; a += v.x; b += v.y; c += v.z; }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = a; sh[w][1] = b; sh[w][2] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double Np = 0, Sp = 0, Sn = 0;
+    for (int k = 0; k < 4; ++k) { Np += sh[k][0]; Sp += sh[k][1]; Sn += sh[k][2]; }
+    const double N = (double)n, Nn = N - Np;
+    loss[0] = (float)((Nn * Sp + Np * Sn) / (N * N));
+    scal[0] = loss[0]; scal[1] = (float)(Nn / (N * N)); scal[2] = (float)(Np / (N * N));
+  }
+}
+__global__ void cbce_grad_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ scal,
+                                 float* __restrict__ dx, long n) {
+  const float wp = scal[1], wn = scal[2];
+  GRID_STRIDE(i, n) {
+    const float xv = x[i];
+    const bool pos = t[i] >= 0.5f;
+    const float e = expf(-fabsf(xv));
+    const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[i] = pos ? wp * (p - 1.f) : wn * p;
+  }
+}
 void launch_dice(const float* logits, const float* gt, float* dlogits, float* loss, float* partial /*>=4*1024+4*/, int64_t n,
                  int kind, hipStream_t s) {
   const int nb = grid_for(n, 256, 1024);
+  if (kind == 3) {
+    hipLaunchKernelGGL(cbce_partial_kernel, dim3(nb), dim3(256), 0, s, logits, gt, (float4*)partial, (long)n);
+    hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(256), 0, s, (const float4*)partial, nb, (long)n, loss,
+                       partial + 4 * 1024);
+    hipLaunchKernelGGL(cbce_grad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, logits, gt, partial + 4 * 1024,
+                       dlogits, (long)n);
+    return;
+  }
   hipLaunchKernelGGL(dice_partial_kernel, dim3(nb), dim3(256), 0, s, logits, gt, (float4*)partial, (long)n);
   hipLaunchKernelGGL(dice_final_kernel, dim3(1), dim3(256), 0, s, (const float4*)partial, nb, (long)n, kind, loss,
                      partial + 4 * 1024);

@@ -20,6 +20,10 @@ def _dev_f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+LR_LEVELS = {'NEURON': 0, 'TENSOR': 1, 'SINGLE': 2, 'PARAM': 3}      # include/eosvos.h EOSVOS_LR_*
+LOSS_KINDS = {'cross_entropy': 0, 'dice': 1, 'cross_entropy_and_dice': 2, 'class_balanced_cross_entropy': 3}
+
+
 class Engine:
     def __init__(self, encoder='resnet50', height=480, width=854, max_batch=3, device='cuda:0', norm='bn'):
         if not torch.cuda.is_available():
@@ -35,6 +39,8 @@ class Engine:
         self.n_param = int(self.lib.eosvos_param_count(self.arch))
         self.n_lr = int(self.lib.eosvos_lr_count(self.arch))
         self.n_norm = int(self.lib.eosvos_norm_count(self.arch))
+        self.lr_level, self.lr_log = 'NEURON', False
+        self.n_lr_store = self.n_lr
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.current_stream(self.device)
         h = ctypes.c_void_p()
@@ -65,7 +71,28 @@ class Engine:
         flat = _dev_f32(flat, self.device)
         assert flat.numel() == self.n_lr
         _ffi.check(self.lib.eosvos_set_lr(self.h, _ptr(flat)))
+        self.lr_level, self.lr_log, self.n_lr_store = 'NEURON', False, self.n_lr
         self.synchronize()
+
+    def lr_store_count(self, level):
+        return int(self.lib.eosvos_lr_store_count(self.arch, LR_LEVELS[level]))
+
+    def set_lr_state(self, level, use_log, flat):
+        """Learned lr state at `lr_hierarchy_level` (flat, reference tensor order), optionally log(lr)."""
+        if level not in LR_LEVELS:
+            raise NotImplementedError(level)            # meta_optim.py:68-69
+        flat = _dev_f32(flat, self.device)
+        n = self.lr_store_count(level)
+        assert flat.numel() == n, (flat.numel(), n)
+        _ffi.check(self.lib.eosvos_set_lr_state(self.h, LR_LEVELS[level], int(bool(use_log)), _ptr(flat)))
+        self.lr_level, self.lr_log, self.n_lr_store = level, bool(use_log), n
+        self.synchronize()
+
+    def set_loss(self, name):
+        """Loss of finetune_step / meta_grad (`loss_func`, helper_func.py:28-56)."""
+        if name not in LOSS_KINDS:
+            raise NotImplementedError(name)             # helper_func.py:55-56
+        _ffi.check(self.lib.eosvos_set_loss(self.h, LOSS_KINDS[name]))
 
     def set_norm(self, gamma, beta, mean, var, eps=1e-5):
         ts = [_dev_f32(t, self.device) for t in (gamma, beta, mean, var)]
@@ -126,8 +153,8 @@ class Engine:
         return loss
 
     def loss(self, kind, masks):
-        """kind: 'cross_entropy' | 'dice' | 'cross_entropy_and_dice' (compute_loss names); leaves dL/dlogits."""
-        k = {'cross_entropy': 0, 'dice': 1, 'cross_entropy_and_dice': 2}[kind]
+        """kind: a compute_loss name (helper_func.py:28-56, see LOSS_KINDS); leaves dL/dlogits."""
+        k = LOSS_KINDS[kind]
         assert masks.is_cuda and masks.dtype == torch.float32 and masks.is_contiguous()
         out = torch.empty(1, device=self.device)
         _ffi.check(self.lib.eosvos_loss(self.h, k, _ptr(masks), masks.shape[0], _ptr(out)))
@@ -183,7 +210,7 @@ class Engine:
 
     def meta_grad(self, images, masks, flat_meta_grad):
         b = self._check_images(images)
-        assert flat_meta_grad.numel() == self.n_lr + self.n_param and flat_meta_grad.is_cuda
+        assert flat_meta_grad.numel() == self.n_lr_store + self.n_param and flat_meta_grad.is_cuda
         l = ctypes.c_float()
         _ffi.check(self.lib.eosvos_meta_grad(self.h, _ptr(images), _ptr(masks), b, _ptr(flat_meta_grad),
                                              ctypes.byref(l)))

@@ -7,9 +7,9 @@
   early_stopping      `helper_func.py:388-397`
   EpochSampler        `helper_func.py:521-545`
   set_random_seeds    `helper_func.py:515-518`
-`dice` (`networks/loss_dice.py:4-40`) and `cross_entropy_and_dice` (`:45-54`) run as fused HIP
-kernels too; `class_balanced_cross_entropy` raises NotImplementedError -- the error type the
-reference raises for unknown names (`:55-56`).
+`dice` (`networks/loss_dice.py:4-40`), `cross_entropy_and_dice` (`:45-54`) and
+`class_balanced_cross_entropy` (`networks/loss_ce.py:15-60`) run as fused HIP kernels too; unknown
+names raise NotImplementedError as in the reference (`:55-56`).
 """
 import random
 
@@ -23,8 +23,10 @@ def compute_loss(loss_func, outputs, gts, loss_kwargs=None):
     """`compute_loss(loss_func, outputs, gts, loss_kwargs=None)`, helper_func.py:28-56.  The returned
     0-dim loss carries the engine handle so `MetaOptimizer.step(loss)` can run the backward."""
     loss_kwargs = loss_kwargs or {}
-    if loss_func not in ('cross_entropy', 'dice', 'cross_entropy_and_dice'):
+    if loss_func not in ('cross_entropy', 'dice', 'cross_entropy_and_dice', 'class_balanced_cross_entropy'):
         raise NotImplementedError(f"loss_func='{loss_func}'")
+    if loss_func == 'class_balanced_cross_entropy' and not loss_kwargs.get('size_average', True):
+        raise NotImplementedError('class_balanced_cross_entropy with size_average=False')
     eng = getattr(outputs, '_eosvos_engine', None)
     if eng is None:
         raise RuntimeError('compute_loss needs logits produced by eosvos_amd.networks.DeepLabV3Plus '

@@ -14,6 +14,10 @@ Reference semantics kept:
     closed-form meta-gradient;
   * `meta_backward(meta_loss)` stands in for `bptt_loss.backward()` (`meta_run.py:214`): fills
     `.grad` of `named_parameters()` (log_init_lr_* then model_init_*).
+  * `lr_hierarchy_level` SINGLE / TENSOR / NEURON / PARAM and `use_log_init_lr`
+    (`meta_optim.py:27-67,157-163,180-185`): the learned state keeps the reference's tensors
+    (`log_init_lr` (1,1) / (G,1), or one `log_init_lr_<name>` per tensor); the engine expands it to the
+    effective lr of the step and returns d/d(state) in the same layout (`eosvos_set_lr_state`).
 Unsupported reference options raise NotImplementedError exactly like the reference does for
 unknown hierarchy levels (`meta_optim.py:68-69`).
 """
@@ -43,15 +47,15 @@ class _MetaModelShim:
 class MetaOptimizer:
     def __init__(self, model, init_lr, learn_model_init, second_order_gradients, lr_hierarchy_level,
                  use_log_init_lr, max_lr):
-        if lr_hierarchy_level != 'NEURON':
-            raise NotImplementedError(f'lr_hierarchy_level={lr_hierarchy_level} (only NEURON, cfgs/meta.yaml:36)')
-        if use_log_init_lr:
-            raise NotImplementedError('use_log_init_lr=True')
+        if lr_hierarchy_level not in ('SINGLE', 'TENSOR', 'NEURON', 'PARAM'):
+            raise NotImplementedError                   # meta_optim.py:68-69
         if second_order_gradients:
             raise NotImplementedError('second_order_gradients=True needs double backward')
         if not learn_model_init:
             raise NotImplementedError('learn_model_init=False')
         self._max_lr = max_lr
+        self._lr_hierarchy_level = lr_hierarchy_level
+        self._use_log_init_lr = bool(use_log_init_lr)
         self.training = True
         self.only_box_head = False          # evaluate.py:270 sets it; no-op for DeepLab (meta_model.py:73-76)
         self.model = model
@@ -59,23 +63,34 @@ class MetaOptimizer:
         self.state = {'num_steps': 0}
         self._train_loss = None
         names, shapes = model._names, model._shapes
-        n_lr = sum(s[0] for s in shapes)
-        self._lr_flat = torch.zeros(n_lr)
         self._lr_views = OrderedDict()
-        off = 0
-        for n, s in zip(names, shapes):
-            ls = neuron_lr_shape(s)
-            k = s[0]
-            v = self._lr_flat[off:off + k].view(ls)
-            v.copy_(init_lr * (1.0 + (torch.rand(ls) - 0.5)))          # meta_optim.py:57-58
-            self._lr_views['log_init_lr_' + n.replace('.', '-')] = v
-            off += k
+        lvl = lr_hierarchy_level
+        if lvl == 'SINGLE':                               # meta_optim.py:27-31
+            self._lr_flat = torch.ones(1).mul(init_lr)
+            self._lr_views['log_init_lr'] = self._lr_flat.view(1, 1)
+        elif lvl == 'TENSOR':                             # meta_optim.py:33-42
+            self._lr_flat = torch.ones(len(names)).mul(init_lr)
+            self._lr_flat += torch.rand_like(self._lr_flat).sub(0.5) * init_lr
+            self._lr_views['log_init_lr'] = self._lr_flat.view(len(names), 1)
+        else:                                             # meta_optim.py:44-66
+            lshapes = [tuple(s) if lvl == 'PARAM' else neuron_lr_shape(s) for s in shapes]
+            self._lr_flat = torch.zeros(sum(math.prod(ls) for ls in lshapes))
+            off = 0
+            for n, ls in zip(names, lshapes):
+                k = math.prod(ls)
+                v = self._lr_flat[off:off + k].view(ls)
+                v.copy_(init_lr * (1.0 + (torch.rand(ls) - 0.5)))          # meta_optim.py:57-58
+                self._lr_views['log_init_lr_' + n.replace('.', '-')] = v
+                off += k
+        if self._use_log_init_lr:
+            self._lr_flat.log_()
         self._init_views = OrderedDict(('model_init_' + n.replace('.', '-'), model._views[n]) for n in names)
         self._params = OrderedDict()
         for k, v in list(self._lr_views.items()) + list(self._init_views.items()):
             self._params[k] = _Param(k, v, True)
         self._grad_flat = None
         model._lr_flat = self._lr_flat
+        model._lr_mode = (lvl, self._use_log_init_lr)
         model._dirty = True
 
     # ---- nn.Module-like surface ---------------------------------------------------------------
@@ -130,15 +145,23 @@ class MetaOptimizer:
             off += k
 
     @property
-    def init_lr(self):
-        return torch.tensor([float(v.mean()) for v in self._lr_views.values()])
+    def init_lr(self):                                    # meta_optim.py:84-96
+        f = (lambda t: t.exp()) if self._use_log_init_lr else (lambda t: t)
+        if self._lr_hierarchy_level in ('SINGLE', 'TENSOR'):
+            return f(self._lr_views['log_init_lr']).clone()
+        return torch.tensor([float(f(v).mean()) for v in self._lr_views.values()])
 
     @property
-    def state_lr(self):
+    def state_lr(self):                                   # meta_optim.py:98-110 (state = learned lr here)
+        if self._lr_hierarchy_level == 'SINGLE':
+            return self.init_lr.repeat(self.meta_model.num_param_groups, 1)     # `_init_state`, :158-160
         return self.init_lr
 
-    def clamp_init_lr(self):
-        self._lr_flat.clamp_(0, self._max_lr)           # meta_optim.py:116-133, use_log_init_lr False
+    def clamp_init_lr(self):                              # meta_optim.py:116-133
+        if self._use_log_init_lr:
+            self._lr_flat.clamp_(-33, None if self._max_lr is None else math.log(self._max_lr))
+        else:
+            self._lr_flat.clamp_(0, self._max_lr)
         self.model._lr_flat = self._lr_flat
         self.model._dirty = True
 
@@ -168,12 +191,13 @@ class MetaOptimizer:
         eng.backward_step(accumulate=self.training)
         self.state['num_steps'] += 1
 
-    def meta_backward(self, meta_inputs, meta_gts):
+    def meta_backward(self, meta_inputs, meta_gts, loss_func='cross_entropy'):
         """`bptt_loss.backward()` for one meta frame batch: returns the meta loss (float) and ADDS the
         task's meta-gradient into `.grad` of named_parameters()."""
         if self._grad_flat is None:
             self.init_zero_grad()
         eng = self.model._ensure_engine(meta_inputs.shape[2], meta_inputs.shape[3], meta_inputs.shape[0])
+        eng.set_loss(loss_func)
         task = torch.zeros_like(self._grad_flat)
         loss = eng.meta_grad(meta_inputs.contiguous(), meta_gts.contiguous(), task)
         if not math.isnan(loss):

@@ -21,13 +21,17 @@ from .topology import neuron_lr_shape, trainable
 
 class MetaTrainer:
     def __init__(self, engine, dist=None, meta_batch_size=4, model_init_lr=1e-5, log_init_lr_lr=1e-5,
-                 model_init_weight_decay=1e-3, grad_clip=None, max_lr=None):
+                 model_init_weight_decay=1e-3, grad_clip=None, max_lr=None, lr_hierarchy_level='NEURON',
+                 use_log_init_lr=False, loss_func='cross_entropy'):
         self.eng = engine
+        self.level, self.use_log = lr_hierarchy_level, bool(use_log_init_lr)
+        self.n_lr = engine.lr_store_count(lr_hierarchy_level)        # NotImplementedError for unknown levels
+        engine.set_loss(loss_func)
         self.dist = dist
         self.meta_batch_size = meta_batch_size
         self.model_init_lr, self.log_init_lr_lr = model_init_lr, log_init_lr_lr
         self.wd, self.grad_clip, self.max_lr = model_init_weight_decay, grad_clip, max_lr
-        n = engine.n_lr + engine.n_param
+        n = self.n_lr + engine.n_param
         dev = engine.device
         self.state = torch.zeros(n, device=dev)
         self.grad = torch.zeros(n, device=dev)
@@ -39,22 +43,30 @@ class MetaTrainer:
 
     # ---- state ------------------------------------------------------------------------
     def load_state(self, model_state, lrs):
-        """model_state: reference-style model state dict; lrs: list of NEURON lr tensors."""
+        """model_state: reference-style model state dict; lrs: the learned lr state in the reference's
+        layout for the hierarchy level (list of per-tensor tensors for NEURON / PARAM, one (G,1) / (1,1)
+        tensor for TENSOR / SINGLE; log values with `use_log_init_lr`)."""
         names = [n for n, _ in trainable(self.eng.encoder)]
         dev = self.eng.device
-        self.state[:self.eng.n_lr] = torch.cat([l.reshape(-1).float() for l in lrs]).to(dev)
-        self.state[self.eng.n_lr:] = torch.cat([model_state[n].reshape(-1).float() for n in names]).to(dev)
-        self.eng.load_model_state(model_state, lrs)
+        lrs = list(lrs) if isinstance(lrs, (list, tuple)) else [lrs]
+        self.state[:self.n_lr] = torch.cat([l.reshape(-1).float() for l in lrs]).to(dev)
+        self.state[self.n_lr:] = torch.cat([model_state[n].reshape(-1).float() for n in names]).to(dev)
+        self.eng.load_model_state(model_state)
+        self.eng.set_lr_state(self.level, self.use_log, self.state[:self.n_lr])
 
     def state_dict(self):
         """`meta_optim_state_dict` of the reference checkpoints (train_meta.py:277-286)."""
         out, off = {}, 0
         tr = trainable(self.eng.encoder)
-        for n, shape in tr:
-            s = neuron_lr_shape(shape)
-            k = math.prod(s)
-            out['log_init_lr_' + n.replace('.', '-')] = self.state[off:off + k].view(s)
-            off += k
+        if self.level in ('SINGLE', 'TENSOR'):              # one `log_init_lr` Parameter, meta_optim.py:27-42
+            out['log_init_lr'] = self.state[:self.n_lr].view(self.n_lr, 1)
+            off = self.n_lr
+        else:
+            for n, shape in tr:
+                s = tuple(shape) if self.level == 'PARAM' else neuron_lr_shape(shape)
+                k = math.prod(s)
+                out['log_init_lr_' + n.replace('.', '-')] = self.state[off:off + k].view(s)
+                off += k
         for n, shape in tr:
             k = math.prod(shape)
             out['model_init_' + n.replace('.', '-')] = self.state[off:off + k].view(shape)
@@ -62,8 +74,8 @@ class MetaTrainer:
         return out
 
     def _push_state(self):
-        self.eng.set_lr(self.state[:self.eng.n_lr])
-        self.eng.set_init(self.state[self.eng.n_lr:])
+        self.eng.set_lr_state(self.level, self.use_log, self.state[:self.n_lr])
+        self.eng.set_init(self.state[self.n_lr:])
 
     # ---- one task ---------------------------------------------------------------------
     def run_task(self, x_train, y_train, x_meta, y_meta, inner_steps=5):
@@ -94,13 +106,16 @@ class MetaTrainer:
     def outer_step(self):
         eng = self.eng
         self.step += 1
-        nl = eng.n_lr
+        nl = self.n_lr
         scale = 1.0 / self.meta_batch_size
         clip = float(self.grad_clip) if self.grad_clip is not None else 0.0
         for lo, hi, lr, wd in ((0, nl, self.log_init_lr_lr, 0.0), (nl, self.state.numel(), self.model_init_lr, self.wd)):
             eng.radam_step(self.state[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                            lr, wd, self.step, grad_scale=scale, grad_clip=clip)
-        eng.clamp(self.state[:nl], 0.0, float('inf') if self.max_lr is None else float(self.max_lr))
+        if self.use_log:                                    # clamp_init_lr, meta_optim.py:116-133
+            eng.clamp(self.state[:nl], -33.0, float('inf') if self.max_lr is None else math.log(self.max_lr))
+        else:
+            eng.clamp(self.state[:nl], 0.0, float('inf') if self.max_lr is None else float(self.max_lr))
         self.grad.zero_()
         self._push_state()
 

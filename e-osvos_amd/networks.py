@@ -170,7 +170,8 @@ class DeepLabV3Plus:
         else:
             e.set_norm(cat('.weight'), cat('.bias'), cat('.running_mean'), cat('.running_var'))
         if self._lr_flat is not None:
-            e.set_lr(self._lr_flat)
+            level, use_log = getattr(self, '_lr_mode', ('NEURON', False))
+            e.set_lr_state(level, use_log, self._lr_flat)
         self._dirty = False
 
     def __call__(self, inputs):

@@ -47,6 +47,27 @@ def synthetic_lrs(encoder='resnet50', init_lr=1e-3, seed=1):
     return out
 
 
+def synthetic_lr_state(encoder='resnet50', level='NEURON', use_log=False, init_lr=1e-3, seed=1):
+    """Learned lr state in the reference's layout for `lr_hierarchy_level` (meta_optim.py:27-67):
+    SINGLE -> tensor (1,1); TENSOR -> tensor (G,1); NEURON / PARAM -> list of per-tensor tensors.
+    Values init_lr*(1+U(-.5,.5)) (SINGLE: 1.2*init_lr), log() applied for `use_log_init_lr`."""
+    g = torch.Generator().manual_seed(seed)
+    tr = trainable(encoder)
+    if level == 'SINGLE':
+        out = torch.full((1, 1), 1.2 * init_lr)
+    elif level == 'TENSOR':
+        out = init_lr * (1.0 + (torch.rand(len(tr), 1, generator=g) - 0.5))
+    elif level == 'NEURON':
+        out = [init_lr * (1.0 + (torch.rand(neuron_lr_shape(s), generator=g) - 0.5)) for _, s in tr]
+    elif level == 'PARAM':
+        out = [init_lr * (1.0 + (torch.rand(tuple(s), generator=g) - 0.5)) for _, s in tr]
+    else:
+        raise NotImplementedError(level)
+    if use_log:
+        out = [o.log() for o in out] if isinstance(out, list) else out.log()
+    return out
+
+
 def synthetic_frames(batch, height, width, seed=7, second_object=False):
     """image (B,3,H,W) in [0,1), mask (B,1,H,W) in {0,1}: one rectangle per frame
     (shifted per batch element so the frames differ)."""

@@ -85,8 +85,10 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2):
     eng = model._ensure_engine(height, width, cfg['data_cfg']['batch_sizes']['train'])
     mt = MetaTrainer(eng, dist=dist, meta_batch_size=cfg['meta_batch_size'], model_init_lr=oc['model_init_lr'],
                      log_init_lr_lr=oc['log_init_lr_lr'], model_init_weight_decay=oc['model_init_weight_decay'],
-                     grad_clip=oc['grad_clip'], max_lr=cfg['meta_optim_cfg']['max_lr'])
-    mt.load_state(model.state_dict(), [p.data for n, p in meta_optim.named_parameters() if n.startswith('log_init_lr_')])
+                     grad_clip=oc['grad_clip'], max_lr=cfg['meta_optim_cfg']['max_lr'],
+                     lr_hierarchy_level=cfg['meta_optim_cfg']['lr_hierarchy_level'],
+                     use_log_init_lr=cfg['meta_optim_cfg']['use_log_init_lr'], loss_func=cfg['loss_func'])
+    mt.load_state(model.state_dict(), [p.data for n, p in meta_optim.named_parameters() if n.startswith('log_init_lr')])
     for it in range(num_meta_iters):
         tasks = []
         for t in shard_tasks(cfg['meta_batch_size'], rank, world):

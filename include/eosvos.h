@@ -97,7 +97,11 @@ int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss
 #define EOSVOS_LOSS_BCE 0
 #define EOSVOS_LOSS_DICE 1
 #define EOSVOS_LOSS_BCE_DICE 2
+#define EOSVOS_LOSS_CLASS_BALANCED_BCE 3 /* `class_balanced_cross_entropy`, networks/loss_ce.py:15-60 */
 int eosvos_loss(eosvos_engine* e, int kind, const float* masks, int batch, float* loss_out);
+/* Loss used by the fused entry points eosvos_finetune_step / eosvos_meta_grad (`loss_func` of
+ * the run config, cfgs/meta.yaml:68; default EOSVOS_LOSS_BCE = the north-star path). */
+int eosvos_set_loss(eosvos_engine* e, int kind);
 /* Stand-alone BCE-with-logits mean over n elements of caller tensors (compute_loss with
  * `batch_average: False` per sample, helper_func.py:36-39; run_loader metrics :131-134).
  * dlogits_out may be NULL (engine scratch is used; a pending eosvos_loss_bce gradient is
@@ -123,6 +127,23 @@ int eosvos_infer(eosvos_engine* e, const float* images, int batch, float* probs_
 /* labels[p] = 0 if max_o probs[o][p] < 0.5 else argmax_o + 1.  probs: n_obj x H*W. */
 int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t n_pix,
                         uint8_t* labels_out);
+
+/* ---- learning-rate hierarchy (meta_optim.py:27-67) ------------------------------------ */
+/* `lr_hierarchy_level`: how the learned lr state is stored.  NEURON (cfgs/meta.yaml:36) one
+ * value per output channel; TENSOR one per trainable tensor (`log_init_lr` of shape
+ * (num_param_groups,1), meta_optim.py:33-42); SINGLE one value repeated over all tensors
+ * (`:27-31,157-160`); PARAM one per weight, in the parameter's OIHW layout (`:50-51`). */
+#define EOSVOS_LR_NEURON 0
+#define EOSVOS_LR_TENSOR 1
+#define EOSVOS_LR_SINGLE 2
+#define EOSVOS_LR_PARAM 3
+/* number of stored lr values at a level: lr_count / #trainable tensors / 1 / param_count */
+int64_t eosvos_lr_store_count(int arch, int level);
+/* Load the learned lr state at `level`; use_log != 0: the state holds log(lr) and exp() is
+ * applied before the step (`use_log_init_lr`, meta_optim.py:180-185).  Supersedes eosvos_set_lr
+ * (which is level NEURON, use_log 0).  eosvos_meta_grad then writes d/d(state) in the same
+ * layout: [0, lr_store_count) followed by param_count init gradients. */
+int eosvos_set_lr_state(eosvos_engine* e, int level, int use_log, const float* store);
 
 /* ---- meta-training task (meta_run.py:109-238) --------------------------------------- */
 /* theta <- init and sum_k g_k <- 0 (meta_optim.reset(); zero_grad(), meta_run.py:121-122). */

@@ -116,4 +116,16 @@ def loss_fn(name, logits, gt):
         return dice_loss(logits, gt)
     if name == 'cross_entropy_and_dice':
         return bce_loss(logits, gt) - (1 - dice_loss(logits, gt)).log()
+    if name == 'class_balanced_cross_entropy':
+        return class_balanced_bce_loss(logits, gt)
     raise NotImplementedError(name)
+
+
+def class_balanced_bce_loss(logits, gt):
+    """`class_balanced_cross_entropy_loss(output, label, size_average=True, batch_average=True)`,
+    `src/networks/loss_ce.py:15-60`: positives weighted by the negative fraction and vice versa."""
+    lab = (gt >= 0.5).float()
+    n_pos, n_neg = lab.sum(), (1.0 - lab).sum()
+    elem = F.binary_cross_entropy_with_logits(logits, lab, reduction='none')
+    loss = (n_neg * (lab * elem).sum() + n_pos * ((1.0 - lab) * elem).sum()) / (n_pos + n_neg)
+    return loss / gt.numel()

@@ -11,6 +11,8 @@
                        and `bptt_epochs == num_epochs.train`; uses the closed form of
                        SURVEY.md section 3.3 (theta_K = theta_0 - lr * sum_k g_k):
                          d/d init = G,  d/d lr[c] = -sum_{cin,kh,kw}(sum_k g_k * G).
+  * `meta_task_hier` : the same for `lr_hierarchy_level` SINGLE / TENSOR / NEURON / PARAM and
+                       `use_log_init_lr` (`meta_optim.py:27-67,157-163,180-185`).
   * `radam_step`     : `RAdam.step`, `src/util/radam.py:28-94`, per-tensor groups as
                        built at `src/train_meta.py:110-127`.
   * `outer_step`     : average / clip / RAdam / clamp, `src/train_meta.py:361-373` and
@@ -29,7 +31,7 @@ from . import deeplab
 from .topology import trainable_names
 
 
-def loss_and_grads(P, x, y, encoder='resnet50', norm='bn'):
+def loss_and_grads(P, x, y, encoder='resnet50', norm='bn', loss_name='cross_entropy'):
     names = trainable_names(encoder)
     Q = dict(P)
     leaves = []
@@ -38,16 +40,16 @@ def loss_and_grads(P, x, y, encoder='resnet50', norm='bn'):
         Q[n] = t
         leaves.append(t)
     logits = deeplab.forward(Q, x, encoder, norm)
-    loss = deeplab.bce_loss(logits, y)
+    loss = deeplab.loss_fn(loss_name, logits, y)
     grads = torch.autograd.grad(loss, leaves)
     return loss.detach(), list(grads), logits.detach()
 
 
-def finetune_step(P, lrs, x, y, encoder='resnet50', norm='bn'):
+def finetune_step(P, lrs, x, y, encoder='resnet50', norm='bn', loss_name='cross_entropy'):
     """One inner step.  Returns (loss, grads, new P).  `lrs`: list aligned with
     trainable_names(), each broadcastable against its tensor ((Cout,1,1,1) or (1,))."""
     names = trainable_names(encoder)
-    loss, grads, _ = loss_and_grads(P, x, y, encoder, norm)
+    loss, grads, _ = loss_and_grads(P, x, y, encoder, norm, loss_name)
     Pn = dict(P)
     for n, lr, g in zip(names, lrs, grads):
         Pn[n] = P[n] - g * lr
@@ -63,7 +65,52 @@ def finetune(P, lrs, batches, encoder='resnet50', norm='bn'):
     return losses, P
 
 
-def meta_task(P0, lrs, train_batches, meta_batch, encoder='resnet50', norm='bn'):
+def effective_lrs(store, level, use_log, n_tensors):
+    """The lr each tensor's step multiplies with: `state['log_lr']` of `_init_state`
+    (`meta_optim.py:157-163`: SINGLE repeats the one value per param group) after the
+    optional exp() of `step` (`:180-185`).  Iterating a (G,1) tensor yields (1,) rows."""
+    if level == 'SINGLE':
+        rows = list(store.repeat(n_tensors, 1))
+    elif level == 'TENSOR':
+        rows = list(store)
+    elif level in ('NEURON', 'PARAM'):
+        rows = list(store)
+    else:
+        raise NotImplementedError(level)
+    return [r.exp() if use_log else r for r in rows]
+
+
+def meta_task_hier(P0, store, level, use_log, train_batches, meta_batch, encoder='resnet50', norm='bn',
+                   loss_name='cross_entropy'):
+    """`meta_task` for any `lr_hierarchy_level` / `use_log_init_lr`: returns g_lr in the
+    layout of the stored state.  First-order closed form: with lr_eff = f(store),
+    d/d lr_eff = -(sum_k g_k) * G elementwise, summed over the elements that share one
+    stored value (autograd of broadcasting / `repeat`), times lr_eff for log storage."""
+    names = trainable_names(encoder)
+    lrs = effective_lrs(store, level, use_log, len(names))
+    res = meta_task(P0, lrs, train_batches, meta_batch, encoder, norm, _keep_elem=True, loss_name=loss_name)
+    elem = res.pop('g_lr_elem')
+    per_tensor = []
+    for e, lr in zip(elem, lrs):
+        if use_log:
+            e = e * lr
+        if level == 'PARAM':
+            per_tensor.append(e)
+        elif level == 'NEURON':
+            per_tensor.append(e.sum(dim=tuple(range(1, e.dim())), keepdim=True) if e.dim() > 1 else e)
+        else:
+            per_tensor.append(e.sum().reshape(1))
+    if level == 'TENSOR':
+        res['g_lr'] = torch.stack(per_tensor)                   # (G,1)
+    elif level == 'SINGLE':
+        res['g_lr'] = torch.stack(per_tensor).sum().reshape(1, 1)
+    else:
+        res['g_lr'] = per_tensor
+    return res
+
+
+def meta_task(P0, lrs, train_batches, meta_batch, encoder='resnet50', norm='bn', _keep_elem=False,
+              loss_name='cross_entropy'):
     """K inner steps + one meta frame.  Returns dict(meta_loss, train_losses,
     g_init (list), g_lr (list shaped like lrs))."""
     names = trainable_names(encoder)
@@ -71,11 +118,14 @@ def meta_task(P0, lrs, train_batches, meta_batch, encoder='resnet50', norm='bn')
     gsum = None
     train_losses = []
     for x, y in train_batches:
-        loss, grads, P = finetune_step(P, lrs, x, y, encoder, norm)
+        loss, grads, P = finetune_step(P, lrs, x, y, encoder, norm, loss_name)
         train_losses.append(float(loss))
         gsum = [g.clone() for g in grads] if gsum is None else [a + g for a, g in zip(gsum, grads)]
     xm, ym = meta_batch
-    meta_loss, G, _ = loss_and_grads(P, xm, ym, encoder, norm)
+    meta_loss, G, _ = loss_and_grads(P, xm, ym, encoder, norm, loss_name)
+    if _keep_elem:
+        return dict(meta_loss=float(meta_loss), train_losses=train_losses, g_init=G,
+                    g_lr_elem=[-(s * g) for s, g in zip(gsum, G)])
     g_lr = []
     for n, s, g, lr in zip(names, gsum, G, lrs):
         prod = -(s * g)

@@ -79,6 +79,47 @@ def test_engine_fails_loudly_without_gpu():
         Engine('resnet50', 96, 160, 1)
 
 
+HIER_CASES = [('SINGLE', False), ('TENSOR', False), ('TENSOR', True), ('NEURON', True), ('PARAM', False),
+              ('PARAM', True), ('SINGLE', True)]
+
+
+@pytest.mark.parametrize('level,use_log', HIER_CASES)
+def test_meta_optimizer_hierarchy_layout(golden_dir, level, use_log):
+    """State-dict keys/shapes, init_lr, state_lr and clamp_init_lr of every lr_hierarchy_level /
+    use_log_init_lr combination equal the reference MetaOptimizer's (fixture G13); host logic only."""
+    from eosvos_amd import synthetic, topology
+    from eosvos_amd.meta_optim import MetaOptimizer
+    from eosvos_amd.networks import DeepLabV3Plus
+    g = np.load(os.path.join(golden_dir, 'g13_lr_hierarchy.npz'))
+    tag = f'{level}_{int(use_log)}'
+    model = DeepLabV3Plus('resnet50', num_classes=1,
+                          batch_norm={'accum_stats': False, 'learn_weight': False, 'learn_bias': False})
+    mo = MetaOptimizer(model, init_lr=1e-3, learn_model_init=True, second_order_gradients=False,
+                       lr_hierarchy_level=level, use_log_init_lr=use_log, max_lr=1.3e-3)
+    assert [f'{k}:{tuple(v.shape)}' for k, v in mo.state_dict().items()] == list(g[tag + '_keys'])
+    store = synthetic.synthetic_lr_state('resnet50', level, use_log)
+    sd = synthetic.synthetic_state('resnet50')
+    msd = {}
+    if isinstance(store, list):
+        for (n, _), lr in zip(topology.trainable('resnet50'), store):
+            msd['log_init_lr_' + n.replace('.', '-')] = lr
+    else:
+        msd['log_init_lr'] = store
+    for n, _ in topology.trainable('resnet50'):
+        msd['model_init_' + n.replace('.', '-')] = sd[n]
+    mo.load_state_dict(msd)
+    np.testing.assert_allclose(mo.init_lr.numpy(), g[tag + '_init_lr'], rtol=1e-6)
+    np.testing.assert_allclose(mo.state_lr.numpy(), g[tag + '_state_lr'], rtol=1e-6)
+    mo.clamp_init_lr()
+    t = mo._lr_flat.double()
+    idx = torch.linspace(0, t.numel() - 1, 16).long()
+    fp = np.concatenate([[t.sum().item(), t.norm().item()], t[idx].numpy()])
+    np.testing.assert_allclose(fp, g[tag + '_clamped_fp'], rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        MetaOptimizer(model, init_lr=1e-3, learn_model_init=True, second_order_gradients=False,
+                      lr_hierarchy_level='LAYER', use_log_init_lr=False, max_lr=None)
+
+
 def test_checkpoint_layout_compatible(golden_dir):
     """A `.model` file written by the reference's MetaOptimizer.state_dict() layout loads, and
     our state dict has the same key structure (train_meta.py:277-286)."""
@@ -113,7 +154,9 @@ class FakeEngine:
         self.n_lr, self.n_param, self.device = 8, 40, torch.device('cpu')
         self.states = {{}}
     def load_model_state(self, *a): pass
-    def set_lr(self, t): self.lr = t.clone()
+    def lr_store_count(self, level): return self.n_lr
+    def set_loss(self, name): pass
+    def set_lr_state(self, level, use_log, t): self.lr = t.clone()
     def set_init(self, t): self.init = t.clone()
     def meta_task_begin(self): pass
     def finetune_step(self, *a, **k): pass

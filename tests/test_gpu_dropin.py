@@ -78,7 +78,7 @@ def test_reference_style_finetune_loop(model_and_optim, golden_dir):
                        {'batch_average': False})
     assert per.shape == (3,)
     with pytest.raises(NotImplementedError):
-        compute_loss('class_balanced_cross_entropy', out, out)
+        compute_loss('lovasz', out, out)            # unknown name, helper_func.py:55-56
 
 
 def test_reference_style_meta_task(model_and_optim, golden_dir):
@@ -176,3 +176,46 @@ def test_train_meta_entry_points(tmp_path):
     assert info['meta_iter'] == 1 and len(sd) == 128
     assert list(sd)[0] == 'log_init_lr_backbone-conv1-weight' and list(sd)[64] == 'model_init_backbone-conv1-weight'
     assert mt.step == 1
+
+
+@pytest.mark.parametrize('level,use_log', [('TENSOR', True), ('SINGLE', False)])
+def test_reference_style_meta_task_other_levels(golden_dir, level, use_log):
+    """The meta_run.py:121-214 call sequence with `lr_hierarchy_level` TENSOR / SINGLE and
+    `use_log_init_lr` (meta_optim.py:27-42,157-163,180-185): `.grad` of `log_init_lr` vs fixture G13."""
+    from eosvos_amd.helper_func import compute_loss, init_parent_model
+    from eosvos_amd.meta_optim import MetaOptimizer
+    g = np.load(os.path.join(golden_dir, 'g13_lr_hierarchy.npz'))
+    tag = f'{level}_{int(use_log)}'
+    model, _ = init_parent_model(architecture='DeepLabV3Plus', encoder='resnet50', train_encoder=True,
+                                 decoder_norm_layer='BatchNorm2d', replace_batch_with_group_norms=False,
+                                 batch_norm=BN_CFG, roi_pool_output_sizes=None, eval_augment_rpn_proposals_mode=None,
+                                 box_nms_thresh=None, maskrcnn_loss=None)
+    model.to(DEV)
+    sd = synthetic.synthetic_state('resnet50')
+    model.load_state_dict(sd)
+    mo = MetaOptimizer(model, **dict(MO_CFG, lr_hierarchy_level=level, use_log_init_lr=use_log, max_lr=1.3e-3))
+    msd = {'log_init_lr': synthetic.synthetic_lr_state('resnet50', level, use_log)}
+    for n, _ in topology.trainable('resnet50'):
+        msd['model_init_' + n.replace('.', '-')] = sd[n].clone()
+    mo.load_state_dict(msd)
+    mo.init_zero_grad()
+    mo.zero_grad()
+    mo.train()
+    mo.reset()
+    model.train_without_dropout()
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1302)
+    xg, yg = x.to(DEV), y.to(DEV)
+    losses = []
+    for _ in range(2):
+        loss = compute_loss('cross_entropy', model(xg)[-1], yg)
+        losses.append(float(loss))
+        mo.set_train_loss(loss)
+        mo.step(loss)
+    np.testing.assert_allclose(losses, g[tag + '_train_losses'], rtol=5e-4)
+    meta_loss = mo.meta_backward(torch.flip(xg, dims=[3]), torch.flip(yg, dims=[3]))
+    assert abs(meta_loss - g[tag + '_meta_loss'][0]) <= 5e-4 * abs(g[tag + '_meta_loss'][0])
+    grad = dict(mo.named_parameters())['log_init_lr'].grad.flatten().cpu().numpy()
+    ref = g[tag + '_lr_grad']
+    assert grad.shape == ref.shape
+    assert np.abs(grad - ref).max() <= 5e-3 * np.abs(ref).max()
+    model.engine.close()

@@ -252,6 +252,60 @@ def test_meta_task_vs_golden(small_engine, weights, golden_dir, K):
     eng.load_model_state(*weights)
 
 
+HIER_CASES = [('SINGLE', False), ('TENSOR', False), ('TENSOR', True), ('NEURON', True), ('PARAM', False),
+              ('PARAM', True), ('SINGLE', True)]
+
+
+@pytest.mark.parametrize('level,use_log', HIER_CASES)
+def test_lr_hierarchy_vs_golden(small_engine, weights, golden_dir, level, use_log):
+    """eosvos_set_lr_state + eosvos_meta_grad at every lr_hierarchy_level / use_log_init_lr vs the
+    reference MetaOptimizer's autograd (fixture G13, meta_optim.py:27-67,157-163,180-185)."""
+    g = np.load(os.path.join(golden_dir, 'g13_lr_hierarchy.npz'))
+    tag = f'{level}_{int(use_log)}'
+    eng = small_engine
+    eng.load_model_state(weights[0])
+    store = synthetic.synthetic_lr_state('resnet50', level, use_log)
+    flat_store = torch.cat([t.flatten() for t in store]) if isinstance(store, list) else store.flatten()
+    eng.set_lr_state(level, use_log, flat_store)
+    try:
+        x, y = synthetic.synthetic_frames(1, *SMALL, seed=1302)
+        xm, ym = torch.flip(x, dims=[3]).contiguous(), torch.flip(y, dims=[3]).contiguous()
+        xg, yg = x.to(DEV), y.to(DEV)
+        eng.meta_task_begin()
+        tl = [eng.finetune_step(xg, yg, accumulate=True) for _ in range(2)]
+        ns = eng.n_lr_store
+        assert ns == flat_store.numel()
+        flat = torch.zeros(ns + eng.n_param, device=DEV)
+        ml = eng.meta_grad(xm.to(DEV), ym.to(DEV), flat)
+        np.testing.assert_allclose(tl, g[tag + '_train_losses'], rtol=5e-4)
+        assert abs(ml - g[tag + '_meta_loss'][0]) <= 5e-4 * abs(g[tag + '_meta_loss'][0])
+        flat = flat.cpu()
+        tr = topology.trainable('resnet50')
+        sizes = [int(np.prod(s)) for _, s in tr]
+        if level == 'PARAM':
+            offs = np.cumsum([0] + sizes)
+            for i, (n, s) in enumerate(tr):
+                l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
+                r = g[tag + '_lr_grad_fp'][i][1]
+                assert abs(l2 - r) <= 1e-2 * r + 1e-12, (n, l2, r)
+            for idx, key in ((-5, '_lr_grad_dec1'), (-2, '_lr_grad_last')):
+                ref = g[tag + key]
+                i = len(tr) + idx
+                got = flat[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
+                assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max()
+        else:
+            ref = g[tag + '_lr_grad']
+            got = flat[:ns].numpy()
+            assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+        offs = np.cumsum([0] + sizes) + ns
+        for i, (n, s) in enumerate(tr):
+            l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
+            r = g[tag + '_init_grad_fp'][i][1]
+            assert abs(l2 - r) <= 1e-2 * r + 1e-9, (n, l2, r)
+    finally:
+        eng.load_model_state(*weights)          # back to the NEURON lrs the other tests expect
+
+
 def test_radam_vs_golden(small_engine, golden_dir):
     g = np.load(os.path.join(golden_dir, 'g8_radam.npz'))
     eng = small_engine
@@ -372,7 +426,7 @@ def test_groupnorm_mode_vs_golden_and_oracle(weights, golden_dir):
     eng.close()
 
 
-@pytest.mark.parametrize('name', ['dice', 'cross_entropy_and_dice'])
+@pytest.mark.parametrize('name', ['dice', 'cross_entropy_and_dice', 'class_balanced_cross_entropy'])
 def test_dice_losses_vs_oracle(small_engine, weights, name):
     """The other `compute_loss` losses (dice is the reference's config default): value, dL/dlogits and one
     fine-tune step against the CPU oracle (which test_oracle_golden pins to the reference's functions)."""
@@ -392,3 +446,28 @@ def test_dice_losses_vs_oracle(small_engine, weights, name):
     out2 = eng.forward(x.to(DEV))
     assert bool(torch.isfinite(out2).all()) and float((out2 - logits).abs().max()) > 0
     eng.load_model_state(*weights)
+
+
+def test_meta_task_with_dice_loss_vs_oracle(small_engine, weights):
+    """`loss_func: dice` (the shipped config default, cfgs/meta.yaml:68) through the fused task entry points:
+    eosvos_set_loss + finetune_step + meta_grad vs the oracle's closed-form meta task on the same loss."""
+    from oracle import meta
+    eng = small_engine
+    eng.load_model_state(*weights)
+    eng.set_loss('dice')
+    try:
+        x, y = synthetic.synthetic_frames(1, *SMALL, seed=77)
+        xm, ym = torch.flip(x, dims=[3]).contiguous(), torch.flip(y, dims=[3]).contiguous()
+        ref = meta.meta_task(weights[0], weights[1], [(x, y)] * 2, (xm, ym), loss_name='dice')
+        eng.meta_task_begin()
+        tl = [eng.finetune_step(x.to(DEV), y.to(DEV), accumulate=True) for _ in range(2)]
+        flat = torch.zeros(eng.n_lr + eng.n_param, device=DEV)
+        ml = eng.meta_grad(xm.to(DEV), ym.to(DEV), flat)
+        np.testing.assert_allclose(tl, ref['train_losses'], rtol=5e-4)
+        assert abs(ml - ref['meta_loss']) <= 5e-4 * abs(ref['meta_loss'])
+        r = torch.cat([t.flatten() for t in ref['g_lr']]).numpy()
+        got = flat[:eng.n_lr].cpu().numpy()
+        assert np.abs(got - r).max() <= 5e-3 * np.abs(r).max()
+    finally:
+        eng.set_loss('cross_entropy')
+        eng.load_model_state(*weights)

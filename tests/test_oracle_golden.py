@@ -97,7 +97,7 @@ def test_g3_loss(golden_dir):
     lg, gt = torch.from_numpy(g['logits']), torch.from_numpy(g['gt'])
     assert abs(float(deeplab.bce_loss(lg, gt)) - g['mean'][0]) < 1e-6
     np.testing.assert_allclose(deeplab.bce_loss(lg, gt, False).numpy(), g['per_sample'], rtol=1e-6)
-    for name, key in (('dice', 'dice'), ('cross_entropy_and_dice', 'ce_dice')):
+    for name, key in (('dice', 'dice'), ('cross_entropy_and_dice', 'ce_dice'), ('class_balanced_cross_entropy', 'cbce')):
         x = lg.clone().requires_grad_(True)
         l = deeplab.loss_fn(name, x, gt)
         assert abs(float(l) - g[key][0]) < 2e-6 * max(1.0, abs(g[key][0]))
@@ -201,3 +201,35 @@ def test_g12_online_adapt_schedule():
     assert r[1]['propagate_frames'] == [3, 2] and r[2]['propagate_frames'] == [8, 7]
     r = meta.online_adapt_schedule(num_frames=12, train_frame_id=0, step=0, train_batch_size=3)
     assert [(d['eval_min'], d['eval_max']) for d in r] == [(1, 12)]
+
+
+HIER_CASES = [('SINGLE', False), ('TENSOR', False), ('TENSOR', True), ('NEURON', True), ('PARAM', False),
+              ('PARAM', True), ('SINGLE', True)]
+
+
+@pytest.mark.parametrize('level,use_log', HIER_CASES)
+def test_g13_lr_hierarchy(golden_dir, level, use_log):
+    """lr_hierarchy_level / use_log_init_lr (meta_optim.py:27-67,157-163,180-185) vs the reference's autograd."""
+    g = np.load(os.path.join(golden_dir, 'g13_lr_hierarchy.npz'))
+    tag = f'{level}_{int(use_log)}'
+    sd = synthetic.synthetic_state('resnet50')
+    store = synthetic.synthetic_lr_state('resnet50', level, use_log)
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1302)
+    xm, ym = torch.flip(x, dims=[3]), torch.flip(y, dims=[3])
+    out = meta.meta_task_hier(sd, store, level, use_log, [(x, y)] * 2, (xm, ym))
+    np.testing.assert_allclose(out['train_losses'], g[tag + '_train_losses'], rtol=2e-4)
+    assert abs(out['meta_loss'] - g[tag + '_meta_loss'][0]) < 2e-4 * abs(g[tag + '_meta_loss'][0])
+    if level == 'PARAM':
+        for a, b in zip(np.stack([fp(t) for t in out['g_lr']]), g[tag + '_lr_grad_fp']):
+            fp_close(a, b, rtol=2e-3, atol=1e-4 * abs(b[1]) + 1e-12)
+        for idx, key in ((-5, '_lr_grad_dec1'), (-2, '_lr_grad_last')):
+            ref = g[tag + key]
+            assert np.abs(out['g_lr'][idx].numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    else:
+        got = out['g_lr']
+        got = torch.cat([t.flatten() for t in got]).numpy() if isinstance(got, list) else got.flatten().numpy()
+        ref = g[tag + '_lr_grad']
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    for a, b in zip(np.stack([fp(t) for t in out['g_init']]), g[tag + '_init_grad_fp']):
+        fp_close(a, b, rtol=2e-3)
