@@ -26,6 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef EOSVOS_BK
 #define EOSVOS_BK 32
 #endif
+#ifndef EOSVOS_EB
+#define EOSVOS_EB 4   // epilogue rows whose global operands are requested together
+#endif
 #ifndef EOSVOS_OCC
 #define EOSVOS_OCC 2
 #endif
@@ -326,13 +329,50 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
     if (full) {
       const int n = n0 + c_c4 * 4;
       if (n < p.N) {
-#pragma unroll 4
-        for (int row = c_r; row < BM; row += CROWS) {
-          const int m = m0 + row;
-          if (m >= p.M) break;
-          const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c_c4 * 4);
-          const size_t md = dst_pixel(p, m);
-          *reinterpret_cast<float4*>(p.y + md * p.ldy + n) = conv_epilogue4(p, v, md, n);
+        // All global operands of a batch of rows are requested before any is consumed: the epilogue of
+        // the short-K layers is latency bound, and one dependent load per row left the HBM pipe empty.
+        constexpr int NIT = BM / CROWS, EB = EOSVOS_EB;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc = ldg4(p.scale + n);
+        if (p.bias) bi = ldg4(p.bias + n);
+        const bool use_mask = p.mask && n >= p.mask_c0;
+#pragma unroll
+        for (int it0 = 0; it0 < NIT; it0 += EB) {
+          size_t md[EB];
+          bool ok[EB];
+          float4 rs[EB], ac[EB], mk[EB];
+#pragma unroll
+          for (int j = 0; j < EB; ++j) {
+            const int m = m0 + c_r + (it0 + j) * CROWS;
+            ok[j] = m < p.M;
+            md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
+          }
+          if (p.res) {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
+          }
+          if (p.accum) {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
+          }
+          if (use_mask) {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
+          }
+#pragma unroll
+          for (int j = 0; j < EB; ++j) {
+            float4 v = *reinterpret_cast<const float4*>(Cs + (c_r + (it0 + j) * CROWS) * LDC + c_c4 * 4);
+            if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            if (p.bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+            if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
+            if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (use_mask) {
+              v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
+              v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
+            }
+            if (ok[j]) *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+          }
         }
       }
     } else {

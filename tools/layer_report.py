@@ -33,15 +33,21 @@ def main(trace_csv, log, steps=3):
             a[0] += d; a[1] += fl; a[2] += 1; a[3] = (M, N, K, sp, int(mf[i]['Grid_Size_X']) // 256)
     tot_t = tot_f = 0
     by_kind = defaultdict(lambda: [0.0, 0.0])
-    print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6}')
+    print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6} {"excess_us@120":>13}')
+    excess = []
     for (pos, k, ci), (t, f, n, info) in sorted(agg.items()):
         us = t / n / 1e3
-        print(f'{pos:3d} {k:6} {ci:4d} {info[0]:7d} {info[1]:6d} {info[2]:6d} {info[3]:3d} {info[4]:5d} {us:8.1f} {f / t / 1e3:6.1f}')
+        ex = us - f / n / 120e6        # time above what the layer would take at 120 TFLOP/s
+        excess.append((ex, pos, k, ci))
+        print(f'{pos:3d} {k:6} {ci:4d} {info[0]:7d} {info[1]:6d} {info[2]:6d} {info[3]:3d} {info[4]:5d} {us:8.1f} {f / t / 1e3:6.1f} {ex:13.1f}')
         tot_t += t / n; tot_f += f / n
         by_kind[k][0] += t / n; by_kind[k][1] += f / n
     print(f'MFMA kernels per step: {tot_t / 1e6:.2f} ms, {tot_f / 1e9:.1f} GFLOP, {tot_f / tot_t / 1e3:.1f} TF/s')
     for k, (t, f) in by_kind.items():
         print(f'  {k:6s} {t / 1e6:7.2f} ms {f / t / 1e3:6.1f} TF/s')
+    excess.sort(reverse=True)
+    print('largest excess over a 120 TFLOP/s pace: ' + ', '.join(f'{k}{ci}:{ex:.0f}us' for ex, pos, k, ci in excess[:24]))
+    print('total excess: %.2f ms' % (sum(e[0] for e in excess if e[0] > 0) / 1e3))
     all_step = [r for r in rows]
     print('all kernels in trace: %.2f ms' % (sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in all_step) / 1e6))
 
