@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
   constexpr int B_EL = KMAJOR ? BK * LDB : BN * LDB;
   constexpr int STAGE = A_EL + B_EL;
   constexpr int LDC = BN + 4;
-  static_assert(BM * LDC <= 2 * STAGE, "epilogue staging must fit the operand buffers");
+  constexpr int EPASS = (BM * LDC <= 2 * STAGE) ? 1 : 2;      // C-tile staging passes
+  constexpr int EROWS = BM / EPASS;
+  static_assert(EROWS * LDC <= 2 * STAGE, "epilogue staging must fit the operand buffers");
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -314,72 +316,86 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
     }
 
     // ---- epilogue: accumulators -> LDS tile -> full-row float4 stores ------------------------
+    // With a short BK the operand buffers are smaller than the C tile: it is then staged in two
+    // passes of 64 rows (pass ep holds the tm == ep half of every wave's rows).
     float* Cs = smem;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          Cs[(wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (BN / 2) + tn * 32 + r] = acc[tm][tn][e];
-    __syncthreads();
     const bool full = (ks_begin == 0 && ks_end == ks_total);
     constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
     const int c_c4 = tid % CF4, c_r = tid / CF4;
-    if (full) {
-      const int n = n0 + c_c4 * 4;
-      if (n < p.N) {
-        // All global operands of a batch of rows are requested before any is consumed: the epilogue of
-        // the short-K layers is latency bound, and one dependent load per row left the HBM pipe empty.
-        constexpr int NIT = BM / CROWS, EB = EOSVOS_EB;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) sc = ldg4(p.scale + n);
-        if (p.bias) bi = ldg4(p.bias + n);
-        const bool use_mask = p.mask && n >= p.mask_c0;
+    const int n = n0 + c_c4 * 4;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (full && n < p.N) {
+      if (p.scale) sc = ldg4(p.scale + n);
+      if (p.bias) bi = ldg4(p.bias + n);
+    }
+    const bool use_mask = p.mask && n >= p.mask_c0;
 #pragma unroll
-        for (int it0 = 0; it0 < NIT; it0 += EB) {
-          size_t md[EB];
-          bool ok[EB];
-          float4 rs[EB], ac[EB], mk[EB];
+    for (int ep = 0; ep < EPASS; ++ep) {
+      if (ep) __syncthreads();
 #pragma unroll
-          for (int j = 0; j < EB; ++j) {
-            const int m = m0 + c_r + (it0 + j) * CROWS;
-            ok[j] = m < p.M;
-            md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
-          }
-          if (p.res) {
+      for (int tm = 0; tm < 2; ++tm) {
+        if (EPASS == 2 && tm != ep) continue;
 #pragma unroll
-            for (int j = 0; j < EB; ++j) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
-          }
-          if (p.accum) {
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int j = 0; j < EB; ++j) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
-          }
-          if (use_mask) {
+          for (int e = 0; e < 16; ++e)
+            Cs[((EPASS == 1 ? wm * 64 + tm * 32 : wm * 32) + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * (BN / 2) +
+               tn * 32 + r] = acc[tm][tn][e];
+      }
+      __syncthreads();
+      // staged row lr of this pass is tile row trow(lr)
+      auto trow = [&](int lr) { return EPASS == 1 ? lr : ((lr >> 5) << 6) + (ep << 5) + (lr & 31); };
+      if (full) {
+        if (n < p.N) {
+          // All global operands of a batch of rows are requested before any is consumed: the epilogue of
+          // the short-K layers is latency bound, and one dependent load per row left the HBM pipe empty.
+          constexpr int NIT = EROWS / CROWS, EB = EOSVOS_EB;
 #pragma unroll
-            for (int j = 0; j < EB; ++j) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
-          }
+          for (int it0 = 0; it0 < NIT; it0 += EB) {
+            size_t md[EB];
+            bool ok[EB];
+            float4 rs[EB], ac[EB], mk[EB];
 #pragma unroll
-          for (int j = 0; j < EB; ++j) {
-            float4 v = *reinterpret_cast<const float4*>(Cs + (c_r + (it0 + j) * CROWS) * LDC + c_c4 * 4);
-            if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-            if (p.bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
-            if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
-            if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (use_mask) {
-              v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
-              v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
+            for (int j = 0; j < EB; ++j) {
+              const int m = m0 + trow(c_r + (it0 + j) * CROWS);
+              ok[j] = m < p.M;
+              md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
             }
-            if (ok[j]) *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+            if (p.res) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
+            }
+            if (p.accum) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
+            }
+            if (use_mask) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
+            }
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+              float4 v = *reinterpret_cast<const float4*>(Cs + (c_r + (it0 + j) * CROWS) * LDC + c_c4 * 4);
+              if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+              if (p.bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+              if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
+              if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
+              if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              if (use_mask) {
+                v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
+                v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
+              }
+              if (ok[j]) *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+            }
           }
         }
-      }
-    } else {
-      float* slab = p.ws + ((size_t)bid * 2 + (u == u_begin ? 0 : 1)) * (BM * BN);
+      } else {
+        float* slab = p.ws + ((size_t)bid * 2 + (u == u_begin ? 0 : 1)) * (BM * BN);
 #pragma unroll 4
-      for (int row = c_r; row < BM; row += CROWS)
-        *reinterpret_cast<float4*>(slab + row * BN + c_c4 * 4) = *reinterpret_cast<const float4*>(Cs + row * LDC + c_c4 * 4);
+        for (int lr = c_r; lr < EROWS; lr += CROWS)
+          *reinterpret_cast<float4*>(slab + trow(lr) * BN + c_c4 * 4) =
+              *reinterpret_cast<const float4*>(Cs + lr * LDC + c_c4 * 4);
+      }
     }
     if (!dp) u += ks_end - ks_begin;
   }
@@ -454,7 +470,7 @@ long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vect
   return total;
 }
 
-#define CONV_MAX_WG 512
+#define CONV_MAX_WG (256 * EOSVOS_OCC)
 int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG * 2 * 128 * 128; }
 
 // returns the number of workgroups; fills a.dp_q / a.per / a.nwg.

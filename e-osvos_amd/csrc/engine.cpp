@@ -315,6 +315,21 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     a.Ho = a.Hi; a.Wo = a.Wi; a.mul = 1; a.off0 = 0; a.kstep = 0; a.upshift = 0;
     a.M = B * a.Ho * a.Wo; a.dst_up = 1; a.Hf = Hin; a.Wf = Win;
   }
+  const int tail = a.N % 128;
+  if (a.N > 128 && tail > 0 && tail <= 64 && !a.dst_up && !(c.k == 3 && c.dil >= 2)) {
+    // e.g. the decoder's 304 input channels: 2 column tiles of 128 + one of 64 instead of 3 x 128
+    // (the 128-wide kernel would spend a third of its MFMAs on 80 padding columns)
+    ConvArgs b = a;
+    a.N -= tail;
+    trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
+    launch_conv(a, e->s);
+    b.N = tail; b.w += a.N; b.y += a.N;
+    if (b.mask) { b.mask += a.N; b.mask_c0 = b.mask_c0 > a.N ? b.mask_c0 - a.N : 0; }
+    if (b.res) b.res += a.N;
+    trace("dgrad", ci, b.M, b.N, (long)c.T() * c.cout, conv_plan(b));
+    launch_conv(b, e->s);
+    return;
+  }
   attach_tap_table(e, ci, 1, B, a);
   trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
   launch_conv(a, e->s);
