@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -378,14 +379,19 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
   if (!e->upd_tab[slot]) {
     std::vector<UpdEntry> tab(hi - lo);
     int blk = 0;
-    for (int ci = lo; ci < hi; ++ci) {
+    // most slabs first: those workgroups run the longest dependent chains and must not form the tail
+    std::vector<int> order(hi - lo);
+    for (int i = 0; i < hi - lo; ++i) order[i] = lo + i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return e->upd_splits[x] > e->upd_splits[y]; });
+    for (int k = 0; k < hi - lo; ++k) {
+      const int ci = order[k];
       const ConvL& c = t.convs[ci];
-      UpdEntry& u = tab[ci - lo];
+      UpdEntry& u = tab[k];
       u.w_off = c.poff; u.ws_off = e->ws_off[ci];
       u.n = (int)(c.wsize() + (c.bias ? c.cout : 0)); u.slab = u.n;
       u.splits = e->upd_splits[ci]; u.rowlen = c.T() * c.cin;
       u.lr_off = (int)c.lroff; u.norm_off = (c.norm && !e->gn()) ? (int)c.noff : -1; u.blk0 = blk;
-      blk += (u.n + 1023) / 1024;
+      blk += (u.n + 1024 * UPD_CHUNKS - 1) / (1024 * UPD_CHUNKS);
     }
     UpdEntry* d = (UpdEntry*)e->falloc((int64_t)(tab.size() * sizeof(UpdEntry) + 3) / 4);
     if (!d) return fail("hipMalloc update table");

@@ -161,8 +161,9 @@ struct UpdEntry {
   int n;           // elements
   int lr_off;      // offset of its per-neuron learning rates
   int norm_off;    // offset of its frozen-norm scale, -1 if none
-  int blk0;        // first workgroup of this entry (1024 elements per workgroup)
+  int blk0;        // first workgroup of this entry (UPD_CHUNKS x 1024 elements per workgroup)
 };
+#define UPD_CHUNKS 1   // 1024-element chunks per workgroup of the update kernel (UpdEntry::blk0 counts those)
 void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
                            const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s);
 // learning-rate hierarchy (meta_optim.py:27-67): stored lr state -> effective per-neuron lr, and back

@@ -841,30 +841,89 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
     if ((int)blockIdx.x >= blk0s[mid]) lo = mid; else hi = mid - 1;
   }
   const UpdEntry t = tab[lo];
-  const int e0 = ((int)blockIdx.x - t.blk0) * 1024 + threadIdx.x * 4;
-  if (e0 >= t.n) return;
+  constexpr int CH = UPD_CHUNKS;        // 1024-element chunks per workgroup, all in flight together
+  const int base = ((int)blockIdx.x - t.blk0) * (1024 * CH) + threadIdx.x * 4;
   const size_t zstride = (size_t)t.slab;
-  const float* s0 = ws + t.ws_off + e0;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e0 + 3 < t.n && (t.slab & 3) == 0) {
-#pragma unroll 8
-    for (int z = 0; z < t.splits; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(s0 + z * zstride);
-      g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
-    }
-  } else {
-    for (int z = 0; z < t.splits; ++z)
-      for (int j = 0; j < 4 && e0 + j < t.n; ++j) g[j] += s0[z * zstride + j];
-  }
+  if (((t.slab | t.n) & 3) == 0) {
+    // the weights and the first slabs of all chunks are
+    // requested before anything is consumed (the large layers have only 4-8 slabs, so a one-chunk loop
+    // left the memory pipe nearly empty)
+    float4 w4[CH], g4[CH];
+    bool ok[CH];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = e0 + j;
+    for (int c = 0; c < CH; ++c) {
+      const int e = base + c * 1024;
+      ok[c] = e < t.n;
+      g4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[c]) w4[c] = *reinterpret_cast<const float4*>(W + t.w_off + e);
+    }
+    // slabs in groups of 8 predicated loads: all of a group are in flight together whatever the trip count
+    // (a plain loop's remainder iterations each waited for their own load: 4-8 slabs = 4-8 serial latencies)
+    for (int z0 = 0; z0 < t.splits; z0 += 8) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (!ok[c]) continue;
+        const float* sp = ws + t.ws_off + base + c * 1024;
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          v[i] = (z0 + i < t.splits) ? *reinterpret_cast<const float4*>(sp + (size_t)(z0 + i) * zstride)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { g4[c].x += v[i].x; g4[c].y += v[i].y; g4[c].z += v[i].z; g4[c].w += v[i].w; }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!ok[c]) continue;
+      const int e = base + c * 1024;
+      const int row = e / t.rowlen;
+      float4 g = g4[c];
+      const bool one_row = (t.rowlen & 3) == 0;       // else the float4 may straddle output channels (stem: 147)
+      int r1 = row, r2 = row, r3 = row;
+      if (!one_row) { r1 = (e + 1) / t.rowlen; r2 = (e + 2) / t.rowlen; r3 = (e + 3) / t.rowlen; }
+      if (t.norm_off >= 0) {
+        const float* a = na + t.norm_off;
+        g.x *= a[row]; g.y *= a[r1]; g.z *= a[r2]; g.w *= a[r3];
+      }
+      if (lr_elem) {                                  // lr_hierarchy_level PARAM
+        const float4 l = *reinterpret_cast<const float4*>(lr_elem + t.w_off + e);
+        w4[c].x -= l.x * g.x; w4[c].y -= l.y * g.y; w4[c].z -= l.z * g.z; w4[c].w -= l.w * g.w;
+        *reinterpret_cast<float4*>(W + t.w_off + e) = w4[c];
+      } else if (lr) {
+        const float* l = lr + t.lr_off;
+        w4[c].x -= l[row] * g.x; w4[c].y -= l[r1] * g.y; w4[c].z -= l[r2] * g.z; w4[c].w -= l[r3] * g.w;
+        *reinterpret_cast<float4*>(W + t.w_off + e) = w4[c];
+      }
+      if (gsum) {
+        float4 q = *reinterpret_cast<const float4*>(gsum + t.w_off + e);
+        q.x += g.x; q.y += g.y; q.z += g.z; q.w += g.w;
+        *reinterpret_cast<float4*>(gsum + t.w_off + e) = q;
+      }
+      if (gout) *reinterpret_cast<float4*>(gout + t.w_off + e) = g;
+    }
+    return;
+  }
+  // odd-sized tensors (the classifier's 256 weights + bias): element per thread, coalesced, the slab
+  // loop unrolled so that 8 loads per element are in flight (these tensors come with ~1000 slabs)
+  const int cbase = ((int)blockIdx.x - t.blk0) * (1024 * CH);
+  for (int j = 0; j < 4 * CH; ++j) {
+    const int e = cbase + j * 256 + threadIdx.x;
     if (e >= t.n) break;
+    const float* sp = ws + t.ws_off + e;
+    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= t.splits; z += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc8[i] += sp[(size_t)(z + i) * zstride];
+    }
+    // sequential order of the additions is kept per lane i; lanes are combined in a fixed order
+    for (; z < t.splits; ++z) acc8[z & 7] += sp[(size_t)z * zstride];
+    float gv = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
     const int row = e / t.rowlen;
-    float gv = g[j];
     if (t.norm_off >= 0) gv *= na[t.norm_off + row];
     float* wp = W + t.w_off + e;
-    if (lr_elem) *wp = *wp - lr_elem[t.w_off + e] * gv;      // lr_hierarchy_level PARAM
+    if (lr_elem) *wp = *wp - lr_elem[t.w_off + e] * gv;
     else if (lr) *wp = *wp - lr[t.lr_off + row] * gv;
     if (gsum) gsum[t.w_off + e] += gv;
     if (gout) gout[t.w_off + e] = gv;

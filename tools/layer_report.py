@@ -48,6 +48,17 @@ def main(trace_csv, log, steps=3):
     excess.sort(reverse=True)
     print('largest excess over a 120 TFLOP/s pace: ' + ', '.join(f'{k}{ci}:{ex:.0f}us' for ex, pos, k, ci in excess[:24]))
     print('total excess: %.2f ms' % (sum(e[0] for e in excess if e[0] > 0) / 1e3))
+    nsteps = max(1, len(starts))
+    byname = defaultdict(lambda: [0, 0])
+    for r in rows:
+        nm = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('eosvos::', '')
+        byname[nm][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); byname[nm][1] += 1
+    print(f'per-step kernel totals over {nsteps} traced steps (launches/step, us/step):')
+    for nm, (t, c) in sorted(byname.items(), key=lambda kv: -kv[1][0])[:22]:
+        print(f'  {nm[:60]:60s} {c / nsteps:7.1f} {t / nsteps / 1e3:9.1f}')
+    upd = [r for r in rows if 'sgd_update_all' in r['Kernel_Name']][-4:]
+    print('last update launches (us, workgroups):', [(round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, 1),
+                                                      int(r['Grid_Size_X']) // 256) for r in upd])
     all_step = [r for r in rows]
     print('all kernels in trace: %.2f ms' % (sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in all_step) / 1e6))
 
