@@ -523,7 +523,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   ALLOC(e->cat, n16 * 1280); ALLOC(e->g_cat, n16 * 1280);
   ALLOC(e->vec, (int64_t)B * 2048); ALLOC(e->gvec, (int64_t)B * 2048);
   ALLOC(e->poolout, (int64_t)B * 256); ALLOC(e->gp, (int64_t)B * 256);
-  ALLOC(e->colscratch, (int64_t)B * 32 * 2048);
+  ALLOC(e->colscratch, (int64_t)B * 64 * 2048);      // COLSUM_CHUNKS partial sums
   ALLOC(e->proj, n16 * 256); ALLOC(e->g_proj, n16 * 256);
   ALLOC(e->dcat, n4 * 304); ALLOC(e->g_dcat, n4 * 304);
   ALLOC(e->d1, n4 * 256); ALLOC(e->g_d1, n4 * 256);

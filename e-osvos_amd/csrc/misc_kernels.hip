@@ -447,18 +447,27 @@ void launch_resize_bwd(const float* gy, int ldgy, float* gx, int ldgx, const flo
 
 // ---- ASPP image pooling branch ---------------------------------------------------------------
 // scratch[b][chunk][c] = sum over the chunk's pixels ; out[b][c] = alpha * sum over chunks
-#define COLSUM_CHUNKS 32
-__global__ void colsum_partial_kernel(const float* __restrict__ x, int ldx, float* __restrict__ scratch, int P,
-                                      int C) {
+#define COLSUM_CHUNKS 64
+// C % 4 == 0; a thread owns float4 channel groups and walks its chunk's pixels with 8 loads in flight
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx,
+                                                              float* __restrict__ scratch, int P, int C) {
   const int b = blockIdx.y, ch = blockIdx.x;
   const int per = (P + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
   const int p0 = ch * per;
   int p1 = p0 + per;
   if (p1 > P) p1 = P;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int p = p0; p < p1; ++p) s += x[((long)b * P + p) * ldx + c];
-    scratch[((long)b * COLSUM_CHUNKS + ch) * C + c] = s;
+  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xp = x + ((long)b * P) * ldx + c;
+    for (int q = p0; q < p1; q += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        v[i] = (q + i < p1) ? *reinterpret_cast<const float4*>(xp + (long)(q + i) * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    }
+    *reinterpret_cast<float4*>(scratch + ((long)b * COLSUM_CHUNKS + ch) * C + c) = s;
   }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ scratch, float* __restrict__ out, int B, int C,
@@ -467,6 +476,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ scratch, float* __
   GRID_STRIDE(e, n) {
     const int c = (int)(e % C), b = (int)(e / C);
     float s = 0.f;
+#pragma unroll 16
     for (int ch = 0; ch < COLSUM_CHUNKS; ++ch) s += scratch[((long)b * COLSUM_CHUNKS + ch) * C + c];
     out[e] = alpha * s;
   }
@@ -506,6 +516,7 @@ __global__ void gemv_bwd_kernel(const float* __restrict__ W, const float* __rest
     if (e < nv) {
       const int k = (int)(e % K), b = (int)(e / K);
       float s = 0.f;
+#pragma unroll 16
       for (int n = 0; n < N; ++n) s = fmaf(gp[b * N + n] * (a ? a[n] : 1.f), W[(long)n * K + k], s);
       gv[e] = s;
     } else {
