@@ -171,6 +171,8 @@ struct eosvos_engine {
   bool keep_grads = false;
   // learned-lr storage level (meta_optim.py:27-67): the update consumes `lr` (per neuron) or `lr_elem`
   int loss_kind = EOSVOS_LOSS_BCE;      // loss of the fused entry points (eosvos_set_loss)
+  int* aug_tab = nullptr;               // eosvos_warp_affine: adelta[W] bdelta[W] X0[H] Y0[H], then the nonzero counter
+  float* aug_ctab = nullptr;            // bicubic coefficients at 1/32 pixel: [32][4]
   int lr_level = EOSVOS_LR_NEURON, lr_log = 0;
   float *lr_elem = nullptr, *glr_tmp = nullptr, *ptmp = nullptr;
   int *row_tensor = nullptr, *tensor_row0 = nullptr, *all_row0 = nullptr;
@@ -585,7 +587,7 @@ int eosvos_synchronize(eosvos_engine* e) {
 static void import_params(eosvos_engine* e, const float* flat, float* dst) {
   for (const ConvL& c : e->t.convs) {
     launch_oihw_to_ohwi(flat + c.poff, dst + c.poff, c.cout, c.cin, c.T(), e->s);
-    if (c.bias) hipMemcpyAsync(dst + c.poff + c.wsize(), flat + c.poff + c.wsize(), c.cout * 4, hipMemcpyDeviceToDevice, e->s);
+    if (c.bias) (void)hipMemcpyAsync(dst + c.poff + c.wsize(), flat + c.poff + c.wsize(), c.cout * 4, hipMemcpyDeviceToDevice, e->s);
   }
 }
 static void export_params(eosvos_engine* e, const float* src, float* flat, float alpha, int add) {
@@ -984,6 +986,62 @@ int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t
   return 0;
 }
 
+// ---- data augmentation on the device (custom_transforms.py:9-92,189-213) --------------------------
+int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int flip, double rot_deg, double scale,
+                       int interp, float* dst, int* nonzero_host) {
+  if (!e || !src || !dst || channels < 1) return fail("bad argument");
+  if (interp != EOSVOS_INTER_NEAREST && interp != EOSVOS_INTER_CUBIC) return fail("unknown interpolation");
+  const int H = e->H, W = e->W;
+  if (!e->aug_tab) {
+    e->aug_tab = (int*)e->falloc(2 * W + 2 * H + 1);
+    e->aug_ctab = e->falloc(128);
+    if (!e->aug_tab || !e->aug_ctab) return fail("hipMalloc augmentation tables");
+    float ct[128];
+    for (int i = 0; i < 32; ++i) {        // interpolateCubic(i/32), A = -0.75, float arithmetic as OpenCV's table
+      const float A = -0.75f, x = i * (1.f / 32);
+      float* c = ct + i * 4;
+      c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+      c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+      c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+      c[3] = 1.f - c[0] - c[1] - c[2];
+    }
+    HIPOK(hipMemcpy(e->aug_ctab, ct, sizeof(ct), hipMemcpyHostToDevice));
+  }
+  // cv2.getRotationMatrix2D((w/2, h/2), rot, sc): center is a Point2f
+  const double ang = rot_deg * (3.1415926535897932384626433832795 / 180.0);
+  const double alpha = cos(ang) * scale, beta = sin(ang) * scale;
+  const double cx = (double)(float)(W / 2.0), cy = (double)(float)(H / 2.0);
+  double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+  // cv::warpAffine without WARP_INVERSE_MAP inverts the matrix, then walks dst pixels in fixed point
+  double D = M[0] * M[4] - M[1] * M[3];
+  D = D != 0 ? 1. / D : 0;
+  const double A11 = M[4] * D, A22 = M[0] * D;
+  M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+  const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+  M[2] = b1; M[5] = b2;
+  const int AB_SCALE = 1 << 10;
+  const int round_delta = interp == EOSVOS_INTER_NEAREST ? AB_SCALE / 2 : AB_SCALE / 32 / 2;
+  std::vector<int> tab(2 * W + 2 * H + 1);
+  for (int x = 0; x < W; ++x) {
+    tab[x] = (int)lrint(M[0] * x * AB_SCALE);
+    tab[W + x] = (int)lrint(M[3] * x * AB_SCALE);
+  }
+  for (int y = 0; y < H; ++y) {
+    tab[2 * W + y] = (int)lrint((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+    tab[2 * W + H + y] = (int)lrint((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+  }
+  tab[2 * W + 2 * H] = 0;
+  HIPOK(hipMemcpyAsync(e->aug_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, e->s));
+  launch_warp_affine(src, dst, channels, H, W, e->aug_tab, e->aug_ctab, interp == EOSVOS_INTER_CUBIC, flip != 0,
+                     nonzero_host ? e->aug_tab + 2 * W + 2 * H : nullptr, e->s);
+  HIPOK(hipGetLastError());
+  if (nonzero_host) {
+    HIPOK(hipMemcpyAsync(nonzero_host, e->aug_tab + 2 * W + 2 * H, sizeof(int), hipMemcpyDeviceToHost, e->s));
+    HIPOK(hipStreamSynchronize(e->s));
+  }
+  return 0;
+}
+
 int eosvos_meta_task_begin(eosvos_engine* e) {
   if (!e) return fail("null engine");
   if (!e->gsum) {
@@ -1085,8 +1143,8 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
   HIPOK(hipEventElapsedTime(&ms, a, b));
   *ms_host = ms / reps;
   *flops_host = 2.0 * (double)batch * e->h4 * e->w4 * 256.0 * 304.0 * 9.0;
-  hipEventDestroy(a);
-  hipEventDestroy(b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
   return 0;
 }
 
@@ -1230,8 +1288,8 @@ int eosvos_test_conv(eosvos_engine* e, const float* x, const float* w_oihw, cons
   a.ws = ws;
   launch_conv(a, e->s);
   HIPOK(hipStreamSynchronize(e->s));
-  hipFree(w);
-  hipFree(ws);
+  (void)hipFree(w);
+  (void)hipFree(ws);
   HIPOK(hipGetLastError());
   return 0;
 }
@@ -1267,7 +1325,7 @@ int eosvos_test_conv_bwd(eosvos_engine* e, const float* x, const float* w_oihw, 
   launch_sgd_update(dw, wsw, g2.splits, n, nullptr, nullptr, nullptr, dw, (int64_t)T * Cin, n, e->s);
   launch_ohwi_to_oihw(dw, dw_oihw, Cout, Cin, T, 1.f, 0, e->s);
   HIPOK(hipStreamSynchronize(e->s));
-  hipFree(w); hipFree(ws); hipFree(wsw); hipFree(dw);
+  (void)hipFree(w); (void)hipFree(ws); (void)hipFree(wsw); (void)hipFree(dw);
   HIPOK(hipGetLastError());
   return 0;
 }

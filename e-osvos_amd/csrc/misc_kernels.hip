@@ -1172,3 +1172,84 @@ void launch_dice(const float* logits, const float* gt, float* dlogits, float* lo
                      (long)n);
 }
 }  // namespace eosvos
+
+// ---- device-side data augmentation: cv2.warpAffine restated (custom_transforms.py:41-51) -----------------
+// RandomScaleNRotate warps the frame with cv2.INTER_CUBIC and the label with cv2.INTER_NEAREST, border 0,
+// canvas size unchanged; RandomHorizontalFlip mirrors the source first (cv2.flip, `:202-211`).  OpenCV's
+// warpAffine (imgproc/imgwarp.cpp, 4.1) computes the source coordinates in 10-bit fixed point from integer
+// tables adelta/bdelta (per column) and X0/Y0 (per row); the host builds those tables in double exactly as
+// OpenCV does, so the coordinates here are bit-identical to the restated algorithm; cubic taps use the
+// a = -0.75 kernel sampled at 1/32 pixel (INTER_BITS = 5), weights = cy[k1]*cx[k2] in float.
+namespace eosvos {
+__global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int H, int W, const int* __restrict__ adelta,
+                                                           const int* __restrict__ bdelta, const int* __restrict__ X0,
+                                                           const int* __restrict__ Y0, const float* __restrict__ ctab,
+                                                           int cubic, int flip, int* __restrict__ nonzero) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  int cnt = 0;
+  if (x < W) {
+    const long hw = (long)H * W;
+    const int Xf = X0[y] + adelta[x], Yf = Y0[y] + bdelta[x];
+    if (!cubic) {
+      const int sx = Xf >> 10, sy = Yf >> 10;
+      const bool in = (unsigned)sx < (unsigned)W && (unsigned)sy < (unsigned)H;
+      const int ux = flip ? W - 1 - sx : sx;
+      for (int c = 0; c < C; ++c) {
+        const float v = in ? src[c * hw + (long)sy * W + ux] : 0.f;
+        dst[c * hw + (long)y * W + x] = v;
+        cnt += v != 0.f;
+      }
+    } else {
+      const int X = Xf >> 5, Y = Yf >> 5;
+      const int sx = (X >> 5) - 1, sy = (Y >> 5) - 1;
+      const float* cx = ctab + (X & 31) * 4;
+      const float* cy = ctab + (Y & 31) * 4;
+      const bool interior = (unsigned)sx < (unsigned)(W - 3 > 0 ? W - 3 : 0) && (unsigned)sy < (unsigned)(H - 3 > 0 ? H - 3 : 0);
+      const bool centre_out = (unsigned)(sx + 1) >= (unsigned)W || (unsigned)(sy + 1) >= (unsigned)H;
+      for (int c = 0; c < C; ++c) {
+        const float* S = src + c * hw;
+        float sum = 0.f;
+        if (interior) {
+          // remapBicubic's interior order: one 4-term expression per row, rows accumulated
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float* R = S + (long)(sy + i) * W;
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ux = flip ? W - 1 - (sx + j) : sx + j;
+              const float t = R[ux] * (cy[i] * cx[j]);
+              r = j == 0 ? t : r + t;
+            }
+            sum = i == 0 ? r : sum + r;
+          }
+        } else if (!centre_out) {
+          // border branch: taps outside the image contribute the constant 0, tap-by-tap accumulation
+          for (int i = 0; i < 4; ++i) {
+            const int yy = sy + i;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int j = 0; j < 4; ++j) {
+              const int xx = sx + j;
+              if ((unsigned)xx >= (unsigned)W) continue;
+              const int ux = flip ? W - 1 - xx : xx;
+              sum += S[(long)yy * W + ux] * (cy[i] * cx[j]);
+            }
+          }
+        }
+        dst[c * hw + (long)y * W + x] = sum;
+        cnt += sum != 0.f;
+      }
+    }
+  }
+  if (nonzero) {
+    cnt = (int)wave_sum((float)cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nonzero, cnt);
+  }
+}
+void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const int* tables /*adelta[W] bdelta[W] X0[H] Y0[H]*/,
+                        const float* ctab, int cubic, int flip, int* nonzero, hipStream_t s) {
+  hipLaunchKernelGGL(warp_affine_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, src, dst, C, H, W, tables, tables + W,
+                     tables + 2 * W, tables + 2 * W + H, ctab, cubic, flip, nonzero);
+}
+}  // namespace eosvos

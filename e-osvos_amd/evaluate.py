@@ -9,8 +9,10 @@ own loop cannot run the DeepLab model at this commit):
   first when `reset_model_mode == 'FIRST_STEP'` (`:200-205,283-287`);
   finally merge objects: background where max prob < 0.5, else argmax + 1 (`:322-326`), the
   train frame being seeded with 2*GT (`:167-168`).
-Data loading / augmentation is the caller's business (`augment(frame, gt, batch, seed)`):
-benchmarks use synthetic frames.
+Data loading is the caller's business; the first-frame augmentation of round 0
+(`random_train_transform`, `evaluate.py:215-218`, `helper_func.py:255-261`) runs on the device
+(`custom_transforms.FirstFrameAugmenter`) when `data_cfg.random_train_transform` is set, or through a
+caller-supplied `augment(frame, gt, batch, seed)`; benchmarks use synthetic frames.
 """
 import torch
 
@@ -39,6 +41,18 @@ def online_adapt_schedule(num_frames, train_frame_id, step, train_batch_size):
     return rounds
 
 
+def device_augment(model):
+    """Round-0 batches = `batch` independent flip / scale / rotate warps of the first frame, drawn with the
+    `random` state that `set_random_seeds(seed + epoch + round)` just set (evaluate.py:221-224)."""
+    from .custom_transforms import FirstFrameAugmenter
+
+    def fn(frame, gt, batch, seed):
+        eng = model._ensure_engine(frame.shape[2], frame.shape[3], batch)
+        images, labels, _ = FirstFrameAugmenter(eng).batch(frame[0].contiguous(), gt[0].contiguous(), batch)
+        return images, labels
+    return fn
+
+
 def _repeat_batch(frame, gt, batch, seed):
     return frame.expand(batch, -1, -1, -1).contiguous(), gt.expand(batch, -1, -1, -1).contiguous()
 
@@ -49,6 +63,8 @@ def evaluate_sequence(model, meta_optim, meta_optim_state_dict, frames, object_g
     cfg keys (names of cfgs/meta.yaml): num_epochs.eval, eval_online_adapt.{step,reset_model_mode,
     num_epochs,min_prop}, data_cfg.batch_sizes.train, seed, loss_func, train_early_stopping_cfg.
     Returns (labels (N,H,W) uint8, per-object probs list, train loss history per object)."""
+    if augment is None and cfg['data_cfg'].get('random_train_transform'):
+        augment = device_augment(model)
     augment = augment or _repeat_batch
     n = frames.shape[0]
     ona = cfg['eval_online_adapt']

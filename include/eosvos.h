@@ -128,6 +128,21 @@ int eosvos_infer(eosvos_engine* e, const float* images, int batch, float* probs_
 int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t n_pix,
                         uint8_t* labels_out);
 
+/* ---- data augmentation (data/custom_transforms.py:9-92,189-213; helper_func.py:255-261) --- */
+/* One RandomHorizontalFlip + RandomScaleNRotate application on the device: dst = cv2.warpAffine(
+ * cv2.flip(src) if flip else src, cv2.getRotationMatrix2D((W/2, H/2), rot_deg, scale), (W, H),
+ * flags = INTER_NEAREST (labels, `:46-47`) | INTER_CUBIC (frames, `:48-49`)), border constant 0.
+ * src/dst: channels x H x W planes (H, W of the engine).  The caller draws flip / rot / scale with the
+ * reference's `random` sequence and repeats the label warp while it lost the object (`:53-78`):
+ * nonzero_host (may be NULL; synchronises) receives the number of non-zero output elements.
+ * OpenCV is not part of the reference tree; the algorithm restated is opencv-python 4.1
+ * (requirements.txt:63) imgproc/imgwarp.cpp: inverse matrix, 10-bit fixed-point coordinates,
+ * 1/32-pixel bicubic (a = -0.75) table. */
+#define EOSVOS_INTER_NEAREST 0
+#define EOSVOS_INTER_CUBIC 2
+int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int flip, double rot_deg,
+                       double scale, int interp, float* dst, int* nonzero_host);
+
 /* ---- learning-rate hierarchy (meta_optim.py:27-67) ------------------------------------ */
 /* `lr_hierarchy_level`: how the learned lr state is stored.  NEURON (cfgs/meta.yaml:36) one
  * value per output channel; TENSOR one per trainable tensor (`log_init_lr` of shape

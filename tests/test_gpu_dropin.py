@@ -115,6 +115,8 @@ def test_online_adaptation_sequence(model_and_optim):
     pseudo-label batches and the merged label maps, against the same loop run on the CPU oracle."""
     from eosvos_amd import config
     from eosvos_amd.evaluate import evaluate_sequence, online_adapt_schedule
+    from eosvos_amd.helper_func import set_random_seeds
+    from oracle import augment as oaug
     from oracle import deeplab, meta
     model, mo, msd = model_and_optim
     cfg = config.parse_cli(['with', 'DAVIS-2017', 'e-OSVOS-OnA', 'num_epochs.eval=3', 'eval_online_adapt.num_epochs=2',
@@ -140,7 +142,18 @@ def test_online_adaptation_sequence(model_and_optim):
         masks = torch.zeros(N, 1, H, W)
         masks[0] = 2 * y0[0]
         x0 = seq[0:1]
-        _, P = meta.finetune(sd, lrs, [(x0.expand(3, -1, -1, -1), y0.expand(3, -1, -1, -1))] * 3)
+        # round 0: random_train_transform (e-OSVOS configs): 3 flip / scale / rotate warps per iteration, drawn
+        # after set_random_seeds(seed + epoch + round) as evaluate.py:221-224 does
+        batches = []
+        for epoch in (1, 2, 3):
+            set_random_seeds(cfg.get('seed', 1) + epoch)
+            xs, ys = [], []
+            for _ in range(3):
+                ai, ag, _p = oaug.random_flip_scale_rotate(x0[0].permute(1, 2, 0).contiguous().numpy(), y0[0, 0].numpy())
+                xs.append(torch.from_numpy(ai).permute(2, 0, 1))
+                ys.append(torch.from_numpy(ag)[None])
+            batches.append((torch.stack(xs).contiguous(), torch.stack(ys).contiguous()))
+        _, P = meta.finetune(sd, lrs, batches)
         P_first = P
         with torch.no_grad():
             for f in range(1, 4):

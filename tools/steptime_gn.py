@@ -1,0 +1,13 @@
+import sys,time,torch
+sys.path.insert(0,".")
+from eosvos_amd import synthetic
+from eosvos_amd.engine import Engine
+for B in (1,3):
+    eng=Engine("resnet50",480,854,max_batch=B,norm="gn")
+    sd=synthetic.synthetic_state("resnet50")
+    eng.load_model_state(sd, synthetic.synthetic_lrs("resnet50"))
+    x,y=synthetic.synthetic_frames(B,480,854); xg,yg=x.cuda(),y.cuda()
+    for _ in range(3): eng.finetune_step(xg,yg,sync_loss=False)
+    eng.synchronize(); t0=time.perf_counter()
+    for _ in range(10): eng.finetune_step(xg,yg,sync_loss=False)
+    eng.synchronize(); print("GN B",B,"ms/step %.2f"%((time.perf_counter()-t0)*100)); eng.close()
