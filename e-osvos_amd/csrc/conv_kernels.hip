@@ -419,20 +419,59 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   const int c_c4 = threadIdx.x % CF4, c_r = threadIdx.x / CF4;
   const int n = n0 + c_c4 * 4;
   if (n >= p.N) return;
-  // blockIdx.y selects one eighth of the tile's rows (more, shorter workgroups: the sum is
-  // latency bound)
-  for (int row = blockIdx.y * (BM / 8) + c_r; row < (blockIdx.y + 1) * (BM / 8); row += CROWS) {
-    const int m = m0 + row;
-    if (m >= p.M) break;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int g = g0; g <= g1; ++g) {
-      const int slot = (sk0 + (long)g * p.per >= a) ? 0 : 1;
-      const float4 t = ldg4(p.ws + ((size_t)g * 2 + slot) * (BM * BN) + row * BN + c_c4 * 4);
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  // blockIdx.y selects one eighth of the tile's rows (more, shorter workgroups: the sum is latency
+  // bound); every global operand of the thread's rows is requested before the first is consumed
+  constexpr int RPB = BM / 8 / CROWS;          // rows per thread: 2 (BN = 128) or 1 (BN = 64)
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.scale) sc = ldg4(p.scale + n);
+  if (p.bias) bi = ldg4(p.bias + n);
+  const bool use_mask = p.mask && n >= p.mask_c0;
+  size_t md[RPB];
+  bool ok[RPB];
+  int rows[RPB];
+  float4 rs[RPB], ac[RPB], mk[RPB], sum[RPB];
+#pragma unroll
+  for (int j = 0; j < RPB; ++j) {
+    rows[j] = blockIdx.y * (BM / 8) + c_r + j * CROWS;
+    const int m = m0 + rows[j];
+    ok[j] = m < p.M;
+    md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
+    sum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.res) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
+    if (p.accum) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
+    if (use_mask) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
+  }
+  for (int g = g0; g <= g1; g += 4) {
+    float4 t[4][RPB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gi = g + i <= g1 ? g + i : g1;
+      const int slot = (sk0 + (long)gi * p.per >= a) ? 0 : 1;
+#pragma unroll
+      for (int j = 0; j < RPB; ++j)
+        t[i][j] = ldg4(p.ws + ((size_t)gi * 2 + slot) * (BM * BN) + rows[j] * BN + c_c4 * 4);
     }
-    const size_t md = dst_pixel(p, m);
-    *reinterpret_cast<float4*>(p.y + md * p.ldy + n) = conv_epilogue4(p, s, md, n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (g + i > g1) break;
+#pragma unroll
+      for (int j = 0; j < RPB; ++j) { sum[j].x += t[i][j].x; sum[j].y += t[i][j].y; sum[j].z += t[i][j].z; sum[j].w += t[i][j].w; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RPB; ++j) {
+    if (!ok[j]) continue;
+    float4 v = sum[j];
+    if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+    if (p.bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+    if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
+    if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (use_mask) {
+      v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
+      v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
   }
 }
 
@@ -500,8 +539,11 @@ int conv_plan(ConvArgs& a) {
 #ifndef EOSVOS_MINK
 #define EOSVOS_MINK 3
 #endif
-    if (ksteps <= EOSVOS_MINK + 1 && a.total_units <= 0) {
-      per = ksteps; nwg = tiles;                       // short K: one whole tile per workgroup, no fix-up
+    // short K, or at least one tile per CU and a K so short that the fix-up pass (a second launch, >= 10 us)
+    // costs more than the idle second slot of some CUs: one whole tile per workgroup
+    const bool dp_small = tiles >= CONV_MAX_WG / 2 && ksteps * EOSVOS_BK <= 256;
+    if ((ksteps <= EOSVOS_MINK + 1 || dp_small) && a.total_units <= 0) {
+      per = ksteps; nwg = tiles;                       // no fix-up
     } else {
       if (U / nwg < EOSVOS_MINK) nwg = U / EOSVOS_MINK > 0 ? U / EOSVOS_MINK : 1;   // >= MINK K-steps per workgroup
       per = (U + nwg - 1) / nwg;

@@ -13,6 +13,11 @@ def main(trace_csv, log, steps=3):
     rows = [r for r in csv.DictReader(open(trace_csv))]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     mf = [r for r in rows if 'conv_igemm_kernel' in r['Kernel_Name'] or 'wgrad_kernel<' in r['Kernel_Name']]
+    # fix-up launch that follows a conv launch (same stream order)
+    for i, r in enumerate(rows):
+        if 'conv_igemm_kernel' in r['Kernel_Name']:
+            nx = rows[i + 1] if i + 1 < len(rows) else None
+            r['fix_ns'] = (int(nx['End_Timestamp']) - int(nx['Start_Timestamp'])) if nx is not None and 'conv_fixup' in nx['Kernel_Name'] else 0
     launches = []
     for line in open(log, errors='ignore'):
         m = re.search(r'EOSVOS_TRACE (\w+) conv=(\d+) M=(\d+) N=(\d+) K=(\d+) splits=(\d+) flops=(\d+)', line)
@@ -24,22 +29,24 @@ def main(trace_csv, log, steps=3):
     starts = [i for i, l in enumerate(launches) if l[0] == 'fwd' and l[1] == 1]
     per = starts[1] - starts[0] if len(starts) > 1 else len(launches)
     agg = defaultdict(lambda: [0.0, 0.0, 0, None])
+    fixt = defaultdict(float)
     full = [s for s in starts if s + per <= len(launches)][-steps:]
     for s in full:
         for i in range(s, s + per):
             k, ci, M, N, K, sp, fl = launches[i]
             d = int(mf[i]['End_Timestamp']) - int(mf[i]['Start_Timestamp'])
             a = agg[(i - s, k, ci)]
+            fixt[(i - s, k, ci)] += mf[i].get('fix_ns', 0)
             a[0] += d; a[1] += fl; a[2] += 1; a[3] = (M, N, K, sp, int(mf[i]['Grid_Size_X']) // 256)
     tot_t = tot_f = 0
     by_kind = defaultdict(lambda: [0.0, 0.0])
-    print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6} {"excess_us@120":>13}')
+    print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6} {"excess_us@120":>13} {"fixup":>7}')
     excess = []
     for (pos, k, ci), (t, f, n, info) in sorted(agg.items()):
         us = t / n / 1e3
         ex = us - f / n / 120e6        # time above what the layer would take at 120 TFLOP/s
         excess.append((ex, pos, k, ci))
-        print(f'{pos:3d} {k:6} {ci:4d} {info[0]:7d} {info[1]:6d} {info[2]:6d} {info[3]:3d} {info[4]:5d} {us:8.1f} {f / t / 1e3:6.1f} {ex:13.1f}')
+        print(f'{pos:3d} {k:6} {ci:4d} {info[0]:7d} {info[1]:6d} {info[2]:6d} {info[3]:3d} {info[4]:5d} {us:8.1f} {f / t / 1e3:6.1f} {ex:13.1f} {fixt[(pos, k, ci)] / n / 1e3:7.1f}')
         tot_t += t / n; tot_f += f / n
         by_kind[k][0] += t / n; by_kind[k][1] += f / n
     print(f'MFMA kernels per step: {tot_t / 1e6:.2f} ms, {tot_f / 1e9:.1f} GFLOP, {tot_f / tot_t / 1e3:.1f} TF/s')
