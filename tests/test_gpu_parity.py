@@ -477,3 +477,41 @@ def test_meta_task_with_dice_loss_vs_oracle(small_engine, weights):
     finally:
         eng.set_loss('cross_entropy')
         eng.load_model_state(*weights)
+
+
+def test_edge_cases_and_error_behaviour(small_engine, weights):
+    """Empty / full masks through every loss, and the C-ABI's error contract: non-zero status + message, no abort
+    ('every call returns int status with eosvos_last_error()')."""
+    import ctypes
+    from eosvos_amd import _ffi
+    from oracle import deeplab
+    eng = small_engine
+    eng.load_model_state(*weights)
+    x, _ = synthetic.synthetic_frames(2, *SMALL, seed=5)
+    logits = eng.forward(x.to(DEV))
+    for fill in (0.0, 1.0):
+        gt = torch.full((2, 1, *SMALL), fill)
+        for name in ('cross_entropy', 'dice', 'cross_entropy_and_dice', 'class_balanced_cross_entropy'):
+            got = float(eng.loss(name, gt.to(DEV)))
+            ref = float(deeplab.loss_fn(name, logits.cpu(), gt))
+            # `(1 - dice_loss).log()` with an empty mask is 1 - (1 - 7e-5) in fp32 in the reference formula (the
+            # kernel evaluates log(num/den) in double): allow that cancellation error
+            tol = 1e-4 if name == 'cross_entropy_and_dice' else 2e-5
+            assert np.isfinite(got) and abs(got - ref) <= tol * max(1.0, abs(ref)), (name, fill, got, ref)
+    lib = eng.lib
+    xg = x.to(DEV)
+    rc = lib.eosvos_forward(eng.h, ctypes.c_void_p(xg.data_ptr()), eng.max_batch + 1, None)
+    assert rc != 0 and len(lib.eosvos_last_error()) > 0
+    rc = lib.eosvos_forward(eng.h, None, 1, None)
+    assert rc != 0
+    eng.forward(xg[:1].contiguous(), want_logits=False)
+    gt2 = torch.zeros(2, 1, *SMALL, device=DEV)
+    with pytest.raises(_ffi.EosvosError):
+        _ffi.check(lib.eosvos_loss_bce(eng.h, ctypes.c_void_p(gt2.data_ptr()), 2, None))     # batch differs from the forward
+    with pytest.raises(_ffi.EosvosError):
+        _ffi.check(lib.eosvos_loss(eng.h, 7, ctypes.c_void_p(gt2.data_ptr()), 1, None))       # unknown loss kind
+    with pytest.raises(_ffi.EosvosError):
+        _ffi.check(lib.eosvos_set_lr_state(eng.h, 9, 0, ctypes.c_void_p(gt2.data_ptr())))     # unknown hierarchy level
+    # the engine is still usable after the failed calls
+    assert np.isfinite(eng.finetune_step(xg, torch.zeros(2, 1, *SMALL, device=DEV)))
+    eng.load_model_state(*weights)
