@@ -55,6 +55,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long
 // destination pixel of GEMM row m: dense, or (1x1 stride-2 data gradient) the even pixels of
 // the finer destination grid -- the odd ones receive no contribution and are never touched
 __device__ __forceinline__ size_t dst_pixel(const ConvArgs& p, int m) {
+  if (p.par) return (size_t)conv_par_pixel(p.B, p.Ho, p.Wo, m);
   if (!p.dst_up) return (size_t)m;
   const int hw = p.Ho * p.Wo;
   const int b = m / hw, rem = m - b * hw;
@@ -170,8 +171,9 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
     int a_sy0[APASS], a_sx0[APASS], a_img[APASS];
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      const int m = m0 + a_r + i * AROWS;
+      int m = m0 + a_r + i * AROWS;
       if (m < p.M) {
+        if (p.par) m = conv_par_pixel(p.B, p.Ho, p.Wo, m);
         const int hw = p.Ho * p.Wo;
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -475,7 +477,8 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   }
 }
 
-// Host: per-tile compacted K-step prefix and valid-tap masks for a unit-stride gather (upshift 0).
+// Host: per-tile compacted K-step prefix and valid-tap masks (dilated unit-stride gathers; stride-2 data
+// gradients in parity-major row order).
 // Returns the total number of valid K steps.  prefix has tiles+1 entries, mask tiles entries.
 long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vector<int>& mask) {
   const int bn = (a.N > 64) ? 128 : 64;
@@ -485,15 +488,17 @@ long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vect
   prefix.assign((size_t)mt * nt + 1, 0);
   mask.assign((size_t)mt * nt, 0);
   long total = 0;
+  const int up = 1 << a.upshift;
   for (int tm = 0; tm < mt; ++tm) {
     int mk = 0;
-    for (int m = tm * 128; m < a.M && m < tm * 128 + 128; ++m) {
+    for (int mr = tm * 128; mr < a.M && mr < tm * 128 + 128; ++mr) {
+      const int m = a.par ? conv_par_pixel(a.B, a.Ho, a.Wo, mr) : mr;
       const int hw = a.Ho * a.Wo, rem = m % hw;
       const int oy = rem / a.Wo, ox = rem % a.Wo;
       for (int t2 = 0; t2 < T; ++t2) {
         const int ky = t2 / a.KW, kx = t2 % a.KW;
         const int sy = oy * a.mul + a.off0 + ky * a.kstep, sx = ox * a.mul + a.off0 + kx * a.kstep;
-        if (sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi) mk |= 1 << t2;
+        if (sy >= 0 && sx >= 0 && sy % up == 0 && sx % up == 0 && sy / up < a.Hi && sx / up < a.Wi) mk |= 1 << t2;
       }
     }
     int nv = 0;

@@ -237,7 +237,9 @@ int upload_resize(eosvos_engine* e, const HostResize& h, int in, int out, Resize
 // padding for every pixel of the tile.  Tables are built once per (conv, pass, batch).
 void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
   const ConvL& c = e->t.convs[ci];
-  if (c.k != 3 || c.dil < 2 || a.upshift != 0) return;
+  const bool dilated = c.k == 3 && c.dil >= 2 && a.upshift == 0;
+  const bool s2_dgrad = c.k == 3 && kind == 1 && a.upshift == 1 && !a.dst_up;    // 2.25 of 9 taps per pixel on average
+  if (!dilated && !s2_dgrad) return;
   const int bn = (a.N > 64) ? 128 : 64;
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   if (tiles > 1024) return;                       // keep the partial-tile slab count bounded
@@ -245,7 +247,9 @@ void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
   auto it = e->tap_tabs.find(key);
   if (it == e->tap_tabs.end()) {
     std::vector<int> prefix, mask;
-    const long total = conv_build_tap_table(a, prefix, mask);
+    ConvArgs probe = a;
+    probe.par = s2_dgrad ? 1 : 0;
+    const long total = conv_build_tap_table(probe, prefix, mask);
     eosvos_engine::TapTab tt{nullptr, nullptr, total};
     tt.prefix = (int*)e->falloc((int64_t)prefix.size());
     tt.mask = (int*)e->falloc((int64_t)mask.size());
@@ -256,6 +260,7 @@ void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
   }
   if (it->second.total >= tiles * (long)c.T() * ((a.Kc + 31) / 32)) return;   // nothing to skip
   a.tprefix = it->second.prefix; a.tmask = it->second.mask; a.total_units = it->second.total;
+  a.par = s2_dgrad ? 1 : 0;
 }
 
 int ksteps_of(int T, int kc) { return T * ((kc + 31) / 32); }

@@ -41,12 +41,34 @@ struct ConvArgs {
   int ldmask, mask_c0;
   int relu;
   int accum;            // dgrad: add the existing contents of y
+  int par;              // 1: GEMM rows enumerate the Ho x Wo grid parity class by parity class (stride-2 3x3 dgrad)
   int dst_up, Hf, Wf;   // dst_up=1: GEMM row (b,oy,ox) is written to pixel (b,2oy,2ox) of an Hf x Wf grid
   const int* tprefix;   // optional (device): compacted K-step prefix per tile (tiles+1), see conv_build_tap_table
   const int* tmask;     // optional (device): valid-tap bit mask per tile
   long total_units;     // sum of valid K steps when tprefix is set, else 0
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
 };
+// Parity-major row order of a stride-2 data gradient: rows [0, M) walk the (even,even) output pixels of all
+// images, then (even,odd), (odd,even), (odd,odd).  A pixel of parity (py,px) only receives the filter taps with
+// ky = (py+pad) mod 2, kx likewise: 1, 2, 2 or 4 of the 9 taps of a 3x3 kernel, so tiles that are pure in parity
+// skip the other taps through the per-tile tap table.  Returns the ordinary index (b*Ho + oy)*Wo + ox.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int conv_par_pixel(int B, int Ho, int Wo, int m) {
+  const int He = (Ho + 1) >> 1, Hod = Ho >> 1, We = (Wo + 1) >> 1, Wod = Wo >> 1;
+  const int n00 = B * He * We, n01 = B * He * Wod, n10 = B * Hod * We;
+  int py, px, r = m;
+  if (r < n00) { py = 0; px = 0; }
+  else if ((r -= n00) < n01) { py = 0; px = 1; }
+  else if ((r -= n01) < n10) { py = 1; px = 0; }
+  else { r -= n10; py = 1; px = 1; }
+  const int Hc = py ? Hod : He, Wc = px ? Wod : We;
+  const int nc = Hc * Wc;
+  const int b = r / nc, rr = r - b * nc;
+  const int cy = rr / Wc, cx = rr - cy * Wc;
+  return (b * Ho + 2 * cy + py) * Wo + 2 * cx + px;
+}
 // fills a.per, launches the stream-K kernel (+ the fix-up kernel when tiles are shared)
 void launch_conv(ConvArgs& a, hipStream_t s);
 int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
