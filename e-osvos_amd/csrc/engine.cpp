@@ -238,7 +238,11 @@ int upload_resize(eosvos_engine* e, const HostResize& h, int in, int out, Resize
 void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
   const ConvL& c = e->t.convs[ci];
   const bool dilated = c.k == 3 && c.dil >= 2 && a.upshift == 0;
+#ifdef EOSVOS_NO_PARITY            // A/B switch (tools/build_variant.sh)
+  const bool s2_dgrad = false;
+#else
   const bool s2_dgrad = c.k == 3 && kind == 1 && a.upshift == 1 && !a.dst_up;    // 2.25 of 9 taps per pixel on average
+#endif
   if (!dilated && !s2_dgrad) return;
   const int bn = (a.N > 64) ? 128 : 64;
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
