@@ -747,8 +747,11 @@ static int wg_tile(int c) {
   const int padded = (c + 127) / 128 * 128;
   return (padded - c) * 100 > 15 * c ? 64 : 128;
 }
+#ifndef EOSVOS_WG_SMALLP
+#define EOSVOS_WG_SMALLP 2500        // pixel count below which 64x64 tiles are used (more tiles, fewer K splits)
+#endif
 int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
-  const int bm = wg_tile(Cout), bn = wg_tile(Cin);
+  const int bm = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(Cout), bn = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(Cin);
   const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
   const int steps = (P + 31) / 32;
   // pick the K split so that tiles*S fills whole rounds of the 512 resident workgroups
@@ -765,7 +768,8 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-  const int bm = wg_tile(a.Cout), bn = wg_tile(a.Cin);
+  const int P = a.B * a.Ho * a.Wo;
+  const int bm = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(a.Cout), bn = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(a.Cin);
   const int T = a.KH * a.KW;
   const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * T;
   const dim3 grid(tiles * a.splits), block(256);
