@@ -10,7 +10,9 @@ frames that are already resident in HBM.  Each rank fine-tunes its own (sequence
 replica -- evaluation shards by (sequence, object) with no collective -- so
 scaling is weak and `value` = fine-tune iterations/s summed over ranks.
 `extra.meta_tasks_per_sec` reports the meta-train metric (K=5 inner steps + meta frame,
-B=1, RCCL all-reduce of the 161 MB meta-gradient + fused RAdam at N > 1).
+B=1, RCCL all-reduce of the 161 MB meta-gradient + fused RAdam at N > 1);
+`--metric meta` makes that the headline of the JSON line instead (BASELINE configs[3..4]:
+one task per rank per meta-iteration, a step = one meta-iteration).
 
 Prints ONE JSON line on rank 0.
 """
@@ -57,6 +59,51 @@ def cpu_baseline(sd, lrs, x, y, seconds_budget=25.0):
                       f'iterations/s)'}
 
 
+def bench_meta(a, eng, dist, rank, world, sd, lrs, xg, yg, barrier, dev):
+    """meta-tasks/s: every rank runs one task (5 inner steps at batch 1 + the meta frame) per meta-iteration, then
+    ONE all-reduce of the 161 MB meta-gradient and the fused RAdam step + lr clamp on every rank."""
+    from eosvos_amd.meta_run import MetaTrainer
+    mt = MetaTrainer(eng, dist=dist, meta_batch_size=world)
+    mt.load_state(sd, lrs)
+    x1, y1 = xg[:1].contiguous(), yg[:1].contiguous()
+    xm, ym = torch.flip(x1, dims=[3]).contiguous(), torch.flip(y1, dims=[3]).contiguous()
+    for _ in range(a.warmup):
+        mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k_ms, k_flops = eng.time_hot_kernel(1, reps=20)
+    achieved = k_flops / (k_ms * 1e-3) / 1e12
+    if rank == 0:
+        out = {
+            'metric': 'meta_tasks_per_sec', 'value': world * a.steps / dt, 'unit': 'meta_tasks/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'meta-train iteration (BASELINE configs[3..4]): meta_batch_size = number of ranks, one '
+                                   f'task per rank = 5 inner fine-tune steps + 1 meta frame at batch 1, {H}x{W}, BCE; one '
+                                   'all-reduce(sum) of the 40.3 M-float meta-gradient, RAdam + lr clamp on every rank',
+                       'meta_batch_size': world, 'inner_steps': 5, 'height': H, 'width': W,
+                       'parallelism': f'tasks sharded x{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false> (decoder.last_conv.0 forward, batch 1)',
+                         'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP32_MATRIX_PEAK, 'traffic': None, 'kernel_ms': k_ms,
+                         'flops_per_launch': k_flops,
+                         'whole_step_tflops': 6 * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12},
+            'cpu_baseline': None, 'extra': {'last_meta_loss': losses[-1]},
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -64,6 +111,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meta', action='store_true')
+    ap.add_argument('--metric', choices=['finetune', 'meta'], default='finetune',
+                    help="'meta': the JSON line reports meta-tasks/s (BASELINE configs[3..4]: one task per rank per "
+                         "meta-iteration, all-reduce + RAdam included); a step is then one meta-iteration")
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -95,6 +145,9 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if a.metric == 'meta':
+        return bench_meta(a, eng, dist, rank, world, sd, lrs, xg, yg, barrier, dev)
 
     for _ in range(a.warmup):
         eng.finetune_step(xg, yg, sync_loss=False)
