@@ -53,6 +53,8 @@ _SIGNATURES = {
     'eosvos_meta_task_begin': (ctypes.c_int, [_E]),
     'eosvos_meta_grad': (ctypes.c_int, [_E, c_float_p, c_float_p, ctypes.c_int, c_float_p,
                                         ctypes.POINTER(ctypes.c_float)]),
+    'eosvos_meta_grad_ex': (ctypes.c_int, [_E, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                           ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.c_int]),
     'eosvos_radam_step': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int64,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, ctypes.c_int, ctypes.c_float, ctypes.c_float]),

@@ -1062,6 +1062,10 @@ int eosvos_meta_task_begin(eosvos_engine* e) {
 }
 int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, int batch, float* flat_meta_grad,
                      float* meta_loss_host) {
+  return eosvos_meta_grad_ex(e, images, masks, batch, flat_meta_grad, meta_loss_host, 1.f, EOSVOS_META_INIT_GRAD);
+}
+int eosvos_meta_grad_ex(eosvos_engine* e, const float* images, const float* masks, int batch, float* flat_meta_grad,
+                        float* meta_loss_host, float weight, int flags) {
   if (!e || !images || !masks || !flat_meta_grad) return fail("null argument");
   if (!e->gsum) return fail("eosvos_meta_grad without eosvos_meta_task_begin");
   if (eosvos_forward(e, images, batch, nullptr)) return 1;
@@ -1075,7 +1079,7 @@ int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, 
   const int64_t nstore = lr_store_count(t, e->lr_level);
   if (e->lr_level == EOSVOS_LR_PARAM) {
     launch_meta_lr_grad_elem(e->gsum, e->gout, e->lr_log ? e->lr_elem : nullptr, e->ptmp, t.nparam, e->s);
-    export_params(e, e->ptmp, flat_meta_grad, 1.f, 1);
+    export_params(e, e->ptmp, flat_meta_grad, weight, 1);
   } else {
     // per-neuron d/d lr first (into the caller's buffer directly when that is the stored level)
     const bool direct = e->lr_level == EOSVOS_LR_NEURON && !e->lr_log;
@@ -1085,10 +1089,10 @@ int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, 
       HIPOK(hipMemsetAsync(e->glr_tmp, 0, (size_t)t.nlr * 4, e->s));
     }
     for (const ConvL& c : t.convs) {
-      launch_meta_lr_grad(e->gsum + c.poff, e->gout + c.poff, gl + c.lroff, c.cout, (int64_t)c.T() * c.cin, e->s);
+      launch_meta_lr_grad(e->gsum + c.poff, e->gout + c.poff, gl + c.lroff, c.cout, (int64_t)c.T() * c.cin, weight, e->s);
       if (c.bias)
         launch_meta_lr_grad(e->gsum + c.poff + c.wsize(), e->gout + c.poff + c.wsize(), gl + c.lroff + c.cout,
-                            c.cout, 1, e->s);
+                            c.cout, 1, weight, e->s);
     }
     if (e->lr_level == EOSVOS_LR_NEURON) {
       if (!direct) launch_lr_grad_neuron(gl, e->lr, flat_meta_grad, (int)t.nlr, e->lr_log, e->s);
@@ -1098,7 +1102,9 @@ int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, 
       launch_lr_grad_reduce(gl, e->lr, e->all_row0, flat_meta_grad, 1, e->lr_log, e->s);
     }
   }
-  export_params(e, e->gout, flat_meta_grad + nstore, 1.f, 1);
+  if (flags & EOSVOS_META_INIT_GRAD) export_params(e, e->gout, flat_meta_grad + nstore, weight, 1);
+  // truncated BPTT: the next segment starts from detached parameters (meta_optim.reset(keep_state=True))
+  if (flags & EOSVOS_META_NEW_SEGMENT) HIPOK(hipMemsetAsync(e->gsum, 0, (size_t)t.nparam * 4, e->s));
   HIPOK(hipGetLastError());
   if (meta_loss_host) {
     HIPOK(hipMemcpyAsync(meta_loss_host, e->loss_dev, 4, hipMemcpyDeviceToHost, e->s));

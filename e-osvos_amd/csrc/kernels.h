@@ -201,7 +201,7 @@ void launch_lr_grad_neuron(const float* g, const float* lr, float* out, int n, i
 void launch_meta_lr_grad_elem(const float* gsum, const float* G, const float* lr_elem, float* out, int64_t n,
                               hipStream_t s);
 // g_lr[c] += -sum_row(gsum*G) ;  (G itself is exported by launch_ohwi_to_oihw with add=1)
-void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen,
+void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen, float weight,
                          hipStream_t s);
 void launch_radam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float wd,
                   float beta1, float beta2, float eps, float step_size, int use_denom,

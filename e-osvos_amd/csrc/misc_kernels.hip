@@ -724,17 +724,17 @@ void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, cons
 // one block per row: glr[row] += -sum_e gsum[row][e] * G[row][e]
 __global__ __launch_bounds__(256) void meta_lr_grad_kernel(const float* __restrict__ gsum,
                                                             const float* __restrict__ G, float* __restrict__ glr,
-                                                            long rowlen) {
+                                                            long rowlen, float weight) {
   __shared__ float sh[4];
   const long base = (long)blockIdx.x * rowlen;
   float s = 0.f;
   for (long e = threadIdx.x; e < rowlen; e += 256) s = fmaf(gsum[base + e], G[base + e], s);
   s = block_sum_256(s, sh);
-  if (threadIdx.x == 0) glr[blockIdx.x] -= s;
+  if (threadIdx.x == 0) glr[blockIdx.x] -= weight * s;
 }
-void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen,
+void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen, float weight,
                          hipStream_t s) {
-  hipLaunchKernelGGL(meta_lr_grad_kernel, dim3(rows), dim3(256), 0, s, gsum, G, glr, (long)rowlen);
+  hipLaunchKernelGGL(meta_lr_grad_kernel, dim3(rows), dim3(256), 0, s, gsum, G, glr, (long)rowlen, weight);
 }
 
 // ---- RAdam (radam.py:28-94) -----------------------------------------------------------------------------

@@ -208,12 +208,15 @@ class Engine:
     def meta_task_begin(self):
         _ffi.check(self.lib.eosvos_meta_task_begin(self.h))
 
-    def meta_grad(self, images, masks, flat_meta_grad):
+    def meta_grad(self, images, masks, flat_meta_grad, weight=1.0, init_grad=True, new_segment=False):
+        """ADDS weight * task meta-gradient into flat_meta_grad ([lr state | init]); returns the meta loss.
+        weight / init_grad / new_segment: `multi_step_bptt_loss` and truncated BPTT (include/eosvos.h)."""
         b = self._check_images(images)
         assert flat_meta_grad.numel() == self.n_lr_store + self.n_param and flat_meta_grad.is_cuda
         l = ctypes.c_float()
-        _ffi.check(self.lib.eosvos_meta_grad(self.h, _ptr(images), _ptr(masks), b, _ptr(flat_meta_grad),
-                                             ctypes.byref(l)))
+        flags = (1 if init_grad else 0) | (2 if new_segment else 0)
+        _ffi.check(self.lib.eosvos_meta_grad_ex(self.h, _ptr(images), _ptr(masks), b, _ptr(flat_meta_grad),
+                                                ctypes.byref(l), float(weight), flags))
         return l.value
 
     def radam_step(self, param, grad, exp_avg, exp_avg_sq, lr, weight_decay, step, grad_scale=1.0,

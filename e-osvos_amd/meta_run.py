@@ -27,6 +27,7 @@ class MetaTrainer:
         self.level, self.use_log = lr_hierarchy_level, bool(use_log_init_lr)
         self.n_lr = engine.lr_store_count(lr_hierarchy_level)        # NotImplementedError for unknown levels
         engine.set_loss(loss_func)
+        self.loss_func = loss_func
         self.dist = dist
         self.meta_batch_size = meta_batch_size
         self.model_init_lr, self.log_init_lr_lr = model_init_lr, log_init_lr_lr
@@ -78,16 +79,42 @@ class MetaTrainer:
         self.eng.set_init(self.state[self.n_lr:])
 
     # ---- one task ---------------------------------------------------------------------
-    def run_task(self, x_train, y_train, x_meta, y_meta, inner_steps=5):
-        """Returns (train losses or None, meta loss).  Adds the task's meta-gradient into
-        self.grad unless the meta loss is NaN (meta_run.py:209-211,226: skipped tasks
-        contribute zeros but the average still divides by meta_batch_size)."""
+    def run_task(self, x_train, y_train, x_meta, y_meta, inner_steps=5, bptt_epochs=None, multi_step_bptt_loss=None):
+        """Returns the (last) meta loss.  Adds the task's meta-gradient into self.grad unless a meta loss is NaN
+        (meta_run.py:209-211,226: skipped tasks contribute zeros but the average still divides by
+        meta_batch_size).  `bptt_epochs` < inner_steps = truncated BPTT (`:187-221`): every bptt_epochs steps the
+        meta frame is back-propagated and `meta_optim.reset(keep_state=True)` detaches the parameters AND the
+        state lr (`meta_optim.py:145-151`), so only the first segment leaves gradients on the learned init / lr;
+        the later segments are still run (inner steps, meta loss, NaN check) but need no backward here.
+        `multi_step_bptt_loss` = per-step weights of the meta loss (`:154-177`)."""
         eng = self.eng
+        if multi_step_bptt_loss:
+            assert inner_steps == len(multi_step_bptt_loss)             # meta_run.py:156
+        bptt = bptt_epochs or inner_steps
         eng.meta_task_begin()
-        for _ in range(inner_steps):
-            eng.finetune_step(x_train, y_train, accumulate=True, sync_loss=False)
         self.task_grad.zero_()
-        meta_loss = eng.meta_grad(x_meta, y_meta, self.task_grad)
+        first_segment, meta_loss = True, float('nan')
+
+        def meta_frame(weight, boundary):
+            if first_segment:
+                return eng.meta_grad(x_meta, y_meta, self.task_grad, weight=weight, init_grad=True, new_segment=boundary)
+            eng.forward(x_meta, want_logits=False)                     # detached segment: loss value only
+            return float(eng.loss(self.loss_func, y_meta))
+
+        if inner_steps == 0:                                           # meta frame at the learned init only
+            meta_loss = meta_frame(1.0, True)
+        for epoch in range(1, inner_steps + 1):
+            eng.finetune_step(x_train, y_train, accumulate=first_segment, sync_loss=False)
+            boundary = epoch % bptt == 0 or epoch == inner_steps
+            evaluated = bool(multi_step_bptt_loss) or boundary
+            if multi_step_bptt_loss:
+                meta_loss = meta_frame(multi_step_bptt_loss[epoch - 1], boundary)
+            elif boundary:
+                meta_loss = meta_frame(1.0, True)
+            if evaluated and math.isnan(meta_loss):
+                break
+            if boundary:
+                first_segment = False
         if math.isnan(meta_loss):
             self.skipped_tasks += 1
         else:
@@ -95,9 +122,10 @@ class MetaTrainer:
         return meta_loss
 
     # ---- one meta-iteration --------------------------------------------------------------
-    def meta_iteration(self, local_tasks, inner_steps=5):
+    def meta_iteration(self, local_tasks, inner_steps=5, bptt_epochs=None, multi_step_bptt_loss=None):
         """local_tasks: this rank's share of the meta-batch: [(x_train, y_train, x_meta, y_meta)]."""
-        losses = [self.run_task(*t, inner_steps=inner_steps) for t in local_tasks]
+        losses = [self.run_task(*t, inner_steps=inner_steps, bptt_epochs=bptt_epochs,
+                                multi_step_bptt_loss=multi_step_bptt_loss) for t in local_tasks]
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
             self.dist.all_reduce(self.grad)             # sum over ranks, one 161 MB message
         self.outer_step()

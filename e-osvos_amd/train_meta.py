@@ -95,7 +95,8 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2):
             x, y = synthetic.synthetic_frames(1, height, width, seed=1000 + t + cfg['meta_batch_size'] * (meta_iter + it))
             xg, yg = x.to(dev), y.to(dev)
             tasks.append((xg, yg, torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()))
-        losses = mt.meta_iteration(tasks, inner_steps=cfg['num_epochs']['train'])
+        losses = mt.meta_iteration(tasks, inner_steps=cfg['num_epochs']['train'], bptt_epochs=cfg['bptt_epochs'],
+                                   multi_step_bptt_loss=cfg['multi_step_bptt_loss'] or None)
         if rank == 0:
             print(json.dumps({'mode': 'meta', 'meta_iter': meta_iter + it + 1, 'meta_losses': losses,
                               'skipped_tasks': mt.skipped_tasks}))

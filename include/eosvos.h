@@ -171,6 +171,20 @@ int eosvos_meta_task_begin(eosvos_engine* e);
  * model_init_*).  meta_loss_host may be NULL. */
 int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, int batch,
                      float* flat_meta_grad, float* meta_loss_host);
+/* The same with the other BPTT schedules of meta_run.py:154-221:
+ *  - `multi_step_bptt_loss` (cfgs/meta.yaml:19): the meta loss is evaluated after EVERY inner step and
+ *    weighted: call after step e with weight = multi_step_bptt_loss[e-1] (`:154-177`);
+ *  - `bptt_epochs` < num_epochs.train (truncated BPTT, `:187-221`): `meta_optim.reset(keep_state=True)`
+ *    detaches the parameters and the state lr (meta_optim.py:145-151), so in the reference only the
+ *    FIRST segment leaves gradients on the learned init / lr: call this for the first segment's meta
+ *    frames only and evaluate the later ones with eosvos_forward + eosvos_loss.
+ * ADDS weight * [d/d lr-state | d/d init (if INIT_GRAD)] into flat_meta_grad; NEW_SEGMENT zeroes
+ * sum_k g_k afterwards (theta is kept): the next call then differentiates through the steps taken
+ * since -- a segment-wise variant that keeps learning the lr in every segment. */
+#define EOSVOS_META_INIT_GRAD 1
+#define EOSVOS_META_NEW_SEGMENT 2
+int eosvos_meta_grad_ex(eosvos_engine* e, const float* images, const float* masks, int batch,
+                        float* flat_meta_grad, float* meta_loss_host, float weight, int flags);
 
 /* ---- outer step (train_meta.py:361-373, radam.py:28-94, meta_optim.py:116-133) ------ */
 /* One RAdam step on n contiguous floats that share (lr, weight_decay):

@@ -13,6 +13,7 @@
                          d/d init = G,  d/d lr[c] = -sum_{cin,kh,kw}(sum_k g_k * G).
   * `meta_task_hier` : the same for `lr_hierarchy_level` SINGLE / TENSOR / NEURON / PARAM and
                        `use_log_init_lr` (`meta_optim.py:27-67,157-163,180-185`).
+  * `meta_task_bptt` : truncated / multi-step BPTT schedules (`meta_run.py:154-221`).
   * `radam_step`     : `RAdam.step`, `src/util/radam.py:28-94`, per-tensor groups as
                        built at `src/train_meta.py:110-127`.
   * `outer_step`     : average / clip / RAdam / clamp, `src/train_meta.py:361-373` and
@@ -133,6 +134,53 @@ def meta_task(P0, lrs, train_batches, meta_batch, encoder='resnet50', norm='bn',
             prod = prod.sum(dim=tuple(range(1, prod.dim())), keepdim=True)
         g_lr.append(prod.reshape(lr.shape))
     return dict(meta_loss=float(meta_loss), train_losses=train_losses, g_init=G, g_lr=g_lr)
+
+
+def meta_task_bptt(P0, lrs, train_batches, meta_batch, bptt_epochs=None, multi_step_bptt_loss=None,
+                   encoder='resnet50', norm='bn', loss_name='cross_entropy'):
+    """The BPTT schedules of `src/util/meta_run.py:154-221` with first-order gradients: the meta loss is
+    back-propagated every `bptt_epochs` steps (and at the last step) and the state is then detached
+    (`meta_optim.reset(keep_state=True)`, `meta_optim.py:145-151`): that detaches the parameters
+    (`meta_model.py:62-65`) AND the state lr (`state['log_lr'] = [l.detach() ...]`), so only the FIRST segment,
+    theta_e = init - lr * sum_{k<=e} g_k, reaches the learned init and the learned lr; the later segments'
+    backward passes leave no gradient on the meta-optimizer (their losses are still evaluated, NaN-checked and
+    reported).  `multi_step_bptt_loss` weights a meta loss evaluated after every step (`:154-177`).
+    Returns dict(meta_losses, g_init, g_lr)."""
+    names = trainable_names(encoder)
+    K = len(train_batches)
+    bptt = bptt_epochs or K
+    xm, ym = meta_batch
+    P = P0
+    gsum = None
+    g_init = [torch.zeros_like(P0[n]) for n in names]
+    g_lr = [torch.zeros_like(lr) for lr in lrs]
+    meta_losses = []
+    first_segment = True
+
+    def add(weight):
+        ml, G, _ = loss_and_grads(P, xm, ym, encoder, norm, loss_name)
+        meta_losses.append(float(ml))
+        if not first_segment:
+            return
+        for i, (s_, g, lr) in enumerate(zip(gsum, G, lrs)):
+            prod = -(s_ * g) * weight
+            if prod.dim() > 1:
+                prod = prod.sum(dim=tuple(range(1, prod.dim())), keepdim=True)
+            g_lr[i] += prod.reshape(lr.shape)
+            g_init[i] += weight * g
+
+    for epoch, (x, y) in enumerate(train_batches, start=1):
+        _, grads, P = finetune_step(P, lrs, x, y, encoder, norm, loss_name)
+        gsum = [g.clone() for g in grads] if gsum is None else [a + g for a, g in zip(gsum, grads)]
+        boundary = epoch % bptt == 0 or epoch == K
+        if multi_step_bptt_loss:
+            add(multi_step_bptt_loss[epoch - 1])
+        elif boundary:
+            add(1.0)
+        if boundary:
+            first_segment = False
+            gsum = None
+    return dict(meta_losses=meta_losses, g_init=g_init, g_lr=g_lr)
 
 
 def radam_scalars(step, beta1=0.9, beta2=0.999):

@@ -515,3 +515,31 @@ def test_edge_cases_and_error_behaviour(small_engine, weights):
     # the engine is still usable after the failed calls
     assert np.isfinite(eng.finetune_step(xg, torch.zeros(2, 1, *SMALL, device=DEV)))
     eng.load_model_state(*weights)
+
+
+@pytest.mark.parametrize('tag,bptt,multi', [('trunc', 2, None), ('multi', 4, [0.1, 0.2, 0.3, 0.4]),
+                                            ('both', 2, [0.1, 0.2, 0.3, 0.4])])
+def test_bptt_schedules_vs_golden(small_engine, weights, golden_dir, tag, bptt, multi):
+    """MetaTrainer.run_task with `bptt_epochs` < inner steps and `multi_step_bptt_loss` (eosvos_meta_grad_ex) vs the
+    reference's autograd through meta_optim.reset(keep_state=True) (fixture G14, meta_run.py:154-221)."""
+    from eosvos_amd.meta_run import MetaTrainer
+    g = np.load(os.path.join(golden_dir, 'g14_bptt.npz'))
+    eng = small_engine
+    mt = MetaTrainer(eng, meta_batch_size=1)
+    mt.load_state(*weights)
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1404)
+    xg, yg = x.to(DEV), y.to(DEV)
+    xm, ym = torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()
+    ml = mt.run_task(xg, yg, xm, ym, inner_steps=4, bptt_epochs=bptt, multi_step_bptt_loss=multi)
+    assert abs(ml - g[tag + '_meta_losses'][-1]) <= 5e-4 * abs(g[tag + '_meta_losses'][-1])
+    flat = mt.grad.cpu()
+    ref = g[tag + '_lr_grad']
+    got = flat[:eng.n_lr].numpy()
+    assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    tr = topology.trainable('resnet50')
+    offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr]) + eng.n_lr
+    for i, (n, s) in enumerate(tr):
+        l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
+        r = g[tag + '_init_grad_fp'][i][1]
+        assert abs(l2 - r) <= 1e-2 * r + 1e-9, (n, l2, r)
+    eng.load_model_state(*weights)

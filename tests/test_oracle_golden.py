@@ -233,3 +233,22 @@ def test_g13_lr_hierarchy(golden_dir, level, use_log):
         assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
     for a, b in zip(np.stack([fp(t) for t in out['g_init']]), g[tag + '_init_grad_fp']):
         fp_close(a, b, rtol=2e-3)
+
+
+@pytest.mark.parametrize('tag,bptt,multi', [('trunc', 2, None), ('multi', 4, [0.1, 0.2, 0.3, 0.4]),
+                                            ('both', 2, [0.1, 0.2, 0.3, 0.4])])
+def test_g14_bptt_schedules(golden_dir, tag, bptt, multi):
+    """Truncated and multi-step BPTT (meta_run.py:154-221) vs the reference's autograd (fixture G14)."""
+    g = np.load(os.path.join(golden_dir, 'g14_bptt.npz'))
+    sd, lrs = _meta_inputs()
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1404)
+    xm, ym = torch.flip(x, dims=[3]), torch.flip(y, dims=[3])
+    out = meta.meta_task_bptt(sd, lrs, [(x, y)] * 4, (xm, ym), bptt_epochs=bptt, multi_step_bptt_loss=multi)
+    np.testing.assert_allclose(out['meta_losses'], g[tag + '_meta_losses'], rtol=2e-4)
+    lr_g = torch.cat([t.flatten() for t in out['g_lr']]).numpy()
+    ref = g[tag + '_lr_grad']
+    assert np.abs(lr_g - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(lr_g - ref).max() / np.abs(ref).max()
+    for a, b in zip(np.stack([fp(t) for t in out['g_init']]), g[tag + '_init_grad_fp']):
+        fp_close(a, b, rtol=2e-3)
+    ref_last = g[tag + '_init_grad_last']
+    assert np.abs(out['g_init'][-2].numpy() - ref_last).max() <= 2e-3 * np.abs(ref_last).max()
