@@ -160,7 +160,7 @@ class FakeEngine:
     def set_init(self, t): self.init = t.clone()
     def meta_task_begin(self): pass
     def finetune_step(self, *a, **k): pass
-    def meta_grad(self, xm, ym, flat):
+    def meta_grad(self, xm, ym, flat, weight=1.0, init_grad=True, new_segment=False):
         flat += self.task_vec
         return float(self.task_loss)
     def radam_step(self, p, g, m, v, lr, wd, step, grad_scale=1.0, grad_clip=0.0):
