@@ -51,9 +51,8 @@ class MetaOptimizer:
             raise NotImplementedError                   # meta_optim.py:68-69
         if second_order_gradients:
             raise NotImplementedError('second_order_gradients=True needs double backward')
-        if not learn_model_init:
-            raise NotImplementedError('learn_model_init=False')
         self._max_lr = max_lr
+        self._learn_model_init = bool(learn_model_init)
         self._lr_hierarchy_level = lr_hierarchy_level
         self._use_log_init_lr = bool(use_log_init_lr)
         self.training = True
@@ -86,7 +85,10 @@ class MetaOptimizer:
             self._lr_flat.log_()
         self._init_views = OrderedDict(('model_init_' + n.replace('.', '-'), model._views[n]) for n in names)
         self._params = OrderedDict()
-        for k, v in list(self._lr_views.items()) + list(self._init_views.items()):
+        # learn_model_init False: the init tensors are not registered parameters (meta_optim.py:76-78): they keep
+        # the model's weights, receive no meta-gradient and do not appear in state_dict()
+        learned = list(self._lr_views.items()) + (list(self._init_views.items()) if self._learn_model_init else [])
+        for k, v in learned:
             self._params[k] = _Param(k, v, True)
         self._grad_flat = None
         model._lr_flat = self._lr_flat

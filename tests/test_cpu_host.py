@@ -120,7 +120,19 @@ def test_meta_optimizer_hierarchy_layout(golden_dir, level, use_log):
                       lr_hierarchy_level='LAYER', use_log_init_lr=False, max_lr=None)
 
 
-def test_checkpoint_layout_compatible(golden_dir):
+def test_meta_optimizer_without_learned_init(golden_dir):
+    """`learn_model_init: False` registers only the lr tensors (meta_optim.py:76-78), fixture G13."""
+    from eosvos_amd.meta_optim import MetaOptimizer
+    from eosvos_amd.networks import DeepLabV3Plus
+    g = np.load(os.path.join(golden_dir, 'g13_lr_hierarchy.npz'))
+    model = DeepLabV3Plus('resnet50', num_classes=1,
+                          batch_norm={'accum_stats': False, 'learn_weight': False, 'learn_bias': False})
+    mo = MetaOptimizer(model, init_lr=1e-3, learn_model_init=False, second_order_gradients=False,
+                       lr_hierarchy_level='NEURON', use_log_init_lr=False, max_lr=None)
+    assert [f'{k}:{tuple(v.shape)}' for k, v in mo.state_dict().items()] == list(g['nolearn_keys'])
+    assert [n for n, _ in mo.named_parameters()] == list(g['nolearn_named'])
+
+
     """A `.model` file written by the reference's MetaOptimizer.state_dict() layout loads, and
     our state dict has the same key structure (train_meta.py:277-286)."""
     ck = torch.load(os.path.join(golden_dir, 'g11_last_meta_iter.model'), weights_only=False)
