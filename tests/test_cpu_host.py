@@ -133,6 +133,7 @@ def test_meta_optimizer_without_learned_init(golden_dir):
     assert [n for n, _ in mo.named_parameters()] == list(g['nolearn_named'])
 
 
+def test_checkpoint_layout_compatible(golden_dir):
     """A `.model` file written by the reference's MetaOptimizer.state_dict() layout loads, and
     our state dict has the same key structure (train_meta.py:277-286)."""
     ck = torch.load(os.path.join(golden_dir, 'g11_last_meta_iter.model'), weights_only=False)
