@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
     int tile, ks_begin, ks_end = ksteps;
     const bool dp = dp_i < p.dp_q;
     if (dp) {
-      tile = bid * p.dp_q + dp_i;
+      tile = dp_i * (int)gridDim.x + bid;      // neighbouring workgroups (one XCD) work on neighbouring tiles at the same time: shared operand rows meet in L2
       ks_begin = 0;
       ++dp_i;
       if (tile >= tiles) continue;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# PMC passes on the bench's roofline kernel (one counter group per pass, gpurun-safe: --pmc with --kernel-trace only)
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/pmc; mkdir -p $O
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python3 tools/hot_kernel.py > $O/$c.log 2>&1
+  python3 - <<PY
+import csv,glob
+f=glob.glob("$O/$c/**/*counter_collection.csv",recursive=True)[0]
+rows=[r for r in csv.DictReader(open(f)) if "conv_igemm_kernel<128, false>" in r["Kernel_Name"] and r["Counter_Name"]=="$c" and r["Grid_Size"]=="131072"]
+vals=[float(r["Counter_Value"]) for r in rows]
+print("$c (KB per launch, last 5 launches of the 512-WG forward kernel):", vals[-5:])
+PY
+done
