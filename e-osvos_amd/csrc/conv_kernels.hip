@@ -84,8 +84,11 @@ __device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, si
 // slabs (ws[wg][0|1][BM][BN]) and conv_fixup_kernel sums them in workgroup order
 // (deterministic) and applies the epilogue.  This removes the 59-78 % wave-quantisation loss
 // a tile-per-workgroup grid has on 256 CUs for this network's shapes.
-template <int BN, bool KMAJOR>
-__global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvArgs p) {
+// DEEP = 1: one LDS stage (two barriers per K step) and a smaller register budget so that 3 workgroups fit a
+// CU: 3 waves per SIMD keep the MFMA pipe busier on long-K, many-tile layers (decoder 3x3: +3-4 %) but lose
+// on short or small ones, so conv_plan selects it per launch (ConvArgs::deep).
+template <int BN, bool KMAJOR, int DEEP = 0>
+__global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int BM = 128, BK = EOSVOS_BK;
   constexpr int LDA = BK + 4;
   constexpr int LDB = KMAJOR ? BN + 4 : BK + 4;
@@ -93,10 +96,11 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
   constexpr int B_EL = KMAJOR ? BK * LDB : BN * LDB;
   constexpr int STAGE = A_EL + B_EL;
   constexpr int LDC = BN + 4;
-  constexpr int EPASS = (BM * LDC <= 2 * STAGE) ? 1 : 2;      // C-tile staging passes
+  constexpr int NBUF = DEEP ? 1 : 2;
+  constexpr int EPASS = (BM * LDC <= NBUF * STAGE) ? 1 : 2;      // C-tile staging passes
   constexpr int EROWS = BM / EPASS;
-  static_assert(EROWS * LDC <= 2 * STAGE, "epilogue staging must fit the operand buffers");
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  static_assert(EROWS * LDC <= NBUF * STAGE, "epilogue staging must fit the operand buffers");
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
     __syncthreads();
 
     for (int ks = ks_begin; ks < ks_end; ++ks) {
-      const int buf = (ks - ks_begin) & 1;
+      const int buf = NBUF == 2 ? (ks - ks_begin) & 1 : 0;
       const bool more = (ks + 1) < ks_end;
 #ifndef EOSVOS_LOAD_AT
       if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
@@ -312,7 +316,8 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
 #endif
       }
 #ifndef EOSVOS_STORE_AT
-      if (more) store_tiles(buf ^ 1);
+      if (NBUF == 1) __syncthreads();         // every wave is done reading the single stage
+      if (more) store_tiles(NBUF == 2 ? buf ^ 1 : 0);
 #endif
       __syncthreads();
     }
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256, EOSVOS_OCC) void conv_igemm_kernel(const ConvA
         if (n < p.N) {
           // All global operands of a batch of rows are requested before any is consumed: the epilogue of
           // the short-K layers is latency bound, and one dependent load per row left the HBM pipe empty.
-          constexpr int NIT = EROWS / CROWS, EB = EOSVOS_EB;
+          constexpr int NIT = EROWS / CROWS, EB = DEEP ? 1 : EOSVOS_EB;
 #pragma unroll
           for (int it0 = 0; it0 < NIT; it0 += EB) {
             size_t md[EB];
@@ -515,7 +520,8 @@ long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vect
 }
 
 #define CONV_MAX_WG (256 * EOSVOS_OCC)
-int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG * 2 * 128 * 128; }
+#define CONV_MAX_WG_DEEP (256 * 3)
+int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG_DEEP * 2 * 128 * 128; }
 
 // returns the number of workgroups; fills a.dp_q / a.per / a.nwg.
 //   tiles >= 512: each workgroup takes dp_q = tiles/512 whole tiles (no workspace traffic) and
@@ -526,7 +532,13 @@ int conv_plan(ConvArgs& a) {
   const int T = a.KH * a.KW;
   const long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
-  long nwg = CONV_MAX_WG, q = 0, per = 0;
+#ifndef EOSVOS_NO_DEEP
+  // 3-workgroups-per-CU kernel for long-K layers with many tiles (measured: decoder 3x3 fwd/dgrad at batch >= 2)
+  a.deep = (bn == 128 && tiles >= 1024 && ksteps >= 64 && a.total_units <= 0) ? 1 : 0;
+#else
+  a.deep = 0;
+#endif
+  long nwg = a.deep ? CONV_MAX_WG_DEEP : CONV_MAX_WG, q = 0, per = 0;
 #ifndef EOSVOS_DPK
 #define EOSVOS_DPK 0
 #endif
@@ -564,7 +576,10 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const int nwg = conv_plan(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   const dim3 grid(nwg), block(256);
-  if (a.kmajor) {
+  if (a.deep) {
+    if (a.kmajor) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, false, 1>), grid, block, 0, s, a);
+  } else if (a.kmajor) {
     if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, block, 0, s, a);
   } else {
