@@ -84,19 +84,21 @@ __device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, si
 // slabs (ws[wg][0|1][BM][BN]) and conv_fixup_kernel sums them in workgroup order
 // (deterministic) and applies the epilogue.  This removes the 59-78 % wave-quantisation loss
 // a tile-per-workgroup grid has on 256 CUs for this network's shapes.
-// DEEP = 1: one LDS stage (two barriers per K step) and a smaller register budget so that 3 workgroups fit a
-// CU: 3 waves per SIMD keep the MFMA pipe busier on long-K, many-tile layers (decoder 3x3: +3-4 %) but lose
-// on short or small ones, so conv_plan selects it per launch (ConvArgs::deep).
+// DEEP != 0: half the LDS and a smaller register budget so that 3 workgroups fit a CU -- 3 waves per SIMD keep
+// the MFMA pipe busier on long-K, many-tile launches (decoder 3x3: +3-5 %) but lose on short or small ones, so
+// conv_plan selects it per launch (ConvArgs::deep).  DEEP = 1: one LDS stage of K = 32 (two barriers per K
+// step); DEEP = 2: two stages of K = 16, for channel counts that are not a multiple of 32 (304: no padded step).
+#define EOSVOS_BK_DEEP 16
 template <int BN, bool KMAJOR, int DEEP = 0>
 __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(const ConvArgs p) {
-  constexpr int BM = 128, BK = EOSVOS_BK;
+  constexpr int BM = 128, BK = DEEP == 2 ? EOSVOS_BK_DEEP : EOSVOS_BK;
   constexpr int LDA = BK + 4;
   constexpr int LDB = KMAJOR ? BN + 4 : BK + 4;
   constexpr int A_EL = BM * LDA;
   constexpr int B_EL = KMAJOR ? BK * LDB : BN * LDB;
   constexpr int STAGE = A_EL + B_EL;
   constexpr int LDC = BN + 4;
-  constexpr int NBUF = DEEP ? 1 : 2;
+  constexpr int NBUF = DEEP == 1 ? 1 : 2;
   constexpr int EPASS = (BM * LDC <= NBUF * STAGE) ? 1 : 2;      // C-tile staging passes
   constexpr int EROWS = BM / EPASS;
   static_assert(EROWS * LDC <= NBUF * STAGE, "epilogue staging must fit the operand buffers");
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
         if (n < p.N) {
           // All global operands of a batch of rows are requested before any is consumed: the epilogue of
           // the short-K layers is latency bound, and one dependent load per row left the HBM pipe empty.
-          constexpr int NIT = EROWS / CROWS, EB = DEEP ? 1 : EOSVOS_EB;
+          constexpr int NIT = EROWS / CROWS, EB = DEEP == 1 ? 1 : (DEEP == 2 ? 2 : EOSVOS_EB);
 #pragma unroll
           for (int it0 = 0; it0 < NIT; it0 += EB) {
             size_t md[EB];
@@ -411,7 +413,8 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
 // Sum the parked partial tiles in workgroup order and apply the fused epilogue.
 template <int BN>
 __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
-  constexpr int BM = 128, BK = EOSVOS_BK;
+  constexpr int BM = 128;
+  const int BK = p.deep == 2 ? EOSVOS_BK_DEEP : EOSVOS_BK;
   const int T = p.KH * p.KW;
   const int ksteps = T * ((p.Kc + BK - 1) / BK);
   const int nt = (p.N + BN - 1) / BN;
@@ -530,14 +533,15 @@ int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG_DEEP * 2 * 128 * 128; }
 int conv_plan(ConvArgs& a) {
   const int bn = (a.N > 64) ? 128 : 64;
   const int T = a.KH * a.KW;
-  const long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
+  long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
 #ifndef EOSVOS_NO_DEEP
   // 3-workgroups-per-CU kernel for long-K layers with many tiles (measured: decoder 3x3 fwd/dgrad at batch >= 2)
-  a.deep = (bn == 128 && tiles >= 1024 && ksteps >= 64 && a.total_units <= 0) ? 1 : 0;
+  a.deep = (bn == 128 && tiles >= 1024 && ksteps >= 64 && a.total_units <= 0) ? ((a.Kc & 31) ? 2 : 1) : 0;
 #else
   a.deep = 0;
 #endif
+  if (a.deep == 2) ksteps = (long)T * ((a.Kc + EOSVOS_BK_DEEP - 1) / EOSVOS_BK_DEEP);
   long nwg = a.deep ? CONV_MAX_WG_DEEP : CONV_MAX_WG, q = 0, per = 0;
 #ifndef EOSVOS_DPK
 #define EOSVOS_DPK 0
@@ -576,9 +580,12 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const int nwg = conv_plan(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   const dim3 grid(nwg), block(256);
-  if (a.deep) {
+  if (a.deep == 1) {
     if (a.kmajor) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, false, 1>), grid, block, 0, s, a);
+  } else if (a.deep == 2) {
+    if (a.kmajor) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, false, 2>), grid, block, 0, s, a);
   } else if (a.kmajor) {
     if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, block, 0, s, a);
@@ -587,7 +594,8 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, block, 0, s, a);
   }
   const int T = a.KH * a.KW;
-  const long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
+  const int bk = a.deep == 2 ? EOSVOS_BK_DEEP : EOSVOS_BK;
+  const long ksteps = (long)T * ((a.Kc + bk - 1) / bk);
   const long sk_tiles = tiles - (long)a.dp_q * nwg;
   if (a.per > 0 && sk_tiles > 0 && (a.per % ksteps != 0 || a.tprefix)) {   // some tile is shared between workgroups
     if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);

@@ -46,7 +46,7 @@ struct ConvArgs {
   const int* tprefix;   // optional (device): compacted K-step prefix per tile (tiles+1), see conv_build_tap_table
   const int* tmask;     // optional (device): valid-tap bit mask per tile
   long total_units;     // sum of valid K steps when tprefix is set, else 0
-  int deep;             // set by conv_plan: 1 = the 3-workgroups-per-CU kernel variant
+  int deep;             // set by conv_plan: 1 / 2 = the 3-workgroups-per-CU kernel variants (K step 32 single stage / 16)
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
 };
 // Parity-major row order of a stride-2 data gradient: rows [0, M) walk the (even,even) output pixels of all
