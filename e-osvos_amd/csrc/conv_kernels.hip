@@ -89,6 +89,9 @@ __device__ __forceinline__ float4 conv_epilogue4(const ConvArgs& p, float4 v, si
 // conv_plan selects it per launch (ConvArgs::deep).  DEEP = 1: one LDS stage of K = 32 (two barriers per K
 // step); DEEP = 2: two stages of K = 16, for channel counts that are not a multiple of 32 (304: no padded step).
 #define EOSVOS_BK_DEEP 16
+#ifndef EOSVOS_DEEP_TILES
+#define EOSVOS_DEEP_TILES 1024
+#endif
 template <int BN, bool KMAJOR, int DEEP = 0>
 __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int BM = 128, BK = DEEP == 2 ? EOSVOS_BK_DEEP : EOSVOS_BK;
@@ -537,7 +540,7 @@ int conv_plan(ConvArgs& a) {
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
 #ifndef EOSVOS_NO_DEEP
   // 3-workgroups-per-CU kernel for long-K layers with many tiles (measured: decoder 3x3 fwd/dgrad at batch >= 2)
-  a.deep = (bn == 128 && tiles >= 1024 && ksteps >= 64 && a.total_units <= 0) ? ((a.Kc & 31) ? 2 : 1) : 0;
+  a.deep = (bn == 128 && tiles >= EOSVOS_DEEP_TILES && ksteps >= 64 && a.total_units <= 0) ? ((a.Kc & 31) ? 2 : 1) : 0;
 #else
   a.deep = 0;
 #endif
@@ -609,9 +612,15 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
 // so tiles are staged as [pixel][channel] rows and fragments are read with ds_read_b32
 // (consecutive lanes -> consecutive channels: conflict free).
 // ---------------------------------------------------------------------------------------
+#ifndef EOSVOS_WG_BKP
+#define EOSVOS_WG_BKP 32
+#endif
+#ifndef EOSVOS_WG_OCC
+#define EOSVOS_WG_OCC 2
+#endif
 template <int BMO, int BNI>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
-  constexpr int BKP = 32;
+__global__ __launch_bounds__(256, EOSVOS_WG_OCC) void wgrad_kernel(const WgradArgs p) {
+  constexpr int BKP = EOSVOS_WG_BKP;
   constexpr int LDA = BMO + 4, LDB = BNI + 4;
   constexpr int A_EL = BKP * LDA, B_EL = BKP * LDB, STAGE = A_EL + B_EL;
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
@@ -776,14 +785,15 @@ static int wg_tile(int c) {
 int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
   const int bm = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(Cout), bn = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(Cin);
   const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
-  const int steps = (P + 31) / 32;
-  // pick the K split so that tiles*S fills whole rounds of the 512 resident workgroups
+  const int steps = (P + EOSVOS_WG_BKP - 1) / EOSVOS_WG_BKP;
+  // pick the K split so that tiles*S fills whole rounds of the resident workgroups
+  constexpr int RES = 256 * EOSVOS_WG_OCC;
   int best = 1;
   double best_eff = 0.0;
-  for (int s = 1; s <= 512 && steps / s >= 4; ++s) {
+  for (int s = 1; s <= 512 && steps / s >= 128 / EOSVOS_WG_BKP; ++s) {
     const long wgs = (long)tiles * s;
-    const long rounds = (wgs + 511) / 512;
-    const double eff = (double)wgs / (double)(rounds * 512);
+    const long rounds = (wgs + RES - 1) / RES;
+    const double eff = (double)wgs / (double)(rounds * RES);
     if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
     if (eff >= 0.93) { best = s; break; }
   }
