@@ -167,8 +167,8 @@ def main():
     # dominant kernel, timed live with HIP events on the engine's stream
     k_ms, k_flops = eng.time_hot_kernel(BATCH, reps=20)
     achieved = k_flops / (k_ms * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false> (decoder.last_conv.0 forward, 3x3 304->256 '
-                '@120x214, batch 3)', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
+    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,2> (decoder.last_conv.0 forward, 3x3 304->256 '
+                '@120x214, batch 3; + its fix-up launch)', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MATRIX_PEAK,
                 # bytes per launch from the rocprofv3 --pmc passes of this kernel (separate runs,
                 # profiles/r01_pmc_hot_kernel.txt): 2*FETCH_SIZE (gfx950 half-count correction) +
