@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 H, W, BATCH = 480, 854, 3
 FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
-HOT_KERNEL_TRAFFIC_BYTES = (2 * 443.5e3 + 108.7e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
+HOT_KERNEL_TRAFFIC_BYTES = (2 * 525.5e3 + 125.4e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
 
 
 def cpu_baseline(sd, lrs, x, y, seconds_budget=25.0):
