@@ -215,8 +215,13 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
     }
     int cur_tap = -1;
     auto load_tiles = [&](int ks) {
+#ifdef EOSVOS_DEEP_CHUNK_MAJOR      // experiment: taps innermost (the 9 taps of a channel chunk re-read nearly the same rows)
+      const int vt = DEEP ? ks % T : ks / chunks;
+      const int c0 = DEEP ? (ks / T) * BK : (ks - vt * chunks) * BK;
+#else
       const int vt = ks / chunks;
       const int c0 = (ks - vt * chunks) * BK;
+#endif
       const int tap = p.tprefix ? (int)((tappack >> (4 * vt)) & 15) : vt;
       if (tap != cur_tap) {          // wave-uniform
         cur_tap = tap;

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/pmc; mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python3 tools/hot_kernel.py > $O/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python3 tools/hot_kernel.py > $O/$c.log 2>&1; tail -1 $O/$c.log
   python3 - <<PY
 import csv,glob
 f=glob.glob("$O/$c/**/*counter_collection.csv",recursive=True)[0]
