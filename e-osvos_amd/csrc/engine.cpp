@@ -185,7 +185,7 @@ struct eosvos_engine {
   float *g_c1, *g_p1;
   float *cat, *g_cat, *vec, *gvec, *poolout, *gp, *colscratch, *proj, *g_proj;
   float *dcat, *g_dcat, *d1, *g_d1, *d2, *g_d2, *lowlog, *g_low, *logits, *dlogits, *loss_dev, *bce_partial;
-  float *ws_conv, *ws_wg;
+  float *ws_conv, *ws_wg, *ws_conv2 = nullptr;
   int norm_mode = 0;                  // EOSVOS_NORM_BN_FROZEN / EOSVOS_NORM_GN16
   std::vector<float*> zbuf;           // GN: raw conv outputs (then, in backward, their gradients), dense [B*Ho*Wo][cout]
   std::vector<float*> gn_stats;       // GN: per conv {mean, rstd} per (image, group)
@@ -279,12 +279,15 @@ void trace(const char* kind, int ci, long M, long N, long K, int splits) {
   if (trace_on()) fprintf(stderr, "EOSVOS_TRACE %s conv=%d M=%ld N=%ld K=%ld splits=%d flops=%.0f\n", kind, ci, M, N, K, splits, 2.0 * M * N * K);
 }
 
+// `side`: launch on the side stream with its own stream-K workspace (forward branches that do not depend on
+// each other: downsample convs, decoder.conv1)
 void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi, float* y, int ldy, int B,
-              const float* res, int ldres, bool relu) {
+              const float* res, int ldres, bool relu, bool side = false) {
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.w = e->W_(ci); a.y = y; a.ws = e->ws_conv;
+  hipStream_t st = side ? e->s2 : e->s;
+  a.x = x; a.w = e->W_(ci); a.y = y; a.ws = side ? e->ws_conv2 : e->ws_conv;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.ldx = ldx; a.Kc = c.cin;
   a.Ho = conv_out(Hi, c.k, c.stride, c.dil, c.pad); a.Wo = conv_out(Wi, c.k, c.stride, c.dil, c.pad);
   a.N = c.cout; a.ldy = ldy; a.KH = a.KW = c.k;
@@ -299,10 +302,10 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   }
   attach_tap_table(e, ci, 0, B, a);
   trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a));
-  launch_conv(a, e->s);
+  launch_conv(a, st);
   if (gn)
     launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
-                      a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, e->s);
+                      a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st);
 }
 // gx[B,Hin,Win,cin] (ld ldgx) (+)= dgrad of conv ci applied to g[B,Ho,Wo,cout] (ld ldg)
 void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int Win, float* gx, int ldgx, int B,
@@ -567,6 +570,8 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
       HIPOK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
       e->ev.resize(t.convs.size() + 2);
       for (auto& evt : e->ev) HIPOK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
+      e->ws_conv2 = e->falloc(conv_ws_floats());
+      if (!e->ws_conv2) { eosvos_destroy(e); return fail("hipMalloc side workspace"); }
     }
   }
   // identity norm until eosvos_set_norm
@@ -735,19 +740,38 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
     launch_stem_fwd(e->xpad, e->W_(0), e->A_(0), e->B_(0), e->c1, B, e->H, e->W, e->h2, e->w2, s);
   }
   launch_maxpool_fwd(e->c1, e->p1, e->p1idx, B, e->h2, e->w2, 64, e->h4, e->w4, s);
+  // independent forward branches go to the side stream (frozen-BN mode; the GroupNorm kernels share scratch)
+#ifdef EOSVOS_NO_FWD_SIDE          // A/B switch
+  const bool fside = false;
+#else
+  const bool fside = e->s2 != nullptr && !e->gn();
+#endif
+  auto fork = [&](int ci) {      // the side stream continues from this point of the main stream
+    (void)hipEventRecord(e->ev[ci], s);
+    (void)hipStreamWaitEvent(e->s2, e->ev[ci], 0);
+  };
   for (size_t i = 0; i < t.blocks.size(); ++i) {
     const Block& b = t.blocks[i];
     auto& f = e->bb[i];
     const int cmid = t.convs[b.c1].cout, cout = t.convs[b.c3].cout;
-    conv_fwd(e, b.c1, f.xin, f.Cin, f.Hi, f.Wi, f.t1, cmid, B, nullptr, 0, true);
-    conv_fwd(e, b.c2, f.t1, cmid, f.Hm, f.Wm, f.t2, cmid, B, nullptr, 0, true);
     const float* res = f.xin;
     int ldres = f.Cin;
-    if (b.ds >= 0) {
-      conv_fwd(e, b.ds, f.xin, f.Cin, f.Hi, f.Wi, f.dsb, cout, B, nullptr, 0, false);
+    if (b.ds >= 0) {               // the projection shortcut only needs the block input: beside conv1 / conv2
+      if (fside) fork(b.ds);
+      conv_fwd(e, b.ds, f.xin, f.Cin, f.Hi, f.Wi, f.dsb, cout, B, nullptr, 0, false, fside);
+      if (fside) (void)hipEventRecord(e->ev[b.c3], e->s2);
       res = f.dsb; ldres = cout;
     }
+    conv_fwd(e, b.c1, f.xin, f.Cin, f.Hi, f.Wi, f.t1, cmid, B, nullptr, 0, true);
+    conv_fwd(e, b.c2, f.t1, cmid, f.Hm, f.Wm, f.t2, cmid, B, nullptr, 0, true);
+    if (b.ds >= 0 && fside) (void)hipStreamWaitEvent(s, e->ev[b.c3], 0);
     conv_fwd(e, b.c3, f.t2, cmid, f.Ho, f.Wo, f.out, cout, B, res, ldres, true);
+    if ((int)i == t.layer1_last_block && fside) {
+      // decoder.conv1 reads the layer1 feature only: it runs beside layer2..4 + ASPP
+      fork(t.dec1);
+      conv_fwd(e, t.dec1, f.out, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true, true);
+      (void)hipEventRecord(e->ev[t.dec_a], e->s2);
+    }
   }
   const float* l4 = e->bb.back().out;
   const int P16 = e->h16 * e->w16;
@@ -764,7 +788,8 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s);
   conv_fwd(e, t.project, e->cat, 1280, e->h16, e->w16, e->proj, 256, B, nullptr, 0, true);
   const float* low = e->bb[t.layer1_last_block].out;
-  conv_fwd(e, t.dec1, low, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true);
+  if (fside) (void)hipStreamWaitEvent(s, e->ev[t.dec_a], 0);
+  else conv_fwd(e, t.dec1, low, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true);
   launch_resize_fwd(e->proj, 256, e->dcat, 304, B, 256, e->up_h, e->up_w, s);
   conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, B, nullptr, 0, true);
   conv_fwd(e, t.dec_b, e->d1, 256, e->h4, e->w4, e->d2, 256, B, nullptr, 0, true);
