@@ -286,9 +286,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       const int buf = NBUF == 2 ? (ks - ks_begin) & 1 : 0;
       const bool more = (ks + 1) < ks_end;
-#ifndef EOSVOS_LOAD_AT
       if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
-#endif
       const float* As = smem + buf * STAGE;
       const float* Bs = As + A_EL;
 #pragma unroll
@@ -318,17 +316,9 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
             for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(av, bv[tn][j], acc[tm][tn]);
           }
         }
-#ifdef EOSVOS_LOAD_AT
-        if (kk == EOSVOS_LOAD_AT && more) load_tiles(ks + 1);
-#endif
-#ifdef EOSVOS_STORE_AT
-        if (kk == EOSVOS_STORE_AT && more) store_tiles(buf ^ 1);
-#endif
       }
-#ifndef EOSVOS_STORE_AT
       if (NBUF == 1) __syncthreads();         // every wave is done reading the single stage
       if (more) store_tiles(NBUF == 2 ? buf ^ 1 : 0);
-#endif
       __syncthreads();
     }
 
@@ -551,12 +541,7 @@ int conv_plan(ConvArgs& a) {
 #endif
   if (a.deep == 2) ksteps = (long)T * ((a.Kc + EOSVOS_BK_DEEP - 1) / EOSVOS_BK_DEEP);
   long nwg = a.deep ? CONV_MAX_WG_DEEP : CONV_MAX_WG, q = 0, per = 0;
-#ifndef EOSVOS_DPK
-#define EOSVOS_DPK 0
-#endif
-  if (tiles >= nwg && ksteps <= EOSVOS_DPK && a.total_units <= 0) {
-    q = 1; nwg = tiles;                                  // short K, many tiles: one tile per workgroup, no fix-up
-  } else if (tiles >= nwg && a.total_units <= 0) {
+  if (tiles >= nwg && a.total_units <= 0) {
     q = tiles / nwg;
     const long rem = tiles - q * nwg;
     if (rem > 0) {
