@@ -977,6 +977,17 @@ int eosvos_bce(eosvos_engine* e, const float* logits, const float* masks, int64_
   HIPOK(hipGetLastError());
   return 0;
 }
+int eosvos_loss_tensors(eosvos_engine* e, int kind, const float* logits, const float* masks, int64_t n, float* loss_out) {
+  if (kind == EOSVOS_LOSS_BCE) return eosvos_bce(e, logits, masks, n, loss_out, nullptr);
+  if (!e || !logits || !masks || !loss_out || n < 1) return fail("bad argument");
+  if (kind != EOSVOS_LOSS_DICE && kind != EOSVOS_LOSS_BCE_DICE && kind != EOSVOS_LOSS_CLASS_BALANCED_BCE)
+    return fail("unknown loss kind");
+  if (n > (int64_t)e->maxB * e->H * e->W) return fail("n exceeds the engine's scratch");
+  e->have_loss_grad = false;              // the gradient scratch is overwritten
+  launch_dice(logits, masks, e->dlogits, loss_out, e->bce_partial, n, kind, e->s);
+  HIPOK(hipGetLastError());
+  return 0;
+}
 int eosvos_backward_step(eosvos_engine* e, int accumulate) {
   if (!e) return fail("null engine");
   return backward_impl(e, true, accumulate != 0);

@@ -160,6 +160,15 @@ class Engine:
         _ffi.check(self.lib.eosvos_loss(self.h, k, _ptr(masks), masks.shape[0], _ptr(out)))
         return out
 
+    def loss_of(self, kind, logits, masks):
+        """Value of a compute_loss loss on arbitrary device tensors (one sample of a batch for
+        `batch_average: False`); no gradient is kept."""
+        logits, masks = logits.contiguous(), masks.contiguous()
+        assert logits.is_cuda and masks.is_cuda and logits.numel() == masks.numel()
+        out = torch.empty(1, device=self.device)
+        _ffi.check(self.lib.eosvos_loss_tensors(self.h, LOSS_KINDS[kind], _ptr(logits), _ptr(masks), logits.numel(), _ptr(out)))
+        return out
+
     def bce(self, logits, masks):
         """Mean BCE-with-logits of arbitrary device tensors (no gradient kept)."""
         logits, masks = logits.contiguous(), masks.contiguous()

@@ -36,9 +36,8 @@ def compute_loss(loss_func, outputs, gts, loss_kwargs=None):
         loss = eng.loss(loss_func, gts).view(())      # also leaves dL/dlogits in the engine
         loss._eosvos_engine = eng
         return loss
-    if loss_func != 'cross_entropy':
-        raise NotImplementedError('per-sample (batch_average=False) values are implemented for cross_entropy only')
-    return torch.cat([eng.bce(outputs[b], gts[b]) for b in range(outputs.shape[0])])
+    # per-sample values (run_loader metrics, helper_func.py:131-137): every loss evaluated sample by sample
+    return torch.cat([eng.loss_of(loss_func, outputs[b], gts[b]) for b in range(outputs.shape[0])])
 
 
 def init_parent_model(architecture, encoder, train_encoder, decoder_norm_layer=None,

@@ -108,6 +108,11 @@ int eosvos_set_loss(eosvos_engine* e, int kind);
  * then invalidated). */
 int eosvos_bce(eosvos_engine* e, const float* logits, const float* masks, int64_t n,
                float* loss_out, float* dlogits_out);
+/* The same for any loss kind: value of `compute_loss(loss_func, ...)` on n elements of caller tensors, e.g.
+ * one sample of a batch for `batch_average: False` (run_loader metrics, helper_func.py:131-137;
+ * loss_dice.py:33-40, loss_ce.py:26-40).  No gradient is kept; a pending loss gradient is invalidated. */
+int eosvos_loss_tensors(eosvos_engine* e, int kind, const float* logits, const float* masks, int64_t n,
+                        float* loss_out);
 /* autograd.grad + theta <- theta - lr (.) grad (meta_optim.py:177-214,
  * meta_model.py:78-80), using the gradient left by eosvos_loss_bce.
  * accumulate != 0 additionally adds the step's gradients into the task's sum_k g_k

@@ -121,6 +121,13 @@ def loss_fn(name, logits, gt):
     raise NotImplementedError(name)
 
 
+def loss_per_sample(name, logits, gt):
+    """`compute_loss(name, ..., {'batch_average': False})`: every loss of `helper_func.py:28-56` reduces per sample
+    (`loss_dice.py:33-40`, `loss_ce.py:26-40`, BCE `helper_func.py:38-39`), i.e. equals the batch-average form on
+    each sample alone."""
+    return torch.stack([loss_fn(name, logits[b:b + 1], gt[b:b + 1]) for b in range(logits.shape[0])])
+
+
 def class_balanced_bce_loss(logits, gt):
     """`class_balanced_cross_entropy_loss(output, label, size_average=True, batch_average=True)`,
     `src/networks/loss_ce.py:15-60`: positives weighted by the negative fraction and vice versa."""

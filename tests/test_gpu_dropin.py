@@ -232,3 +232,17 @@ def test_reference_style_meta_task_other_levels(golden_dir, level, use_log):
     assert grad.shape == ref.shape
     assert np.abs(grad - ref).max() <= 5e-3 * np.abs(ref).max()
     model.engine.close()
+
+
+def test_per_sample_losses_vs_golden(golden_dir):
+    """`compute_loss(loss_func, outputs, gts, {'batch_average': False})` for every loss (run_loader metrics,
+    helper_func.py:131-137) vs the reference's values on fixed logits (fixture G3b)."""
+    from eosvos_amd.engine import Engine
+    g = np.load(os.path.join(golden_dir, 'g3_loss.npz'))
+    gb = np.load(os.path.join(golden_dir, 'g3b_per_sample_loss.npz'))
+    eng = Engine('resnet50', 96, 160, max_batch=1, device=DEV)
+    lg, gt = torch.from_numpy(g['logits']).to(DEV), torch.from_numpy(g['gt']).to(DEV)
+    for name in ('cross_entropy', 'dice', 'cross_entropy_and_dice', 'class_balanced_cross_entropy'):
+        got = torch.cat([eng.loss_of(name, lg[b], gt[b]) for b in range(lg.shape[0])]).cpu().numpy()
+        np.testing.assert_allclose(got, gb['per_' + name], rtol=2e-5)
+    eng.close()

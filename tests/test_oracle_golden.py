@@ -105,6 +105,14 @@ def test_g3_loss(golden_dir):
         np.testing.assert_allclose(d.numpy(), g[key + '_dlogits'], rtol=1e-4, atol=1e-9)
 
 
+def test_g3b_per_sample_losses(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g3_loss.npz'))
+    gb = np.load(os.path.join(golden_dir, 'g3b_per_sample_loss.npz'))
+    lg, gt = torch.from_numpy(g['logits']), torch.from_numpy(g['gt'])
+    for name in ('cross_entropy', 'dice', 'cross_entropy_and_dice', 'class_balanced_cross_entropy'):
+        np.testing.assert_allclose(deeplab.loss_per_sample(name, lg, gt).reshape(-1).numpy(), gb['per_' + name], rtol=1e-6)
+
+
 def _meta_inputs():
     sd = synthetic.synthetic_state('resnet50')
     lrs = synthetic.synthetic_lrs('resnet50')
