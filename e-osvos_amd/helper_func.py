@@ -58,9 +58,10 @@ def init_parent_model(architecture, encoder, train_encoder, decoder_norm_layer=N
     return model, parent_states
 
 
-def run_frames(model, frames, gts=None):
+def run_frames(model, frames, gts=None, loss_func='cross_entropy'):
     """Inference over frames (N,3,H,W) one at a time (batch 1, `test` batch size of the configs):
-    returns (loss per frame or None, acc per frame or None, probs (N,1,H,W))."""
+    returns (`loss_func` per frame or None, acc per frame or None, probs (N,1,H,W)) -- `run_loader`,
+    helper_func.py:131-142, evaluates the configured loss with `batch_average: False`."""
     model.eval()
     probs, losses, accs = [], [], []
     for i in range(frames.shape[0]):
@@ -70,7 +71,7 @@ def run_frames(model, frames, gts=None):
         probs.append(p)
         if gts is not None:
             logits = eng.debug_tensor('logits')[:1]
-            losses.append(eng.bce(logits, gts[i:i + 1].contiguous()))
+            losses.append(eng.loss_of(loss_func, logits, gts[i:i + 1].contiguous()))
             pred = p.ge(0.5)
             accs.append(pred.eq(gts[i:i + 1].bool()).float().mean().view(1))
     probs = torch.cat(probs)
