@@ -246,3 +246,26 @@ def test_per_sample_losses_vs_golden(golden_dir):
         got = torch.cat([eng.loss_of(name, lg[b], gt[b]) for b in range(lg.shape[0])]).cpu().numpy()
         np.testing.assert_allclose(got, gb['per_' + name], rtol=2e-5)
     eng.close()
+
+
+def test_run_frames_metrics(model_and_optim):
+    """`run_loader` for the DeepLab branch (helper_func.py:131-142): per-frame loss of the configured loss, >= 0.5
+    accuracy and probabilities, against the CPU oracle."""
+    from eosvos_amd.helper_func import run_frames
+    from oracle import deeplab
+    model, mo, msd = model_and_optim
+    mo.load_state_dict(msd)
+    mo.reset()
+    x, y = synthetic.synthetic_frames(3, *SMALL, seed=31)
+    sd = synthetic.synthetic_state('resnet50')
+    with torch.no_grad():
+        ref_logits = deeplab.forward(sd, x)
+    for loss_func in ('cross_entropy', 'dice'):
+        losses, accs, probs = run_frames(model, x.to(DEV), y.to(DEV), loss_func=loss_func)
+        ref = deeplab.loss_per_sample(loss_func, ref_logits, y).reshape(-1)
+        np.testing.assert_allclose(losses.numpy(), ref.numpy(), rtol=2e-4)
+        assert float((probs.cpu() - torch.sigmoid(ref_logits)).abs().max()) < 1e-4
+        ref_acc = (torch.sigmoid(ref_logits).ge(0.5) == y.bool()).float().view(3, -1).mean(1)
+        assert float((accs - ref_acc).abs().max()) < 2e-3
+    none = run_frames(model, x.to(DEV))
+    assert none[0] is None and none[2].shape == (3, 1, *SMALL)
