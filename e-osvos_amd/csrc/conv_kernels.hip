@@ -661,8 +661,8 @@ __global__ __launch_bounds__(256, EOSVOS_WG_OCC) void wgrad_kernel(const WgradAr
   // advances by BKP pixels per step with carries instead of divisions; rows past the end use
   // the out-of-range offset of a range-checked buffer load (returns 0): no divergent branches.
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.g, (long)p.B * p.Ho * p.Wo * p.ldg * 4);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.g + tap * p.g_tap_stride, (long)p.B * p.Ho * p.Wo * p.ldg * 4);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + tap * p.x_tap_stride, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
   int a_img[APASS], a_ry[APASS], a_rx[APASS];
   int b_img[BPASS], b_ry[BPASS], b_rx[BPASS];
   {

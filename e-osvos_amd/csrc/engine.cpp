@@ -186,6 +186,8 @@ struct eosvos_engine {
   float *cat, *g_cat, *vec, *gvec, *poolout, *gp, *colscratch, *proj, *g_proj;
   float *dcat, *g_dcat, *d1, *g_d1, *d2, *g_d2, *lowlog, *g_low, *logits, *dlogits, *loss_dev, *bce_partial;
   float *ws_conv, *ws_wg, *ws_conv2 = nullptr;
+  float *wino_v = nullptr, *wino_m = nullptr;     // Winograd-domain input / output-gradient planes (decoder wgrad)
+  int64_t wino_v_n = 0, wino_m_n = 0;
   int norm_mode = 0;                  // EOSVOS_NORM_BN_FROZEN / EOSVOS_NORM_GN16
   std::vector<float*> zbuf;           // GN: raw conv outputs (then, in backward, their gradients), dense [B*Ho*Wo][cout]
   std::vector<float*> gn_stats;       // GN: per conv {mean, rstd} per (image, group)
@@ -349,6 +351,18 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
   launch_conv(a, e->s);
 }
+// Winograd F(2x2,3x3) weight gradient: the decoder's two 3x3 convs on the stride-4 map (27 % of a batch-3
+// iteration's FLOPs sit in those two layers; 2.25x fewer MACs, paid for with two transform passes)
+bool wino_wgrad(const eosvos_engine* e, int ci) {
+#ifdef EOSVOS_NO_WINO
+  (void)e; (void)ci;
+  return false;
+#else
+  const ConvL& c = e->t.convs[ci];
+  return (ci == e->t.dec_a || ci == e->t.dec_b) && c.k == 3 && c.stride == 1 && c.dil == 1 && c.pad == 1 &&
+         (c.cin & 3) == 0 && (c.cout & 3) == 0;
+#endif
+}
 // slabs of dW into ws_wg; returns the number of slabs
 int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x, int ldx, int Hin, int Win, int B) {
   const ConvL& c = e->t.convs[ci];
@@ -358,23 +372,40 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
                        e->s);
     g = e->zbuf[ci]; ldg = c.cout;
   }
-  WgradArgs a;
-  memset(&a, 0, sizeof(a));
-  a.g = g; a.x = x; a.ws = e->ws_wg + e->ws_off[ci];
-  a.B = B; a.Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad); a.Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
-  a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
-  a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
-  a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T());
-  trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits);
+  hipStream_t ws = e->s;
   if (e->s2) {
     // fork: everything this wgrad reads (g, x) is complete at this point of stream s
     (void)hipEventRecord(e->ev[ci], e->s);
     (void)hipStreamWaitEvent(e->s2, e->ev[ci], 0);
-    launch_wgrad(a, e->s2);
+    ws = e->s2;
     e->side_used = true;
-  } else {
-    launch_wgrad(a, e->s);
   }
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
+  if (wino_wgrad(e, ci)) {
+    const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
+    const long ntile = (long)B * th * tw;
+    launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, e->wino_v, ws);
+    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, th, tw, e->wino_m, ws);
+    float* final_slab = e->ws_wg + e->ws_off[ci];
+    a.g = e->wino_m; a.x = e->wino_v; a.ws = final_slab + c.wsize();
+    a.B = B; a.Ho = th; a.Wo = tw; a.ldg = c.cout; a.Cout = c.cout; a.Hi = th; a.Wi = tw; a.ldx = c.cin; a.Cin = c.cin;
+    a.KH = a.KW = 4; a.stride = 1; a.pad = 0; a.dil = 0;          // 16 "taps" = Winograd positions, no pixel shift
+    a.g_tap_stride = ntile * c.cout; a.x_tap_stride = ntile * c.cin;
+    a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, 16);
+    trace("wgrad", ci, c.cout, (long)c.cin * 16, ntile, a.splits);
+    launch_wgrad(a, ws);
+    launch_wino_wgrad_finish(a.ws, a.splits, c.cout, c.cin, final_slab, ws);
+    return 1;
+  }
+  a.g = g; a.x = x; a.ws = e->ws_wg + e->ws_off[ci];
+  a.B = B; a.Ho = Ho; a.Wo = Wo;
+  a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
+  a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
+  a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T());
+  trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits);
+  launch_wgrad(a, ws);
   return a.splits;
 }
 // reduce slabs, scale by the frozen-norm a[cout], (optionally) theta <- theta - lr*g
@@ -505,6 +536,13 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     (void)Md;
     for (int b = 1; b <= B; ++b)
       slabs[ci] = max64(slabs[ci], (int64_t)wgrad_pick_splits(b * Ho * Wo, c.cout, c.cin, c.T()) * c.wsize());
+    if (wino_wgrad(e, ci)) {           // [final 9-tap slab][Winograd-domain slabs: splits x cout x 16 x cin]
+      const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
+      for (int b = 1; b <= B; ++b)
+        slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits(b * th * tw, c.cout, c.cin, 16) * c.cout * 16 * c.cin);
+      e->wino_v_n = max64(e->wino_v_n, (int64_t)16 * B * th * tw * c.cin);
+      e->wino_m_n = max64(e->wino_m_n, (int64_t)16 * B * th * tw * c.cout);
+    }
     (void)Mf;
     if (e->gn() && c.norm) {
       e->zbuf[ci] = e->falloc((int64_t)B * Ho * Wo * c.cout);
@@ -558,6 +596,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     wsw += (slabs[ci] + 3) / 4 * 4;
   }
   ALLOC(e->ws_conv, wsc); ALLOC(e->ws_wg, wsw);
+  if (e->wino_v_n > 0) { ALLOC(e->wino_v, e->wino_v_n); ALLOC(e->wino_m, e->wino_m_n); }
   e->ws_conv_n = wsc; e->ws_wg_n = wsw;
 #undef ALLOC
   if (upload_resize(e, make_resize(e->h16, e->h4, true), e->h16, e->h4, e->up_h)) { eosvos_destroy(e); return 1; }

@@ -91,9 +91,14 @@ struct WgradArgs {
   int Hi, Wi, ldx, Cin;
   int KH, KW, stride, pad, dil;
   int splits;
+  long g_tap_stride, x_tap_stride;   // != 0: tap t reads plane g + t*stride / x + t*stride (batched GEMMs, Winograd)
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 int wgrad_pick_splits(int P, int Cout, int Cin, int T);
+// Winograd F(2x2,3x3) weight gradient pieces (misc_kernels.hip): V = B^T d B, dM = A dY A^T, dW = G^T sum_z dU_z G
+void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, float* V, hipStream_t s);
+void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, float* M, hipStream_t s);
+void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
 
 // ---------------------------------------------------------------------------------
 // misc_kernels.hip

@@ -1253,3 +1253,144 @@ void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const
                      tables + 2 * W, tables + 2 * W + H, ctab, cubic, flip, nonzero);
 }
 }  // namespace eosvos
+
+// ---- Winograd F(2x2, 3x3) weight gradient of the decoder's 3x3 convs ----------------------------------------
+// Y = A^T [ (G w G^T) (.) (B^T d B) ] A per 2x2 output tile and (cin, cout) pair, so with U = G w G^T:
+//   dU[p] = sum_tiles dM[p][tile][cout] * V[p][tile][cin]   (16 positions p: 16 GEMMs with K = tiles, 2.25x fewer
+//   MACs than the 9-tap form),  V = B^T d B,  dM = A dY A^T,  dW = G^T dU G.
+// V / dM are stored plane by plane ([p][tile][channel]) so the batched GEMM runs on wgrad_kernel with the 16
+// positions as "taps" (plane strides instead of pixel shifts).
+namespace eosvos {
+// V[p][tile][c] from X (NHWC, ld ldx): 4x4 patch rows 2ty-1..2ty+2, cols 2tx-1..2tx+2, zero outside the image
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, int C, int B, int H, int W,
+                                                          int th, int tw, float* __restrict__ V) {
+  const int C4 = C >> 2;
+  const long ntile = (long)B * th * tw, n = ntile * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long tile = e / C4;
+    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+    float4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int yy = 2 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xx = 2 * tx - 1 + j;
+        d[i][j] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                      ? *reinterpret_cast<const float4*>(x + (((long)b * H + yy) * W + xx) * ldx + c4 * 4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#define F4OP(r, a, op, b) r.x = a.x op b.x; r.y = a.y op b.y; r.z = a.z op b.z; r.w = a.w op b.w
+    float4 t[4][4];                        // t = B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      F4OP(t[0][j], d[0][j], -, d[2][j]); F4OP(t[1][j], d[1][j], +, d[2][j]);
+      F4OP(t[2][j], d[2][j], -, d[1][j]); F4OP(t[3][j], d[1][j], -, d[3][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // V = t B : columns (t0-t2, t1+t2, t2-t1, t1-t3)
+      float4 v0, v1, v2, v3;
+      F4OP(v0, t[i][0], -, t[i][2]); F4OP(v1, t[i][1], +, t[i][2]);
+      F4OP(v2, t[i][2], -, t[i][1]); F4OP(v3, t[i][1], -, t[i][3]);
+      float* o = V + ((long)(i * 4) * ntile + tile) * C + c4 * 4;
+      *reinterpret_cast<float4*>(o) = v0;
+      *reinterpret_cast<float4*>(o + ntile * C) = v1;
+      *reinterpret_cast<float4*>(o + 2 * ntile * C) = v2;
+      *reinterpret_cast<float4*>(o + 3 * ntile * C) = v3;
+    }
+  }
+}
+// dM[p][tile][c] = A dY A^T from dY (NHWC, ld ldg): 2x2 outputs of the tile (zero outside), A = [[1,0],[1,1],[1,-1],[0,-1]]
+__global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
+                                                         int th, int tw, float* __restrict__ M) {
+  const int C4 = C >> 2;
+  const long ntile = (long)B * th * tw, n = ntile * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long tile = e / C4;
+    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+    float4 d[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int yy = 2 * ty + i, xx = 2 * tx + j;
+        d[i][j] = (yy < H && xx < W) ? *reinterpret_cast<const float4*>(g + (((long)b * H + yy) * W + xx) * ldg + c4 * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    float4 t[4][2];                        // t = A d : rows (d0, d0+d1, d0-d1, -d1)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      t[0][j] = d[0][j];
+      F4OP(t[1][j], d[0][j], +, d[1][j]); F4OP(t[2][j], d[0][j], -, d[1][j]);
+      t[3][j] = make_float4(-d[1][j].x, -d[1][j].y, -d[1][j].z, -d[1][j].w);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // M = t A^T : columns (t0, t0+t1, t0-t1, -t1)
+      float4 m1, m2;
+      F4OP(m1, t[i][0], +, t[i][1]); F4OP(m2, t[i][0], -, t[i][1]);
+      const float4 m3 = make_float4(-t[i][1].x, -t[i][1].y, -t[i][1].z, -t[i][1].w);
+      float* o = M + ((long)(i * 4) * ntile + tile) * C + c4 * 4;
+      *reinterpret_cast<float4*>(o) = t[i][0];
+      *reinterpret_cast<float4*>(o + ntile * C) = m1;
+      *reinterpret_cast<float4*>(o + 2 * ntile * C) = m2;
+      *reinterpret_cast<float4*>(o + 3 * ntile * C) = m3;
+    }
+  }
+}
+// dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][4x4][cin]) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ ws, int splits, int Cout, int Cin,
+                                                                 float* __restrict__ dst) {
+  const int C4 = Cin >> 2;
+  const long n = (long)Cout * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4), co = (int)(e / C4);
+    float4 u[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) u[p >> 2][p & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float* sp = ws + ((size_t)z * Cout + co) * 16 * Cin + c4 * 4;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(sp + (size_t)p * Cin);
+        float4& a = u[p >> 2][p & 3];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    // t = G^T u (3x4): rows (u0 + .5(u1+u2), .5(u1-u2), .5(u1+u2) + u3); then w = t G (3x3), same combination on columns
+    float4 t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 s12, d12;
+      F4OP(s12, u[1][j], +, u[2][j]); F4OP(d12, u[1][j], -, u[2][j]);
+      t[0][j] = make_float4(u[0][j].x + 0.5f * s12.x, u[0][j].y + 0.5f * s12.y, u[0][j].z + 0.5f * s12.z, u[0][j].w + 0.5f * s12.w);
+      t[1][j] = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
+      t[2][j] = make_float4(0.5f * s12.x + u[3][j].x, 0.5f * s12.y + u[3][j].y, 0.5f * s12.z + u[3][j].z, 0.5f * s12.w + u[3][j].w);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float4 s12, d12;
+      F4OP(s12, t[i][1], +, t[i][2]); F4OP(d12, t[i][1], -, t[i][2]);
+      float* o = dst + ((size_t)co * 9 + i * 3) * Cin + c4 * 4;
+      *reinterpret_cast<float4*>(o) = make_float4(t[i][0].x + 0.5f * s12.x, t[i][0].y + 0.5f * s12.y, t[i][0].z + 0.5f * s12.z, t[i][0].w + 0.5f * s12.w);
+      *reinterpret_cast<float4*>(o + Cin) = make_float4(0.5f * d12.x, 0.5f * d12.y, 0.5f * d12.z, 0.5f * d12.w);
+      *reinterpret_cast<float4*>(o + 2 * Cin) = make_float4(0.5f * s12.x + t[i][3].x, 0.5f * s12.y + t[i][3].y, 0.5f * s12.z + t[i][3].z, 0.5f * s12.w + t[i][3].w);
+    }
+  }
+#undef F4OP
+}
+void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, float* V, hipStream_t s) {
+  const long n = (long)B * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, V);
+}
+void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, float* M, hipStream_t s) {
+  const long n = (long)B * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, M);
+}
+void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
+  const long n = (long)Cout * (Cin / 4);
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, ws, splits, Cout, Cin, dst);
+}
+}  // namespace eosvos
