@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
   const int up = 1 << p.upshift;
   constexpr int TN = BN / 64;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (long)p.wN * T * p.wK * 4);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (p.plane_rows ? 16L : 1L) * p.wN * T * p.wK * 4);
 
   for (long u = u_begin;;) {
     int tile, ks_begin, ks_end = ksteps;
@@ -203,14 +203,15 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
     constexpr unsigned OOB = 0x80000000u;
     int a_off[APASS];
     int b_off[BPASS];   // weight offset without the (tap, chunk) term, or -1
+    const int wplane = p.plane_rows ? (m0 / p.plane_rows) * (int)p.w_plane : 0;     // batched GEMM: this tile's weights
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       if (KMAJOR) {
         const int n = n0 + b_c4 * 4;
-        b_off[i] = n < p.N ? (b_r + i * BROWS) * T * p.wK + n : -1;
+        b_off[i] = n < p.N ? wplane + (b_r + i * BROWS) * T * p.wK + n : -1;
       } else {
         const int n = n0 + b_r + i * BROWS;
-        b_off[i] = n < p.N ? n * T * p.wK + b_c4 * 4 : -1;
+        b_off[i] = n < p.N ? wplane + n * T * p.wK + b_c4 * 4 : -1;
       }
     }
     int cur_tap = -1;

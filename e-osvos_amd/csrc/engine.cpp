@@ -186,8 +186,13 @@ struct eosvos_engine {
   float *cat, *g_cat, *vec, *gvec, *poolout, *gp, *colscratch, *proj, *g_proj;
   float *dcat, *g_dcat, *d1, *g_d1, *d2, *g_d2, *lowlog, *g_low, *logits, *dlogits, *loss_dev, *bce_partial;
   float *ws_conv, *ws_wg, *ws_conv2 = nullptr;
-  float *wino_v = nullptr, *wino_m = nullptr;     // Winograd-domain input / output-gradient planes (decoder wgrad)
-  int64_t wino_v_n = 0, wino_m_n = 0;
+  // Winograd F(2x2,3x3) path of the decoder's 3x3 convs: per conv the transformed input planes V (made by the
+  // forward pass, reused by the weight gradient) and transformed weights U; one shared buffer for the
+  // output-domain planes (forward: M, backward: dM)
+  std::map<int, float*> wino_V, wino_U;
+  std::map<int, int> wino_v_batch;                // batch size V was computed for (0 = stale)
+  float* wino_m = nullptr;
+  int64_t wino_m_n = 0;
   int norm_mode = 0;                  // EOSVOS_NORM_BN_FROZEN / EOSVOS_NORM_GN16
   std::vector<float*> zbuf;           // GN: raw conv outputs (then, in backward, their gradients), dense [B*Ho*Wo][cout]
   std::vector<float*> gn_stats;       // GN: per conv {mean, rstd} per (image, group)
@@ -281,6 +286,18 @@ void trace(const char* kind, int ci, long M, long N, long K, int splits) {
   if (trace_on()) fprintf(stderr, "EOSVOS_TRACE %s conv=%d M=%ld N=%ld K=%ld splits=%d flops=%.0f\n", kind, ci, M, N, K, splits, 2.0 * M * N * K);
 }
 
+// Winograd F(2x2,3x3) forward + weight gradient: the decoder's two 3x3 convs on the stride-4 map (27 % of a
+// batch-3 iteration's FLOPs sit in those two layers; 2.25x fewer MACs, paid for with transform passes)
+bool wino_wgrad(const eosvos_engine* e, int ci) {
+#ifdef EOSVOS_NO_WINO
+  (void)e; (void)ci;
+  return false;
+#else
+  const ConvL& c = e->t.convs[ci];
+  return (ci == e->t.dec_a || ci == e->t.dec_b) && c.k == 3 && c.stride == 1 && c.dil == 1 && c.pad == 1 &&
+         (c.cin & 3) == 0 && (c.cout & 3) == 0;
+#endif
+}
 // `side`: launch on the side stream with its own stream-K workspace (forward branches that do not depend on
 // each other: downsample convs, decoder.conv1)
 void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi, float* y, int ldy, int B,
@@ -296,6 +313,29 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   a.mul = c.stride; a.off0 = -c.pad; a.kstep = c.dil; a.upshift = 0;
   a.M = B * a.Ho * a.Wo; a.wN = c.cout; a.wK = c.cin; a.kmajor = 0;
   const bool gn = e->gn() && c.norm;
+  if (wino_wgrad(e, ci) && !side) {
+    // Winograd forward: U = G w G^T, V = B^T d B (kept for the weight gradient), 16 GEMMs [tiles x cin] x [cin x cout]
+    // as one batched launch (2.25x fewer MACs than the 9-tap form), y = epilogue(A^T M A)
+    const int th = (a.Ho + 1) / 2, tw = (a.Wo + 1) / 2;
+    const long ntile = (long)B * th * tw, prow = (ntile + 127) / 128 * 128;
+    launch_wino_weight(e->W_(ci), c.cout, c.cin, e->wino_U[ci], st);
+    launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, prow, e->wino_V[ci], st);
+    e->wino_v_batch[ci] = B;
+    ConvArgs m;
+    memset(&m, 0, sizeof(m));
+    m.x = e->wino_V[ci]; m.w = e->wino_U[ci]; m.y = e->wino_m; m.ws = a.ws;
+    m.B = 1; m.Hi = 1; m.Wi = (int)(16 * prow); m.ldx = c.cin; m.Kc = c.cin;
+    m.Ho = 1; m.Wo = m.Wi; m.N = c.cout; m.ldy = c.cout; m.KH = m.KW = 1; m.mul = 1;
+    m.M = m.Wi; m.wN = c.cout; m.wK = c.cin; m.plane_rows = (int)prow; m.w_plane = (long)c.cout * c.cin;
+    trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
+    launch_conv(m, st);
+    launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
+                       (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
+    if (gn)
+      launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
+                        a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st);
+    return;
+  }
   if (gn) {                       // raw conv output -> GroupNorm kernels (statistics are data dependent)
     a.y = e->zbuf[ci]; a.ldy = c.cout;
   } else {
@@ -351,18 +391,6 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
   launch_conv(a, e->s);
 }
-// Winograd F(2x2,3x3) weight gradient: the decoder's two 3x3 convs on the stride-4 map (27 % of a batch-3
-// iteration's FLOPs sit in those two layers; 2.25x fewer MACs, paid for with two transform passes)
-bool wino_wgrad(const eosvos_engine* e, int ci) {
-#ifdef EOSVOS_NO_WINO
-  (void)e; (void)ci;
-  return false;
-#else
-  const ConvL& c = e->t.convs[ci];
-  return (ci == e->t.dec_a || ci == e->t.dec_b) && c.k == 3 && c.stride == 1 && c.dil == 1 && c.pad == 1 &&
-         (c.cin & 3) == 0 && (c.cout & 3) == 0;
-#endif
-}
 // slabs of dW into ws_wg; returns the number of slabs
 int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x, int ldx, int Hin, int Win, int B) {
   const ConvL& c = e->t.convs[ci];
@@ -385,14 +413,15 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   if (wino_wgrad(e, ci)) {
     const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
-    const long ntile = (long)B * th * tw;
-    launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, e->wino_v, ws);
-    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, th, tw, e->wino_m, ws);
+    const long ntile = (long)B * th * tw, prow = (ntile + 127) / 128 * 128;
+    float* V = e->wino_V[ci];
+    if (e->wino_v_batch[ci] != B) launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, prow, V, ws);   // else: from the forward
+    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, th, tw, prow, e->wino_m, ws);
     float* final_slab = e->ws_wg + e->ws_off[ci];
-    a.g = e->wino_m; a.x = e->wino_v; a.ws = final_slab + c.wsize();
+    a.g = e->wino_m; a.x = V; a.ws = final_slab + c.wsize();
     a.B = B; a.Ho = th; a.Wo = tw; a.ldg = c.cout; a.Cout = c.cout; a.Hi = th; a.Wi = tw; a.ldx = c.cin; a.Cin = c.cin;
     a.KH = a.KW = 4; a.stride = 1; a.pad = 0; a.dil = 0;          // 16 "taps" = Winograd positions, no pixel shift
-    a.g_tap_stride = ntile * c.cout; a.x_tap_stride = ntile * c.cin;
+    a.g_tap_stride = prow * c.cout; a.x_tap_stride = prow * c.cin;
     a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, 16);
     trace("wgrad", ci, c.cout, (long)c.cin * 16, ntile, a.splits);
     launch_wgrad(a, ws);
@@ -540,8 +569,11 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
       const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
       for (int b = 1; b <= B; ++b)
         slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits(b * th * tw, c.cout, c.cin, 16) * c.cout * 16 * c.cin);
-      e->wino_v_n = max64(e->wino_v_n, (int64_t)16 * B * th * tw * c.cin);
-      e->wino_m_n = max64(e->wino_m_n, (int64_t)16 * B * th * tw * c.cout);
+      const int64_t prow = ((int64_t)B * th * tw + 127) / 128 * 128;
+      e->wino_V[ci] = e->falloc(16 * prow * c.cin);
+      e->wino_U[ci] = e->falloc((int64_t)16 * c.cout * c.cin);
+      e->wino_v_batch[ci] = 0;
+      e->wino_m_n = max64(e->wino_m_n, 16 * prow * max64(c.cout, c.cin));
     }
     (void)Mf;
     if (e->gn() && c.norm) {
@@ -596,7 +628,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     wsw += (slabs[ci] + 3) / 4 * 4;
   }
   ALLOC(e->ws_conv, wsc); ALLOC(e->ws_wg, wsw);
-  if (e->wino_v_n > 0) { ALLOC(e->wino_v, e->wino_v_n); ALLOC(e->wino_m, e->wino_m_n); }
+  if (e->wino_m_n > 0) ALLOC(e->wino_m, e->wino_m_n);
   e->ws_conv_n = wsc; e->ws_wg_n = wsw;
 #undef ALLOC
   if (upload_resize(e, make_resize(e->h16, e->h4, true), e->h16, e->h4, e->up_h)) { eosvos_destroy(e); return 1; }

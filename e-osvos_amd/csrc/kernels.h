@@ -41,6 +41,8 @@ struct ConvArgs {
   int ldmask, mask_c0;
   int relu;
   int accum;            // dgrad: add the existing contents of y
+  int plane_rows;       // != 0: batched GEMM -- rows [k*plane_rows, (k+1)*plane_rows) use the weights w + k*w_plane
+  long w_plane;
   int par;              // 1: GEMM rows enumerate the Ho x Wo grid parity class by parity class (stride-2 3x3 dgrad)
   int dst_up, Hf, Wf;   // dst_up=1: GEMM row (b,oy,ox) is written to pixel (b,2oy,2ox) of an Hf x Wf grid
   const int* tprefix;   // optional (device): compacted K-step prefix per tile (tiles+1), see conv_build_tap_table
@@ -96,8 +98,12 @@ struct WgradArgs {
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 int wgrad_pick_splits(int P, int Cout, int Cin, int T);
 // Winograd F(2x2,3x3) weight gradient pieces (misc_kernels.hip): V = B^T d B, dM = A dY A^T, dW = G^T sum_z dU_z G
-void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, float* V, hipStream_t s);
-void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, float* M, hipStream_t s);
+// planes are [16][prow][C] with prow >= B*th*tw rows (padded to the GEMM tile so that a row tile never straddles planes)
+void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V, hipStream_t s);
+void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M, hipStream_t s);
+void launch_wino_weight(const float* w, int Cout, int Cin, float* U, hipStream_t s);           // U = G w G^T
+void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+                        const float* bias, int relu, float* y, int ldy, hipStream_t s);        // y = epilogue(A^T M A)
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
 
 // ---------------------------------------------------------------------------------

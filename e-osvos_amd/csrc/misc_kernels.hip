@@ -1263,7 +1263,7 @@ void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const
 namespace eosvos {
 // V[p][tile][c] from X (NHWC, ld ldx): 4x4 patch rows 2ty-1..2ty+2, cols 2tx-1..2tx+2, zero outside the image
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, int C, int B, int H, int W,
-                                                          int th, int tw, float* __restrict__ V) {
+                                                          int th, int tw, long prow, float* __restrict__ V) {
   const int C4 = C >> 2;
   const long ntile = (long)B * th * tw, n = ntile * C4;
   GRID_STRIDE(e, n) {
@@ -1294,17 +1294,17 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       float4 v0, v1, v2, v3;
       F4OP(v0, t[i][0], -, t[i][2]); F4OP(v1, t[i][1], +, t[i][2]);
       F4OP(v2, t[i][2], -, t[i][1]); F4OP(v3, t[i][1], -, t[i][3]);
-      float* o = V + ((long)(i * 4) * ntile + tile) * C + c4 * 4;
+      float* o = V + ((long)(i * 4) * prow + tile) * C + c4 * 4;
       *reinterpret_cast<float4*>(o) = v0;
-      *reinterpret_cast<float4*>(o + ntile * C) = v1;
-      *reinterpret_cast<float4*>(o + 2 * ntile * C) = v2;
-      *reinterpret_cast<float4*>(o + 3 * ntile * C) = v3;
+      *reinterpret_cast<float4*>(o + prow * C) = v1;
+      *reinterpret_cast<float4*>(o + 2 * prow * C) = v2;
+      *reinterpret_cast<float4*>(o + 3 * prow * C) = v3;
     }
   }
 }
 // dM[p][tile][c] = A dY A^T from dY (NHWC, ld ldg): 2x2 outputs of the tile (zero outside), A = [[1,0],[1,1],[1,-1],[0,-1]]
 __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
-                                                         int th, int tw, float* __restrict__ M) {
+                                                         int th, int tw, long prow, float* __restrict__ M) {
   const int C4 = C >> 2;
   const long ntile = (long)B * th * tw, n = ntile * C4;
   GRID_STRIDE(e, n) {
@@ -1332,11 +1332,11 @@ __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict_
       float4 m1, m2;
       F4OP(m1, t[i][0], +, t[i][1]); F4OP(m2, t[i][0], -, t[i][1]);
       const float4 m3 = make_float4(-t[i][1].x, -t[i][1].y, -t[i][1].z, -t[i][1].w);
-      float* o = M + ((long)(i * 4) * ntile + tile) * C + c4 * 4;
+      float* o = M + ((long)(i * 4) * prow + tile) * C + c4 * 4;
       *reinterpret_cast<float4*>(o) = t[i][0];
-      *reinterpret_cast<float4*>(o + ntile * C) = m1;
-      *reinterpret_cast<float4*>(o + 2 * ntile * C) = m2;
-      *reinterpret_cast<float4*>(o + 3 * ntile * C) = m3;
+      *reinterpret_cast<float4*>(o + prow * C) = m1;
+      *reinterpret_cast<float4*>(o + 2 * prow * C) = m2;
+      *reinterpret_cast<float4*>(o + 3 * prow * C) = m3;
     }
   }
 }
@@ -1381,13 +1381,97 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
   }
 #undef F4OP
 }
-void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, float* V, hipStream_t s) {
+void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V,
+                       hipStream_t s) {
   const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, V);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, prow, V);
 }
-void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, float* M, hipStream_t s) {
+void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M,
+                      hipStream_t s) {
   const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, M);
+  hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, prow, M);
+}
+// U[p][cout][cin] = G w G^T from W[cout][3x3][cin]
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ U) {
+  const int C4 = Cin >> 2;
+  const long n = (long)Cout * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4), co = (int)(e / C4);
+    float4 g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
+    float4 t4[4][3];                       // t = G g : rows (g0, .5(g0+g1+g2), .5(g0-g1+g2), g2)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 a = g[0][j], b = g[1][j], c = g[2][j];
+      t4[0][j] = a;
+      t4[1][j] = make_float4(0.5f * (a.x + b.x + c.x), 0.5f * (a.y + b.y + c.y), 0.5f * (a.z + b.z + c.z), 0.5f * (a.w + b.w + c.w));
+      t4[2][j] = make_float4(0.5f * (a.x - b.x + c.x), 0.5f * (a.y - b.y + c.y), 0.5f * (a.z - b.z + c.z), 0.5f * (a.w - b.w + c.w));
+      t4[3][j] = c;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // U = t G^T : columns likewise
+      const float4 a = t4[i][0], b = t4[i][1], c = t4[i][2];
+      float* o = U + ((size_t)(i * 4) * Cout + co) * Cin + c4 * 4;
+      const size_t ps = (size_t)Cout * Cin;
+      *reinterpret_cast<float4*>(o) = a;
+      *reinterpret_cast<float4*>(o + ps) = make_float4(0.5f * (a.x + b.x + c.x), 0.5f * (a.y + b.y + c.y), 0.5f * (a.z + b.z + c.z), 0.5f * (a.w + b.w + c.w));
+      *reinterpret_cast<float4*>(o + 2 * ps) = make_float4(0.5f * (a.x - b.x + c.x), 0.5f * (a.y - b.y + c.y), 0.5f * (a.z - b.z + c.z), 0.5f * (a.w - b.w + c.w));
+      *reinterpret_cast<float4*>(o + 3 * ps) = c;
+    }
+  }
+}
+void launch_wino_weight(const float* w, int Cout, int Cin, float* U, hipStream_t s) {
+  const long n = (long)Cout * (Cin / 4);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, U);
+}
+// y (NHWC, ld ldy) = relu?(scale * (A^T M A) + bias) from M[p][tile][c], A^T = [[1,1,1,0],[0,1,-1,-1]]
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
+                                                           int th, int tw, const float* __restrict__ scale,
+                                                           const float* __restrict__ bias, int relu, float* __restrict__ y,
+                                                           int ldy) {
+  const int C4 = C >> 2;
+  const long ntile = (long)B * th * tw, n = ntile * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long tile = e / C4;
+    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+    float4 m[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = *reinterpret_cast<const float4*>(M + ((long)p * prow + tile) * C + c4 * 4);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
+    if (bias) bi = *reinterpret_cast<const float4*>(bias + c4 * 4);
+    float4 t[2][4];                        // t = A^T m : rows (m0+m1+m2, m1-m2-m3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = make_float4(m[0][j].x + m[1][j].x + m[2][j].x, m[0][j].y + m[1][j].y + m[2][j].y, m[0][j].z + m[1][j].z + m[2][j].z, m[0][j].w + m[1][j].w + m[2][j].w);
+      t[1][j] = make_float4(m[1][j].x - m[2][j].x - m[3][j].x, m[1][j].y - m[2][j].y - m[3][j].y, m[1][j].z - m[2][j].z - m[3][j].z, m[1][j].w - m[2][j].w - m[3][j].w);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int yy = 2 * ty + i;
+      if (yy >= H) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int xx = 2 * tx + j;
+        if (xx >= W) continue;
+        float4 v;
+        if (j == 0) v = make_float4(t[i][0].x + t[i][1].x + t[i][2].x, t[i][0].y + t[i][1].y + t[i][2].y, t[i][0].z + t[i][1].z + t[i][2].z, t[i][0].w + t[i][1].w + t[i][2].w);
+        else v = make_float4(t[i][1].x - t[i][2].x - t[i][3].x, t[i][1].y - t[i][2].y - t[i][3].y, t[i][1].z - t[i][2].z - t[i][3].z, t[i][1].w - t[i][2].w - t[i][3].w);
+        if (scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+        if (bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(y + (((long)b * H + yy) * W + xx) * ldy + c4 * 4) = v;
+      }
+    }
+  }
+}
+void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+                        const float* bias, int relu, float* y, int ldy, hipStream_t s) {
+  const long n = (long)B * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, scale,
+                     bias, relu, y, ldy);
 }
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
