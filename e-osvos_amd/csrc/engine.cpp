@@ -189,9 +189,10 @@ struct eosvos_engine {
   // Winograd F(2x2,3x3) path of the decoder's 3x3 convs: per conv the transformed input planes V (made by the
   // forward pass, reused by the weight gradient) and transformed weights U; one shared buffer for the
   // output-domain planes (forward: M, backward: dM)
-  std::map<int, float*> wino_V, wino_U;
+  std::map<int, float*> wino_V, wino_U, wino_dM;  // dM = A dY A^T: made once per backward, read by wgrad and dgrad
   std::map<int, int> wino_v_batch;                // batch size V was computed for (0 = stale)
-  float* wino_m = nullptr;
+  std::map<int, int> wino_dm_batch;               // batch size dM is valid for (0 = stale)
+  float *wino_m = nullptr, *wino_dv = nullptr;    // forward M planes; data-gradient dV planes (transient)
   int64_t wino_m_n = 0;
   int norm_mode = 0;                  // EOSVOS_NORM_BN_FROZEN / EOSVOS_NORM_GN16
   std::vector<float*> zbuf;           // GN: raw conv outputs (then, in backward, their gradients), dense [B*Ho*Wo][cout]
@@ -318,7 +319,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     // as one batched launch (2.25x fewer MACs than the 9-tap form), y = epilogue(A^T M A)
     const int th = (a.Ho + 1) / 2, tw = (a.Wo + 1) / 2;
     const long ntile = (long)B * th * tw, prow = (ntile + 127) / 128 * 128;
-    launch_wino_weight(e->W_(ci), c.cout, c.cin, e->wino_U[ci], st);
+    launch_wino_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
     launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, prow, e->wino_V[ci], st);
     e->wino_v_batch[ci] = B;
     ConvArgs m;
@@ -365,6 +366,36 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.kscale = e->A_(ci);
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
   a.res = add; a.ldres = ldadd;
+  if (wino_wgrad(e, ci) && !accum && !add) {
+    // Winograd data gradient: dV[p] = dM[p] (a[cout] U[p]), 16 GEMMs [tiles x cout] x [cout x cin] in one batched
+    // launch, then dX = mask(B dV B^T) gathered per 2x2 pixel block
+    const int th = (Hin + 1) / 2, tw = (Win + 1) / 2;
+    const long prow = ((long)B * th * tw + 127) / 128 * 128;
+    if (e->wino_dm_batch[ci] != B) launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, prow, e->wino_dM[ci], e->s);
+    e->wino_dm_batch[ci] = 0;
+    launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->s);
+    ConvArgs m;
+    memset(&m, 0, sizeof(m));
+    m.x = e->wino_dM[ci]; m.w = e->wino_U[ci]; m.y = e->wino_dv; m.ws = e->ws_conv;
+    m.B = 1; m.Hi = 1; m.Wi = (int)(16 * prow); m.ldx = c.cout; m.Kc = c.cout;
+    m.Ho = 1; m.Wo = m.Wi; m.N = c.cin; m.ldy = c.cin; m.KH = m.KW = 1; m.mul = 1;
+    m.M = m.Wi; m.wN = c.cout; m.wK = c.cin; m.kmajor = 1; m.plane_rows = (int)prow; m.w_plane = (long)c.cout * c.cin;
+    const int tailw = m.N % 128;
+    if (m.N > 128 && tailw > 0 && tailw <= 64) {      // 304 = 2 x 128-wide column tiles + a 64-wide launch
+      ConvArgs b = m;
+      m.N -= tailw;
+      trace("dgrad", ci, m.M, m.N, c.cout, conv_plan(m));
+      launch_conv(m, e->s);
+      b.N = tailw; b.w += m.N; b.y += m.N;
+      trace("dgrad", ci, b.M, b.N, c.cout, conv_plan(b));
+      launch_conv(b, e->s);
+    } else {
+      trace("dgrad", ci, m.M, m.N, c.cout, conv_plan(m));
+      launch_conv(m, e->s);
+    }
+    launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, mask, ldmask, mask_c0, gx, ldgx, e->s);
+    return;
+  }
   if (c.k == 1 && c.stride == 2 && !add) {
     // only the even pixels of the finer grid receive a contribution: run the GEMM on the
     // coarse grid (4x less MFMA work) and scatter; untouched pixels are zero (or keep their sum)
@@ -400,6 +431,13 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
                        e->s);
     g = e->zbuf[ci]; ldg = c.cout;
   }
+  const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
+  if (wino_wgrad(e, ci)) {          // dM feeds this weight gradient (side stream) and the data gradient (main stream)
+    const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
+    const long prow = ((long)B * th * tw + 127) / 128 * 128;
+    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, th, tw, prow, e->wino_dM[ci], e->s);
+    e->wino_dm_batch[ci] = B;
+  }
   hipStream_t ws = e->s;
   if (e->s2) {
     // fork: everything this wgrad reads (g, x) is complete at this point of stream s
@@ -410,15 +448,13 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   }
   WgradArgs a;
   memset(&a, 0, sizeof(a));
-  const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   if (wino_wgrad(e, ci)) {
     const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
     const long ntile = (long)B * th * tw, prow = (ntile + 127) / 128 * 128;
     float* V = e->wino_V[ci];
     if (e->wino_v_batch[ci] != B) launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, prow, V, ws);   // else: from the forward
-    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, th, tw, prow, e->wino_m, ws);
     float* final_slab = e->ws_wg + e->ws_off[ci];
-    a.g = e->wino_m; a.x = V; a.ws = final_slab + c.wsize();
+    a.g = e->wino_dM[ci]; a.x = V; a.ws = final_slab + c.wsize();
     a.B = B; a.Ho = th; a.Wo = tw; a.ldg = c.cout; a.Cout = c.cout; a.Hi = th; a.Wi = tw; a.ldx = c.cin; a.Cin = c.cin;
     a.KH = a.KW = 4; a.stride = 1; a.pad = 0; a.dil = 0;          // 16 "taps" = Winograd positions, no pixel shift
     a.g_tap_stride = prow * c.cout; a.x_tap_stride = prow * c.cin;
@@ -572,7 +608,8 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
       const int64_t prow = ((int64_t)B * th * tw + 127) / 128 * 128;
       e->wino_V[ci] = e->falloc(16 * prow * c.cin);
       e->wino_U[ci] = e->falloc((int64_t)16 * c.cout * c.cin);
-      e->wino_v_batch[ci] = 0;
+      e->wino_dM[ci] = e->falloc(16 * prow * c.cout);
+      e->wino_v_batch[ci] = 0; e->wino_dm_batch[ci] = 0;
       e->wino_m_n = max64(e->wino_m_n, 16 * prow * max64(c.cout, c.cin));
     }
     (void)Mf;
@@ -628,7 +665,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     wsw += (slabs[ci] + 3) / 4 * 4;
   }
   ALLOC(e->ws_conv, wsc); ALLOC(e->ws_wg, wsw);
-  if (e->wino_m_n > 0) ALLOC(e->wino_m, e->wino_m_n);
+  if (e->wino_m_n > 0) { ALLOC(e->wino_m, e->wino_m_n); ALLOC(e->wino_dv, e->wino_m_n); }
   e->ws_conv_n = wsc; e->ws_wg_n = wsw;
 #undef ALLOC
   if (upload_resize(e, make_resize(e->h16, e->h4, true), e->h16, e->h4, e->up_h)) { eosvos_destroy(e); return 1; }

@@ -101,7 +101,9 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T);
 // planes are [16][prow][C] with prow >= B*th*tw rows (padded to the GEMM tile so that a row tile never straddles planes)
 void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V, hipStream_t s);
 void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M, hipStream_t s);
-void launch_wino_weight(const float* w, int Cout, int Cin, float* U, hipStream_t s);           // U = G w G^T
+void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);   // U = G (rowscale*w) G^T
+void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
+                              int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
                         const float* bias, int relu, float* y, int ldy, hipStream_t s);        // y = epilogue(A^T M A)
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);

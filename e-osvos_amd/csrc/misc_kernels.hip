@@ -1392,14 +1392,20 @@ void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int t
   hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, prow, M);
 }
 // U[p][cout][cin] = G w G^T from W[cout][3x3][cin]
-__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ U) {
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                           const float* __restrict__ rowscale, float* __restrict__ U) {
   const int C4 = Cin >> 2;
   const long n = (long)Cout * C4;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4), co = (int)(e / C4);
+    const float rs = rowscale ? rowscale[co] : 1.f;      // data gradient: the frozen-norm scale a[cout] folded into U
     float4 g[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
+    for (int t = 0; t < 9; ++t) {
+      float4 v = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
+      v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+      g[t / 3][t % 3] = v;
+    }
     float4 t4[4][3];                       // t = G g : rows (g0, .5(g0+g1+g2), .5(g0-g1+g2), g2)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -1421,9 +1427,98 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
   }
 }
-void launch_wino_weight(const float* w, int Cout, int Cin, float* U, hipStream_t s) {
+void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, U);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U);
+}
+// dX (NHWC, ld ldgx) = mask?( sum over the covering tiles of (B dV B^T)[i][j] ), one thread per 2x2 pixel block and 4
+// channels: the block (2k..2k+1, 2l..2l+1) takes rows i = 3 of tile k-1, i = 1, 2 of tile k and i = 0 of tile k+1
+// (columns likewise), B = [[1,0,0,0],[0,1,-1,1],[-1,1,1,0],[0,0,0,-1]]; gather form, no atomics: deterministic.
+__global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
+                                                                 int W, int th, int tw, const float* __restrict__ mask,
+                                                                 int ldmask, int mask_c0, float* __restrict__ gx, int ldgx) {
+  const int C4 = C >> 2;
+  const int bh = (H + 1) >> 1, bw = (W + 1) >> 1;          // 2x2 pixel blocks (= tiles grid)
+  const long n = (long)B * bh * bw * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long blk = e / C4;
+    const int l = (int)(blk % bw), k = (int)((blk / bw) % bh), b = (int)(blk / ((long)bw * bh));
+    float4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // tile rows: (tile dk, patch row i) pairs feeding output row r of the block
+    // r = 0 (y = 2k):   (k, i = 1), (k-1, i = 3);   r = 1 (y = 2k+1): (k, i = 2), (k+1, i = 0)
+#pragma unroll
+    for (int dk = -1; dk <= 1; ++dk) {
+      const int ty = k + dk;
+      if ((unsigned)ty >= (unsigned)th) continue;
+#pragma unroll
+      for (int dl = -1; dl <= 1; ++dl) {
+        const int tx = l + dl;
+        if ((unsigned)tx >= (unsigned)tw) continue;
+        const long tile = ((long)b * th + ty) * tw + tx;
+        // rows of B needed from this tile: dk=-1 -> {3}; dk=0 -> {1,2}; dk=+1 -> {0}; columns likewise with dl
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = dk < 0 ? 3 : (dk > 0 ? 0 : 1 + ii);
+          if (dk != 0 && ii == 1) continue;
+          const int r = dk < 0 ? 0 : (dk > 0 ? 1 : ii);              // output row inside the block
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = dl < 0 ? 3 : (dl > 0 ? 0 : 1 + jj);
+            if (dl != 0 && jj == 1) continue;
+            const int cidx = dl < 0 ? 0 : (dl > 0 ? 1 : jj);          // output column inside the block
+            // dd[i][j] = sum_{a,bb} Bm[i][a] * dV[a][bb] * Bm[j][bb]
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const float ba = (i == 0) ? (a == 0 ? 1.f : 0.f)
+                             : (i == 1) ? (a == 1 ? 1.f : (a == 2 ? -1.f : (a == 3 ? 1.f : 0.f)))
+                             : (i == 2) ? (a == 0 ? -1.f : (a == 3 ? 0.f : 1.f))
+                                        : (a == 3 ? -1.f : 0.f);
+              if (ba == 0.f) continue;
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) {
+                const float bj = (j == 0) ? (bb == 0 ? 1.f : 0.f)
+                               : (j == 1) ? (bb == 1 ? 1.f : (bb == 2 ? -1.f : (bb == 3 ? 1.f : 0.f)))
+                               : (j == 2) ? (bb == 0 ? -1.f : (bb == 3 ? 0.f : 1.f))
+                                          : (bb == 3 ? -1.f : 0.f);
+                if (bj == 0.f) continue;
+                const float4 v = *reinterpret_cast<const float4*>(dV + ((long)(a * 4 + bb) * prow + tile) * C + c4 * 4);
+                const float wgt = ba * bj;
+                sum.x += wgt * v.x; sum.y += wgt * v.y; sum.z += wgt * v.z; sum.w += wgt * v.w;
+              }
+            }
+            acc[r][cidx].x += sum.x; acc[r][cidx].y += sum.y; acc[r][cidx].z += sum.z; acc[r][cidx].w += sum.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int yy = 2 * k + r;
+      if (yy >= H) continue;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int xx = 2 * l + cc;
+        if (xx >= W) continue;
+        const long pix = ((long)b * H + yy) * W + xx;
+        float4 v = acc[r][cc];
+        if (mask && c4 * 4 >= mask_c0) {
+          const float4 m = *reinterpret_cast<const float4*>(mask + pix * ldmask + c4 * 4);
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(gx + pix * ldgx + c4 * 4) = v;
+      }
+    }
+  }
+}
+void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
+                              int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s) {
+  const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  hipLaunchKernelGGL(wino_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
+                     mask, ldmask, mask_c0, gx, ldgx);
 }
 // y (NHWC, ld ldy) = relu?(scale * (A^T M A) + bias) from M[p][tile][c], A^T = [[1,1,1,0],[0,1,-1,-1]]
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
