@@ -536,7 +536,12 @@ int conv_plan(ConvArgs& a) {
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
 #ifndef EOSVOS_NO_DEEP
   // 3-workgroups-per-CU kernel for long-K layers with many tiles (measured: decoder 3x3 fwd/dgrad at batch >= 2)
-  a.deep = (bn == 128 && tiles >= EOSVOS_DEEP_TILES && ksteps >= 64 && a.total_units <= 0) ? ((a.Kc & 31) ? 2 : 1) : 0;
+#ifdef EOSVOS_DEEP_BATCHED
+  const bool deep_ok = ksteps >= 64 || a.plane_rows != 0;
+#else
+  const bool deep_ok = ksteps >= 64;
+#endif
+  a.deep = (bn == 128 && tiles >= EOSVOS_DEEP_TILES && deep_ok && a.total_units <= 0) ? ((a.Kc & 31) ? 2 : 1) : 0;
 #else
   a.deep = 0;
 #endif

@@ -295,9 +295,25 @@ bool wino_wgrad(const eosvos_engine* e, int ci) {
   return false;
 #else
   const ConvL& c = e->t.convs[ci];
+#ifdef EOSVOS_WINO_ALL             // experiment: every 3x3 / stride 1 / dilation 1 conv with >= EOSVOS_WINO_ALL channels
+  return c.k == 3 && c.stride == 1 && c.dil == 1 && c.pad == 1 && (c.cin & 3) == 0 && (c.cout & 3) == 0 &&
+         (ci == e->t.dec_a || ci == e->t.dec_b || c.cin >= EOSVOS_WINO_ALL);
+#else
   return (ci == e->t.dec_a || ci == e->t.dec_b) && c.k == 3 && c.stride == 1 && c.dil == 1 && c.pad == 1 &&
          (c.cin & 3) == 0 && (c.cout & 3) == 0;
 #endif
+#endif
+}
+// The batched GEMM of a Winograd forward: rows = 16 planes x prow tiles of V, weights U[p] per plane -> M planes
+ConvArgs wino_fwd_gemm(eosvos_engine* e, int ci, long prow, float* ws) {
+  const ConvL& c = e->t.convs[ci];
+  ConvArgs m;
+  memset(&m, 0, sizeof(m));
+  m.x = e->wino_V[ci]; m.w = e->wino_U[ci]; m.y = e->wino_m; m.ws = ws;
+  m.B = 1; m.Hi = 1; m.Wi = (int)(16 * prow); m.ldx = c.cin; m.Kc = c.cin;
+  m.Ho = 1; m.Wo = m.Wi; m.N = c.cout; m.ldy = c.cout; m.KH = m.KW = 1; m.mul = 1;
+  m.M = m.Wi; m.wN = c.cout; m.wK = c.cin; m.plane_rows = (int)prow; m.w_plane = (long)c.cout * c.cin;
+  return m;
 }
 // `side`: launch on the side stream with its own stream-K workspace (forward branches that do not depend on
 // each other: downsample convs, decoder.conv1)
@@ -322,12 +338,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     launch_wino_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
     launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, prow, e->wino_V[ci], st);
     e->wino_v_batch[ci] = B;
-    ConvArgs m;
-    memset(&m, 0, sizeof(m));
-    m.x = e->wino_V[ci]; m.w = e->wino_U[ci]; m.y = e->wino_m; m.ws = a.ws;
-    m.B = 1; m.Hi = 1; m.Wi = (int)(16 * prow); m.ldx = c.cin; m.Kc = c.cin;
-    m.Ho = 1; m.Wo = m.Wi; m.N = c.cout; m.ldy = c.cout; m.KH = m.KW = 1; m.mul = 1;
-    m.M = m.Wi; m.wN = c.cout; m.wK = c.cin; m.plane_rows = (int)prow; m.w_plane = (long)c.cout * c.cin;
+    ConvArgs m = wino_fwd_gemm(e, ci, prow, a.ws);
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
     launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
@@ -1293,15 +1304,28 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
   hipEvent_t a, b;
   HIPOK(hipEventCreate(&a));
   HIPOK(hipEventCreate(&b));
-  conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);   // warm
-  HIPOK(hipEventRecord(a, e->s));
-  for (int i = 0; i < reps; ++i) conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);
-  HIPOK(hipEventRecord(b, e->s));
+  conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);   // warm (and fills V / U)
+  const ConvL& c = t.convs[t.dec_a];
+  if (wino_wgrad(e, t.dec_a)) {
+    // the step runs this layer in the Winograd domain: time its batched GEMM launch (+ fix-up), the largest
+    // conv_igemm launch of an iteration, against the GEMM's own FLOPs
+    const int th = (e->h4 + 1) / 2, tw = (e->w4 + 1) / 2;
+    const long ntile = (long)batch * th * tw, prow = (ntile + 127) / 128 * 128;
+    ConvArgs m = wino_fwd_gemm(e, t.dec_a, prow, e->ws_conv);
+    HIPOK(hipEventRecord(a, e->s));
+    for (int i = 0; i < reps; ++i) { ConvArgs k = m; launch_conv(k, e->s); }
+    HIPOK(hipEventRecord(b, e->s));
+    *flops_host = 2.0 * 16.0 * (double)ntile * c.cout * c.cin;
+  } else {
+    HIPOK(hipEventRecord(a, e->s));
+    for (int i = 0; i < reps; ++i) conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);
+    HIPOK(hipEventRecord(b, e->s));
+    *flops_host = 2.0 * (double)batch * e->h4 * e->w4 * 256.0 * 304.0 * 9.0;
+  }
   HIPOK(hipEventSynchronize(b));
   float ms = 0.f;
   HIPOK(hipEventElapsedTime(&ms, a, b));
   *ms_host = ms / reps;
-  *flops_host = 2.0 * (double)batch * e->h4 * e->w4 * 256.0 * 304.0 * 9.0;
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return 0;

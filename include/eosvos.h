@@ -202,9 +202,10 @@ int eosvos_radam_step(eosvos_engine* e, float* param, const float* grad, float* 
 int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi);
 
 /* ---- instrumentation ----------------------------------------------------------------- */
-/* Time `reps` launches of the dominant conv kernel of the last finetune step's shape
- * (decoder.last_conv.0 forward) with HIP events on the engine stream; returns the
- * average milliseconds in *ms_host and the algorithmic FLOPs per launch in *flops_host. */
+/* Time `reps` launches of the largest conv_igemm launch of a fine-tune iteration (decoder.last_conv.0
+ * forward: the batched GEMM of its Winograd form, 16 x [tiles x 304] x [304 x 256], + its fix-up launch)
+ * with HIP events on the engine stream; returns the average milliseconds in *ms_host and that launch's own
+ * FLOPs in *flops_host. */
 int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host,
                            double* flops_host);
 /* Tuning aid: average milliseconds of `reps` launches of conv `conv_idx`'s forward (kind 0), data
