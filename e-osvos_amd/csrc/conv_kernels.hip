@@ -536,12 +536,13 @@ int conv_plan(ConvArgs& a) {
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
 #ifndef EOSVOS_NO_DEEP
   // 3-workgroups-per-CU kernel for long-K layers with many tiles (measured: decoder 3x3 fwd/dgrad at batch >= 2)
-#ifdef EOSVOS_DEEP_BATCHED
-  const bool deep_ok = ksteps >= 64 || a.plane_rows != 0;
-#else
-  const bool deep_ok = ksteps >= 64;
+#ifndef EOSVOS_DEEP_BATCHED
+#define EOSVOS_DEEP_BATCHED 2      // 0: never, 1: batched GEMMs with K % 32 != 0 use the K-step-16 variant, 2: all batched GEMMs
 #endif
-  a.deep = (bn == 128 && tiles >= EOSVOS_DEEP_TILES && deep_ok && a.total_units <= 0) ? ((a.Kc & 31) ? 2 : 1) : 0;
+  const bool batched_deep = a.plane_rows != 0 && (EOSVOS_DEEP_BATCHED == 2 || (EOSVOS_DEEP_BATCHED == 1 && (a.Kc & 31)));
+  const bool deep_ok = ksteps >= 64 || batched_deep;
+  a.deep = (bn == 128 && tiles >= EOSVOS_DEEP_TILES && deep_ok && a.total_units <= 0)
+               ? (((a.Kc & 31) || batched_deep) ? 2 : 1) : 0;
 #else
   a.deep = 0;
 #endif
