@@ -287,21 +287,37 @@ void trace(const char* kind, int ci, long M, long N, long K, int splits) {
   if (trace_on()) fprintf(stderr, "EOSVOS_TRACE %s conv=%d M=%ld N=%ld K=%ld splits=%d flops=%.0f\n", kind, ci, M, N, K, splits, 2.0 * M * N * K);
 }
 
-// Winograd F(2x2,3x3) forward + weight gradient: the decoder's two 3x3 convs on the stride-4 map (27 % of a
-// batch-3 iteration's FLOPs sit in those two layers; 2.25x fewer MACs, paid for with transform passes)
-bool wino_wgrad(const eosvos_engine* e, int ci) {
+// Winograd F(2x2,3x3) path (forward, data gradient, weight gradient) of 3x3 / stride 1 convs: 2.25x fewer MACs,
+// paid for with HBM-bound transform passes.  Always on for the decoder's two convs on the stride-4 map (27 % of a
+// batch-3 iteration's FLOPs); for the dilated / undilated conv2 of layer3 / layer4 only when the launch is large
+// enough for the extra passes to pay (EOSVOS_WINO_MINWORK multiply-accumulates per Winograd position).
+struct WinoGeom { int th, tw, d; long ntile, prow; };
+WinoGeom wino_geom(const ConvL& c, int B, int Ho, int Wo) {
+  WinoGeom g;
+  g.d = c.dil;
+  g.th = ((Ho + g.d - 1) / g.d + 1) / 2;                 // 2x2 output tiles per sub-grid of a dilated conv
+  g.tw = ((Wo + g.d - 1) / g.d + 1) / 2;
+  g.ntile = (long)B * g.d * g.d * g.th * g.tw;
+  g.prow = (g.ntile + 127) / 128 * 128;                  // plane rows padded to the GEMM tile
+  return g;
+}
+#ifndef EOSVOS_WINO_MINWORK
+#define EOSVOS_WINO_MINWORK 100000000LL                // measured: layer4 conv2 and the d = 6 ASPP conv gain, layer2/3 conv2 do not
+#endif
+bool wino_shape(const ConvL& c) {
+  return c.k == 3 && c.stride == 1 && c.pad == c.dil && c.dil >= 1 && c.dil <= 8 && (c.cin & 3) == 0 && (c.cout & 3) == 0;
+}
+bool wino_on(const eosvos_engine* e, int ci, int B, int Ho, int Wo) {
 #ifdef EOSVOS_NO_WINO
-  (void)e; (void)ci;
+  (void)e; (void)ci; (void)B; (void)Ho; (void)Wo;
   return false;
 #else
   const ConvL& c = e->t.convs[ci];
-#ifdef EOSVOS_WINO_ALL             // experiment: every 3x3 / stride 1 / dilation 1 conv with >= EOSVOS_WINO_ALL channels
-  return c.k == 3 && c.stride == 1 && c.dil == 1 && c.pad == 1 && (c.cin & 3) == 0 && (c.cout & 3) == 0 &&
-         (ci == e->t.dec_a || ci == e->t.dec_b || c.cin >= EOSVOS_WINO_ALL);
-#else
-  return (ci == e->t.dec_a || ci == e->t.dec_b) && c.k == 3 && c.stride == 1 && c.dil == 1 && c.pad == 1 &&
-         (c.cin & 3) == 0 && (c.cout & 3) == 0;
-#endif
+  if (!wino_shape(c)) return false;
+  if (ci == e->t.dec_a || ci == e->t.dec_b) return true;
+  if (e->wino_V.find(ci) == e->wino_V.end()) return false;            // no buffers were reserved for it
+  const WinoGeom g = wino_geom(c, B, Ho, Wo);
+  return (long long)g.ntile * c.cin * c.cout >= EOSVOS_WINO_MINWORK;
 #endif
 }
 // The batched GEMM of a Winograd forward: rows = 16 planes x prow tiles of V, weights U[p] per plane -> M planes
@@ -330,18 +346,19 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   a.mul = c.stride; a.off0 = -c.pad; a.kstep = c.dil; a.upshift = 0;
   a.M = B * a.Ho * a.Wo; a.wN = c.cout; a.wK = c.cin; a.kmajor = 0;
   const bool gn = e->gn() && c.norm;
-  if (wino_wgrad(e, ci) && !side) {
+  if (!side && wino_on(e, ci, B, a.Ho, a.Wo)) {
     // Winograd forward: U = G w G^T, V = B^T d B (kept for the weight gradient), 16 GEMMs [tiles x cin] x [cin x cout]
     // as one batched launch (2.25x fewer MACs than the 9-tap form), y = epilogue(A^T M A)
-    const int th = (a.Ho + 1) / 2, tw = (a.Wo + 1) / 2;
-    const long ntile = (long)B * th * tw, prow = (ntile + 127) / 128 * 128;
+    const WinoGeom wg = wino_geom(c, B, a.Ho, a.Wo);
+    const int th = wg.th, tw = wg.tw;
+    const long prow = wg.prow;
     launch_wino_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
-    launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, prow, e->wino_V[ci], st);
+    launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
     e->wino_v_batch[ci] = B;
     ConvArgs m = wino_fwd_gemm(e, ci, prow, a.ws);
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
-    launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
+    launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
                        (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
     if (gn)
       launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
@@ -377,12 +394,13 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.kscale = e->A_(ci);
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
   a.res = add; a.ldres = ldadd;
-  if (wino_wgrad(e, ci) && !accum && !add) {
+  if (!accum && !add && wino_on(e, ci, B, Hin, Win)) {
     // Winograd data gradient: dV[p] = dM[p] (a[cout] U[p]), 16 GEMMs [tiles x cout] x [cout x cin] in one batched
     // launch, then dX = mask(B dV B^T) gathered per 2x2 pixel block
-    const int th = (Hin + 1) / 2, tw = (Win + 1) / 2;
-    const long prow = ((long)B * th * tw + 127) / 128 * 128;
-    if (e->wino_dm_batch[ci] != B) launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, prow, e->wino_dM[ci], e->s);
+    const WinoGeom wg = wino_geom(c, B, Hin, Win);
+    const int th = wg.th, tw = wg.tw;
+    const long prow = wg.prow;
+    if (e->wino_dm_batch[ci] != B) launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
     e->wino_dm_batch[ci] = 0;
     launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->s);
     ConvArgs m;
@@ -404,7 +422,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
       trace("dgrad", ci, m.M, m.N, c.cout, conv_plan(m));
       launch_conv(m, e->s);
     }
-    launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, mask, ldmask, mask_c0, gx, ldgx, e->s);
+    launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, gx, ldgx, e->s);
     return;
   }
   if (c.k == 1 && c.stride == 2 && !add) {
@@ -443,10 +461,10 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     g = e->zbuf[ci]; ldg = c.cout;
   }
   const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
-  if (wino_wgrad(e, ci)) {          // dM feeds this weight gradient (side stream) and the data gradient (main stream)
-    const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
-    const long prow = ((long)B * th * tw + 127) / 128 * 128;
-    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, th, tw, prow, e->wino_dM[ci], e->s);
+  const bool wino = wino_on(e, ci, B, Ho, Wo);
+  if (wino) {                       // dM feeds this weight gradient (side stream) and the data gradient (main stream)
+    const WinoGeom wg = wino_geom(c, B, Ho, Wo);
+    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
     e->wino_dm_batch[ci] = B;
   }
   hipStream_t ws = e->s;
@@ -459,14 +477,15 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   }
   WgradArgs a;
   memset(&a, 0, sizeof(a));
-  if (wino_wgrad(e, ci)) {
-    const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
-    const long ntile = (long)B * th * tw, prow = (ntile + 127) / 128 * 128;
+  if (wino) {
+    const WinoGeom wg = wino_geom(c, B, Ho, Wo);
+    const int th = wg.th, tw = wg.tw;
+    const long ntile = wg.ntile, prow = wg.prow;
     float* V = e->wino_V[ci];
-    if (e->wino_v_batch[ci] != B) launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, prow, V, ws);   // else: from the forward
+    if (e->wino_v_batch[ci] != B) launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, wg.d, prow, V, ws);   // else: from the forward
     float* final_slab = e->ws_wg + e->ws_off[ci];
     a.g = e->wino_dM[ci]; a.x = V; a.ws = final_slab + c.wsize();
-    a.B = B; a.Ho = th; a.Wo = tw; a.ldg = c.cout; a.Cout = c.cout; a.Hi = th; a.Wi = tw; a.ldx = c.cin; a.Cin = c.cin;
+    a.B = 1; a.Ho = 1; a.Wo = (int)ntile; a.ldg = c.cout; a.Cout = c.cout; a.Hi = 1; a.Wi = (int)ntile; a.ldx = c.cin; a.Cin = c.cin;
     a.KH = a.KW = 4; a.stride = 1; a.pad = 0; a.dil = 0;          // 16 "taps" = Winograd positions, no pixel shift
     a.g_tap_stride = prow * c.cout; a.x_tap_stride = prow * c.cin;
     a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, 16);
@@ -612,11 +631,15 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     (void)Md;
     for (int b = 1; b <= B; ++b)
       slabs[ci] = max64(slabs[ci], (int64_t)wgrad_pick_splits(b * Ho * Wo, c.cout, c.cin, c.T()) * c.wsize());
-    if (wino_wgrad(e, ci)) {           // [final 9-tap slab][Winograd-domain slabs: splits x cout x 16 x cin]
-      const int th = (Ho + 1) / 2, tw = (Wo + 1) / 2;
+    bool reserve = false;
+#ifndef EOSVOS_NO_WINO
+    reserve = wino_shape(c) && (ci == t.dec_a || ci == t.dec_b ||
+                                (long long)wino_geom(c, B, Ho, Wo).ntile * c.cin * c.cout >= EOSVOS_WINO_MINWORK);
+#endif
+    if (reserve) {                     // [final 9-tap slab][Winograd-domain slabs: splits x cout x 16 x cin]
       for (int b = 1; b <= B; ++b)
-        slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits(b * th * tw, c.cout, c.cin, 16) * c.cout * 16 * c.cin);
-      const int64_t prow = ((int64_t)B * th * tw + 127) / 128 * 128;
+        slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits((int)wino_geom(c, b, Ho, Wo).ntile, c.cout, c.cin, 16) * c.cout * 16 * c.cin);
+      const int64_t prow = wino_geom(c, B, Ho, Wo).prow;
       e->wino_V[ci] = e->falloc(16 * prow * c.cin);
       e->wino_U[ci] = e->falloc((int64_t)16 * c.cout * c.cin);
       e->wino_dM[ci] = e->falloc(16 * prow * c.cout);
@@ -1306,11 +1329,11 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
   HIPOK(hipEventCreate(&b));
   conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);   // warm (and fills V / U)
   const ConvL& c = t.convs[t.dec_a];
-  if (wino_wgrad(e, t.dec_a)) {
+  if (wino_on(e, t.dec_a, batch, e->h4, e->w4)) {
     // the step runs this layer in the Winograd domain: time its batched GEMM launch (+ fix-up), the largest
     // conv_igemm launch of an iteration, against the GEMM's own FLOPs
-    const int th = (e->h4 + 1) / 2, tw = (e->w4 + 1) / 2;
-    const long ntile = (long)batch * th * tw, prow = (ntile + 127) / 128 * 128;
+    const WinoGeom wg = wino_geom(c, batch, e->h4, e->w4);
+    const long ntile = wg.ntile, prow = wg.prow;
     ConvArgs m = wino_fwd_gemm(e, t.dec_a, prow, e->ws_conv);
     HIPOK(hipEventRecord(a, e->s));
     for (int i = 0; i < reps; ++i) { ConvArgs k = m; launch_conv(k, e->s); }

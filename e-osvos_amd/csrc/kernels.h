@@ -99,12 +99,13 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s);
 int wgrad_pick_splits(int P, int Cout, int Cin, int T);
 // Winograd F(2x2,3x3) weight gradient pieces (misc_kernels.hip): V = B^T d B, dM = A dY A^T, dW = G^T sum_z dU_z G
 // planes are [16][prow][C] with prow >= B*th*tw rows (padded to the GEMM tile so that a row tile never straddles planes)
-void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V, hipStream_t s);
-void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M, hipStream_t s);
+// dil: dilation of the 3x3 conv = dil*dil interleaved sub-grids; tiles are (image, sy, sx, ty, tx), th x tw per sub-grid
+void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V, hipStream_t s);
+void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M, hipStream_t s);
 void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);   // U = G (rowscale*w) G^T
-void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
-                              int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
-void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
+                              const float* mask, int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
+void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                         const float* bias, int relu, float* y, int ldy, hipStream_t s);        // y = epilogue(A^T M A)
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
 

@@ -1263,20 +1263,23 @@ void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const
 namespace eosvos {
 // V[p][tile][c] from X (NHWC, ld ldx): 4x4 patch rows 2ty-1..2ty+2, cols 2tx-1..2tx+2, zero outside the image
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, int C, int B, int H, int W,
-                                                          int th, int tw, long prow, float* __restrict__ V) {
+                                                          int th, int tw, int dil, long prow, float* __restrict__ V) {
   const int C4 = C >> 2;
-  const long ntile = (long)B * th * tw, n = ntile * C4;
+  const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
-    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+    // dilation d: d*d interleaved sub-grids, each an ordinary 3x3 convolution; tile = (image, sy, sx, ty, tx)
+    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th);
+    const int sx = (int)((tile / ((long)tw * th)) % dil), sy = (int)((tile / ((long)tw * th * dil)) % dil);
+    const int b = (int)(tile / ((long)tw * th * dil * dil));
     float4 d[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int yy = 2 * ty - 1 + i;
+      const int yy = sy + dil * (2 * ty - 1 + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int xx = 2 * tx - 1 + j;
+        const int xx = sx + dil * (2 * tx - 1 + j);
         d[i][j] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
                       ? *reinterpret_cast<const float4*>(x + (((long)b * H + yy) * W + xx) * ldx + c4 * 4)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1304,19 +1307,21 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 // dM[p][tile][c] = A dY A^T from dY (NHWC, ld ldg): 2x2 outputs of the tile (zero outside), A = [[1,0],[1,1],[1,-1],[0,-1]]
 __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
-                                                         int th, int tw, long prow, float* __restrict__ M) {
+                                                         int th, int tw, int dil, long prow, float* __restrict__ M) {
   const int C4 = C >> 2;
-  const long ntile = (long)B * th * tw, n = ntile * C4;
+  const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
-    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th);
+    const int sx = (int)((tile / ((long)tw * th)) % dil), sy = (int)((tile / ((long)tw * th * dil)) % dil);
+    const int b = (int)(tile / ((long)tw * th * dil * dil));
     float4 d[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int yy = 2 * ty + i, xx = 2 * tx + j;
+        const int yy = sy + dil * (2 * ty + i), xx = sx + dil * (2 * tx + j);
         d[i][j] = (yy < H && xx < W) ? *reinterpret_cast<const float4*>(g + (((long)b * H + yy) * W + xx) * ldg + c4 * 4)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -1381,15 +1386,15 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
   }
 #undef F4OP
 }
-void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V,
+void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,
                        hipStream_t s) {
-  const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, prow, V);
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, dil, prow, V);
 }
-void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M,
+void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M,
                       hipStream_t s) {
-  const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, prow, M);
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M);
 }
 // U[p][cout][cin] = G w G^T from W[cout][3x3][cin]
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
@@ -1435,15 +1440,17 @@ void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale
 // channels: the block (2k..2k+1, 2l..2l+1) takes rows i = 3 of tile k-1, i = 1, 2 of tile k and i = 0 of tile k+1
 // (columns likewise), B = [[1,0,0,0],[0,1,-1,1],[-1,1,1,0],[0,0,0,-1]]; gather form, no atomics: deterministic.
 __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
-                                                                 int W, int th, int tw, const float* __restrict__ mask,
-                                                                 int ldmask, int mask_c0, float* __restrict__ gx, int ldgx) {
+                                                                 int W, int th, int tw, int dil,
+                                                                 const float* __restrict__ mask, int ldmask, int mask_c0,
+                                                                 float* __restrict__ gx, int ldgx) {
   const int C4 = C >> 2;
-  const int bh = (H + 1) >> 1, bw = (W + 1) >> 1;          // 2x2 pixel blocks (= tiles grid)
-  const long n = (long)B * bh * bw * C4;
+  const long n = (long)B * dil * dil * th * tw * C4;      // one 2x2 block of a sub-grid per tile position
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long blk = e / C4;
-    const int l = (int)(blk % bw), k = (int)((blk / bw) % bh), b = (int)(blk / ((long)bw * bh));
+    const int l = (int)(blk % tw), k = (int)((blk / tw) % th);
+    const int sx = (int)((blk / ((long)tw * th)) % dil), sy = (int)((blk / ((long)tw * th * dil)) % dil);
+    const int b = (int)(blk / ((long)tw * th * dil * dil));
     float4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1457,7 +1464,7 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
       for (int dl = -1; dl <= 1; ++dl) {
         const int tx = l + dl;
         if ((unsigned)tx >= (unsigned)tw) continue;
-        const long tile = ((long)b * th + ty) * tw + tx;
+        const long tile = ((((long)b * dil + sy) * dil + sx) * th + ty) * tw + tx;
         // rows of B needed from this tile: dk=-1 -> {3}; dk=0 -> {1,2}; dk=+1 -> {0}; columns likewise with dl
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
@@ -1497,11 +1504,11 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int yy = 2 * k + r;
+      const int yy = sy + dil * (2 * k + r);
       if (yy >= H) continue;
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
-        const int xx = 2 * l + cc;
+        const int xx = sx + dil * (2 * l + cc);
         if (xx >= W) continue;
         const long pix = ((long)b * H + yy) * W + xx;
         float4 v = acc[r][cc];
@@ -1514,23 +1521,25 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
     }
   }
 }
-void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
-                              int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s) {
-  const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
+                              const float* mask, int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s) {
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
-                     mask, ldmask, mask_c0, gx, ldgx);
+                     dil, mask, ldmask, mask_c0, gx, ldgx);
 }
 // y (NHWC, ld ldy) = relu?(scale * (A^T M A) + bias) from M[p][tile][c], A^T = [[1,1,1,0],[0,1,-1,-1]]
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
-                                                           int th, int tw, const float* __restrict__ scale,
+                                                           int th, int tw, int dil, const float* __restrict__ scale,
                                                            const float* __restrict__ bias, int relu, float* __restrict__ y,
                                                            int ldy) {
   const int C4 = C >> 2;
-  const long ntile = (long)B * th * tw, n = ntile * C4;
+  const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
-    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+    const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th);
+    const int sx = (int)((tile / ((long)tw * th)) % dil), sy = (int)((tile / ((long)tw * th * dil)) % dil);
+    const int b = (int)(tile / ((long)tw * th * dil * dil));
     float4 m[4][4];
 #pragma unroll
     for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = *reinterpret_cast<const float4*>(M + ((long)p * prow + tile) * C + c4 * 4);
@@ -1545,11 +1554,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int yy = 2 * ty + i;
+      const int yy = sy + dil * (2 * ty + i);
       if (yy >= H) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int xx = 2 * tx + j;
+        const int xx = sx + dil * (2 * tx + j);
         if (xx >= W) continue;
         float4 v;
         if (j == 0) v = make_float4(t[i][0].x + t[i][1].x + t[i][2].x, t[i][0].y + t[i][1].y + t[i][2].y, t[i][0].z + t[i][1].z + t[i][2].z, t[i][0].w + t[i][1].w + t[i][2].w);
@@ -1562,11 +1571,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
   }
 }
-void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                         const float* bias, int relu, float* y, int ldy, hipStream_t s) {
-  const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, scale,
-                     bias, relu, y, ldy);
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, dil,
+                     scale, bias, relu, y, ldy);
 }
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
