@@ -779,8 +779,14 @@ static int wg_tile(int c) {
 #ifndef EOSVOS_WG_SMALLP
 #define EOSVOS_WG_SMALLP 2500        // pixel count below which 64x64 tiles are used (more tiles, fewer K splits)
 #endif
+// few pixels AND few tiles (stride-16 layers at batch 1): 64x64 tiles give more tiles and fewer K splits
+static bool wg_small(int P, int Cout, int Cin, int T) {
+  const int t128 = ((Cout + wg_tile(Cout) - 1) / wg_tile(Cout)) * ((Cin + wg_tile(Cin) - 1) / wg_tile(Cin)) * T;
+  return P < EOSVOS_WG_SMALLP && t128 < 256;
+}
 int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
-  const int bm = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(Cout), bn = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(Cin);
+  const bool small = wg_small(P, Cout, Cin, T);
+  const int bm = small ? 64 : wg_tile(Cout), bn = small ? 64 : wg_tile(Cin);
   const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
   const int steps = (P + EOSVOS_WG_BKP - 1) / EOSVOS_WG_BKP;
   // pick the K split so that tiles*S fills whole rounds of the resident workgroups
@@ -799,7 +805,8 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
   const int P = a.B * a.Ho * a.Wo;
-  const int bm = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(a.Cout), bn = P < EOSVOS_WG_SMALLP ? 64 : wg_tile(a.Cin);
+  const bool small = wg_small(P, a.Cout, a.Cin, a.KH * a.KW);
+  const int bm = small ? 64 : wg_tile(a.Cout), bn = small ? 64 : wg_tile(a.Cin);
   const int T = a.KH * a.KW;
   const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * T;
   const dim3 grid(tiles * a.splits), block(256);
