@@ -394,7 +394,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.kscale = e->A_(ci);
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
   a.res = add; a.ldres = ldadd;
-  if (!accum && !add && wino_on(e, ci, B, Hin, Win)) {
+  if (!add && wino_on(e, ci, B, Hin, Win)) {
     // Winograd data gradient: dV[p] = dM[p] (a[cout] U[p]), 16 GEMMs [tiles x cout] x [cout x cin] in one batched
     // launch, then dX = mask(B dV B^T) gathered per 2x2 pixel block
     const WinoGeom wg = wino_geom(c, B, Hin, Win);
@@ -422,7 +422,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
       trace("dgrad", ci, m.M, m.N, c.cout, conv_plan(m));
       launch_conv(m, e->s);
     }
-    launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, gx, ldgx, e->s);
+    launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
     return;
   }
   if (c.k == 1 && c.stride == 2 && !add) {

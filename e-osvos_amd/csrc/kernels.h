@@ -104,7 +104,7 @@ void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int 
 void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M, hipStream_t s);
 void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);   // U = G (rowscale*w) G^T
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                              const float* mask, int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
+                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                         const float* bias, int relu, float* y, int ldy, hipStream_t s);        // y = epilogue(A^T M A)
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);

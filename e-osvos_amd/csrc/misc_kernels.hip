@@ -1442,7 +1442,7 @@ void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale
 __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
                                                                  int W, int th, int tw, int dil,
                                                                  const float* __restrict__ mask, int ldmask, int mask_c0,
-                                                                 float* __restrict__ gx, int ldgx) {
+                                                                 int accum, float* __restrict__ gx, int ldgx) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;      // one 2x2 block of a sub-grid per tile position
   GRID_STRIDE(e, n) {
@@ -1512,6 +1512,10 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
         if (xx >= W) continue;
         const long pix = ((long)b * H + yy) * W + xx;
         float4 v = acc[r][cc];
+        if (accum) {                       // several branches feed this gradient (ASPP): add, then mask, like the GEMM epilogue
+          const float4 o = *reinterpret_cast<const float4*>(gx + pix * ldgx + c4 * 4);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
         if (mask && c4 * 4 >= mask_c0) {
           const float4 m = *reinterpret_cast<const float4*>(mask + pix * ldmask + c4 * 4);
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
@@ -1522,10 +1526,10 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
   }
 }
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                              const float* mask, int ldmask, int mask_c0, float* gx, int ldgx, hipStream_t s) {
+                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
-                     dil, mask, ldmask, mask_c0, gx, ldgx);
+                     dil, mask, ldmask, mask_c0, accum, gx, ldgx);
 }
 // y (NHWC, ld ldy) = relu?(scale * (A^T M A) + bias) from M[p][tile][c], A^T = [[1,1,1,0],[0,1,-1,-1]]
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
