@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 H, W, BATCH = 480, 854, 3
 FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
-HOT_KERNEL_TRAFFIC_BYTES = (2 * 212.8e3 + 323.6e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
+HOT_KERNEL_TRAFFIC_BYTES = (2 * 210.4e3 + 352.3e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
 
 
 def cpu_baseline(sd, lrs, x, y, seconds_budget=25.0):
@@ -167,7 +167,7 @@ def main():
     # dominant kernel, timed live with HIP events on the engine's stream
     k_ms, k_flops = eng.time_hot_kernel(BATCH, reps=20)
     achieved = k_flops / (k_ms * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,0>: the largest conv launch of an iteration = batched GEMM '
+    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,2>: the largest conv launch of an iteration = batched GEMM '
                 'of decoder.last_conv.0 forward in the Winograd F(2x2,3x3) domain, 16 x [19260 tiles x 304] x [304 x 256] '
                 '(+ its fix-up launch); achieved counts this GEMM\'s own FLOPs (2.25x fewer than the 9-tap form)', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MATRIX_PEAK,

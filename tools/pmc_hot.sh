@@ -7,8 +7,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 - <<PY
 import csv,glob
 f=glob.glob("$O/$c/**/*counter_collection.csv",recursive=True)[0]
-rows=[r for r in csv.DictReader(open(f)) if "conv_igemm_kernel<128, false, 0>" in r["Kernel_Name"] and r["Counter_Name"]=="$c" and r["Grid_Size"]=="131072"]
+rows=[r for r in csv.DictReader(open(f)) if "conv_igemm_kernel<128, false, 2>" in r["Kernel_Name"] and r["Counter_Name"]=="$c" and r["Grid_Size"]=="196608"]
 vals=[float(r["Counter_Value"]) for r in rows]
-print("$c (KB per launch, last 5 512-workgroup launches of conv_igemm_kernel<128,false,0> = Winograd GEMM of decoder.last_conv.0 forward):", vals[-5:])
+print("$c (KB per launch, last 5 768-workgroup launches of conv_igemm_kernel<128,false,2> = Winograd GEMM of decoder.last_conv.0 forward):", vals[-5:])
 PY
 done
