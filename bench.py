@@ -91,11 +91,12 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, xg, yg, barrier, dev):
                                    'all-reduce(sum) of the 40.3 M-float meta-gradient, RAdam + lr clamp on every rank',
                        'meta_batch_size': world, 'inner_steps': 5, 'height': H, 'width': W,
                        'parallelism': f'tasks sharded x{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false> (decoder.last_conv.0 forward, batch 1)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,2>: Winograd-domain batched GEMM of decoder.last_conv.0 forward, batch 1 '
+                                   '(own FLOPs)',
                          'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
                          'frac': achieved / FP32_MATRIX_PEAK, 'traffic': None, 'kernel_ms': k_ms,
                          'flops_per_launch': k_flops,
-                         'whole_step_tflops': 6 * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12},
+                         'whole_step_tflops': 6 * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12},   # 9-tap-equivalent FLOPs
             'cpu_baseline': None, 'extra': {'last_meta_loss': losses[-1]},
         }
         print(json.dumps(out), flush=True)
