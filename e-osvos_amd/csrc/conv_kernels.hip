@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
   const int up = 1 << p.upshift;
   constexpr int TN = BN / 64;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (p.plane_rows ? 16L : 1L) * p.wN * T * p.wK * 4);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (p.plane_rows ? (long)p.nplanes : 1L) * p.wN * T * p.wK * 4);
 
   for (long u = u_begin;;) {
     int tile, ks_begin, ks_end = ksteps;

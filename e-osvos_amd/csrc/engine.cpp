@@ -291,12 +291,24 @@ void trace(const char* kind, int ci, long M, long N, long K, int splits) {
 // paid for with HBM-bound transform passes.  Always on for the decoder's two convs on the stride-4 map (27 % of a
 // batch-3 iteration's FLOPs); for the dilated / undilated conv2 of layer3 / layer4 only when the launch is large
 // enough for the extra passes to pay (EOSVOS_WINO_MINWORK multiply-accumulates per Winograd position).
-struct WinoGeom { int th, tw, d; long ntile, prow; };
+struct WinoGeom { int th, tw, d, tm, np; long ntile, prow; };
+// F(4x4,3x3) (36 positions, 2.25 MACs per output) for undilated convs on maps of >= 64 x 64 outputs -- the decoder --
+// where 4x4 tiles waste little at the border; F(2x2,3x3) (16 positions, 4 MACs per output) otherwise.
+bool wino_f4(const ConvL& c, int Ho, int Wo) {
+#ifdef EOSVOS_NO_WINO_F4
+  (void)c; (void)Ho; (void)Wo;
+  return false;
+#else
+  return c.dil == 1 && Ho >= 64 && Wo >= 64;
+#endif
+}
 WinoGeom wino_geom(const ConvL& c, int B, int Ho, int Wo) {
   WinoGeom g;
   g.d = c.dil;
-  g.th = ((Ho + g.d - 1) / g.d + 1) / 2;                 // 2x2 output tiles per sub-grid of a dilated conv
-  g.tw = ((Wo + g.d - 1) / g.d + 1) / 2;
+  g.tm = wino_f4(c, Ho, Wo) ? 4 : 2;
+  g.np = (g.tm + 2) * (g.tm + 2);
+  g.th = ((Ho + g.d - 1) / g.d + g.tm - 1) / g.tm;       // output tiles per sub-grid of a dilated conv
+  g.tw = ((Wo + g.d - 1) / g.d + g.tm - 1) / g.tm;
   g.ntile = (long)B * g.d * g.d * g.th * g.tw;
   g.prow = (g.ntile + 127) / 128 * 128;                  // plane rows padded to the GEMM tile
   return g;
@@ -321,12 +333,13 @@ bool wino_on(const eosvos_engine* e, int ci, int B, int Ho, int Wo) {
 #endif
 }
 // The batched GEMM of a Winograd forward: rows = 16 planes x prow tiles of V, weights U[p] per plane -> M planes
-ConvArgs wino_fwd_gemm(eosvos_engine* e, int ci, long prow, float* ws) {
+ConvArgs wino_fwd_gemm(eosvos_engine* e, int ci, const WinoGeom& wg, float* ws) {
   const ConvL& c = e->t.convs[ci];
+  const long prow = wg.prow;
   ConvArgs m;
   memset(&m, 0, sizeof(m));
-  m.x = e->wino_V[ci]; m.w = e->wino_U[ci]; m.y = e->wino_m; m.ws = ws;
-  m.B = 1; m.Hi = 1; m.Wi = (int)(16 * prow); m.ldx = c.cin; m.Kc = c.cin;
+  m.x = e->wino_V[ci]; m.w = e->wino_U[ci]; m.y = e->wino_m; m.ws = ws; m.nplanes = wg.np;
+  m.B = 1; m.Hi = 1; m.Wi = (int)(wg.np * prow); m.ldx = c.cin; m.Kc = c.cin;
   m.Ho = 1; m.Wo = m.Wi; m.N = c.cout; m.ldy = c.cout; m.KH = m.KW = 1; m.mul = 1;
   m.M = m.Wi; m.wN = c.cout; m.wK = c.cin; m.plane_rows = (int)prow; m.w_plane = (long)c.cout * c.cin;
   return m;
@@ -352,14 +365,23 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     const WinoGeom wg = wino_geom(c, B, a.Ho, a.Wo);
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
-    launch_wino_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
-    launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
+    if (wg.tm == 4) {
+      launch_wino4_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
+      launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, prow, e->wino_V[ci], st);
+    } else {
+      launch_wino_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
+      launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
+    }
     e->wino_v_batch[ci] = B;
-    ConvArgs m = wino_fwd_gemm(e, ci, prow, a.ws);
+    ConvArgs m = wino_fwd_gemm(e, ci, wg, a.ws);
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
-    launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
-                       (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
+    if (wg.tm == 4)
+      launch_wino4_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
+                          (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
+    else
+      launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
+                         (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
     if (gn)
       launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
                         a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st);
@@ -400,13 +422,17 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     const WinoGeom wg = wino_geom(c, B, Hin, Win);
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
-    if (e->wino_dm_batch[ci] != B) launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
+    if (e->wino_dm_batch[ci] != B) {
+      if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Hin, Win, th, tw, prow, e->wino_dM[ci], e->s);
+      else launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
+    }
     e->wino_dm_batch[ci] = 0;
-    launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->s);
+    if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->s);
+    else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->s);
     ConvArgs m;
     memset(&m, 0, sizeof(m));
-    m.x = e->wino_dM[ci]; m.w = e->wino_U[ci]; m.y = e->wino_dv; m.ws = e->ws_conv;
-    m.B = 1; m.Hi = 1; m.Wi = (int)(16 * prow); m.ldx = c.cout; m.Kc = c.cout;
+    m.x = e->wino_dM[ci]; m.w = e->wino_U[ci]; m.y = e->wino_dv; m.ws = e->ws_conv; m.nplanes = wg.np;
+    m.B = 1; m.Hi = 1; m.Wi = (int)(wg.np * prow); m.ldx = c.cout; m.Kc = c.cout;
     m.Ho = 1; m.Wo = m.Wi; m.N = c.cin; m.ldy = c.cin; m.KH = m.KW = 1; m.mul = 1;
     m.M = m.Wi; m.wN = c.cout; m.wK = c.cin; m.kmajor = 1; m.plane_rows = (int)prow; m.w_plane = (long)c.cout * c.cin;
     const int tailw = m.N % 128;
@@ -422,7 +448,10 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
       trace("dgrad", ci, m.M, m.N, c.cout, conv_plan(m));
       launch_conv(m, e->s);
     }
-    launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
+    if (wg.tm == 4)
+      launch_wino4_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
+    else
+      launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
     return;
   }
   if (c.k == 1 && c.stride == 2 && !add) {
@@ -464,7 +493,8 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   const bool wino = wino_on(e, ci, B, Ho, Wo);
   if (wino) {                       // dM feeds this weight gradient (side stream) and the data gradient (main stream)
     const WinoGeom wg = wino_geom(c, B, Ho, Wo);
-    launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
+    if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.prow, e->wino_dM[ci], e->s);
+    else launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
     e->wino_dm_batch[ci] = B;
   }
   hipStream_t ws = e->s;
@@ -482,16 +512,20 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     const int th = wg.th, tw = wg.tw;
     const long ntile = wg.ntile, prow = wg.prow;
     float* V = e->wino_V[ci];
-    if (e->wino_v_batch[ci] != B) launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, wg.d, prow, V, ws);   // else: from the forward
+    if (e->wino_v_batch[ci] != B) {                       // else: V comes from the forward pass
+      if (wg.tm == 4) launch_wino4_input(x, ldx, c.cin, B, Hin, Win, th, tw, prow, V, ws);
+      else launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, wg.d, prow, V, ws);
+    }
     float* final_slab = e->ws_wg + e->ws_off[ci];
     a.g = e->wino_dM[ci]; a.x = V; a.ws = final_slab + c.wsize();
     a.B = 1; a.Ho = 1; a.Wo = (int)ntile; a.ldg = c.cout; a.Cout = c.cout; a.Hi = 1; a.Wi = (int)ntile; a.ldx = c.cin; a.Cin = c.cin;
-    a.KH = a.KW = 4; a.stride = 1; a.pad = 0; a.dil = 0;          // 16 "taps" = Winograd positions, no pixel shift
+    a.KH = a.KW = wg.tm + 2; a.stride = 1; a.pad = 0; a.dil = 0;  // the "taps" are the Winograd positions, no pixel shift
     a.g_tap_stride = prow * c.cout; a.x_tap_stride = prow * c.cin;
-    a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, 16);
-    trace("wgrad", ci, c.cout, (long)c.cin * 16, ntile, a.splits);
+    a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, wg.np);
+    trace("wgrad", ci, c.cout, (long)c.cin * wg.np, ntile, a.splits);
     launch_wgrad(a, ws);
-    launch_wino_wgrad_finish(a.ws, a.splits, c.cout, c.cin, final_slab, ws);
+    if (wg.tm == 4) launch_wino4_wgrad_finish(a.ws, a.splits, c.cout, c.cin, final_slab, ws);
+    else launch_wino_wgrad_finish(a.ws, a.splits, c.cout, c.cin, final_slab, ws);
     return 1;
   }
   a.g = g; a.x = x; a.ws = e->ws_wg + e->ws_off[ci];
@@ -637,14 +671,17 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
                                 (long long)wino_geom(c, B, Ho, Wo).ntile * c.cin * c.cout >= EOSVOS_WINO_MINWORK);
 #endif
     if (reserve) {                     // [final 9-tap slab][Winograd-domain slabs: splits x cout x 16 x cin]
-      for (int b = 1; b <= B; ++b)
-        slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits((int)wino_geom(c, b, Ho, Wo).ntile, c.cout, c.cin, 16) * c.cout * 16 * c.cin);
-      const int64_t prow = wino_geom(c, B, Ho, Wo).prow;
-      e->wino_V[ci] = e->falloc(16 * prow * c.cin);
-      e->wino_U[ci] = e->falloc((int64_t)16 * c.cout * c.cin);
-      e->wino_dM[ci] = e->falloc(16 * prow * c.cout);
+      for (int b = 1; b <= B; ++b) {
+        const WinoGeom gb = wino_geom(c, b, Ho, Wo);
+        slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits((int)gb.ntile, c.cout, c.cin, gb.np) * c.cout * gb.np * c.cin);
+      }
+      const WinoGeom gm = wino_geom(c, B, Ho, Wo);
+      const int64_t prow = gm.prow, np = gm.np;
+      e->wino_V[ci] = e->falloc(np * prow * c.cin);
+      e->wino_U[ci] = e->falloc(np * c.cout * c.cin);
+      e->wino_dM[ci] = e->falloc(np * prow * c.cout);
       e->wino_v_batch[ci] = 0; e->wino_dm_batch[ci] = 0;
-      e->wino_m_n = max64(e->wino_m_n, 16 * prow * max64(c.cout, c.cin));
+      e->wino_m_n = max64(e->wino_m_n, np * prow * max64(c.cout, c.cin));
     }
     (void)Mf;
     if (e->gn() && c.norm) {
@@ -1333,12 +1370,12 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
     // the step runs this layer in the Winograd domain: time its batched GEMM launch (+ fix-up), the largest
     // conv_igemm launch of an iteration, against the GEMM's own FLOPs
     const WinoGeom wg = wino_geom(c, batch, e->h4, e->w4);
-    const long ntile = wg.ntile, prow = wg.prow;
-    ConvArgs m = wino_fwd_gemm(e, t.dec_a, prow, e->ws_conv);
+    const long ntile = wg.ntile;
+    ConvArgs m = wino_fwd_gemm(e, t.dec_a, wg, e->ws_conv);
     HIPOK(hipEventRecord(a, e->s));
     for (int i = 0; i < reps; ++i) { ConvArgs k = m; launch_conv(k, e->s); }
     HIPOK(hipEventRecord(b, e->s));
-    *flops_host = 2.0 * 16.0 * (double)ntile * c.cout * c.cin;
+    *flops_host = 2.0 * wg.np * (double)ntile * c.cout * c.cin;
   } else {
     HIPOK(hipEventRecord(a, e->s));
     for (int i = 0; i < reps; ++i) conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, batch, nullptr, 0, true);

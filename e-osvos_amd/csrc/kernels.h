@@ -43,6 +43,7 @@ struct ConvArgs {
   int accum;            // dgrad: add the existing contents of y
   int plane_rows;       // != 0: batched GEMM -- rows [k*plane_rows, (k+1)*plane_rows) use the weights w + k*w_plane
   long w_plane;
+  int nplanes;          // planes of a batched GEMM (16: Winograd F(2,3); 36: F(4,3))
   int par;              // 1: GEMM rows enumerate the Ho x Wo grid parity class by parity class (stride-2 3x3 dgrad)
   int dst_up, Hf, Wf;   // dst_up=1: GEMM row (b,oy,ox) is written to pixel (b,2oy,2ox) of an Hf x Wf grid
   const int* tprefix;   // optional (device): compacted K-step prefix per tile (tiles+1), see conv_build_tap_table
@@ -102,7 +103,16 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T);
 // dil: dilation of the 3x3 conv = dil*dil interleaved sub-grids; tiles are (image, sy, sx, ty, tx), th x tw per sub-grid
 void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V, hipStream_t s);
 void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M, hipStream_t s);
-void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);   // U = G (rowscale*w) G^T
+void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);
+// Winograd F(4x4,3x3), undilated: 36 planes, th x tw tiles of 4x4 outputs per image
+void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V, hipStream_t s);
+void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M, hipStream_t s);
+void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);
+void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+                         const float* bias, int relu, float* y, int ldy, hipStream_t s);
+void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
+void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
+                               int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // U = G (rowscale*w) G^T
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,

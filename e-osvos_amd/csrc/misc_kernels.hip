@@ -1586,3 +1586,358 @@ void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, fl
   hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, ws, splits, Cout, Cin, dst);
 }
 }  // namespace eosvos
+
+// ---- Winograd F(4x4, 3x3): the decoder's two 3x3 convs on the stride-4 map -------------------------------------
+// Same structure as F(2x2,3x3) above with 6x6 patches / 36 positions and 4x4 output tiles: 2.25 MACs per output
+// and (cin, cout) pair instead of 4 (and 9 for the direct form), transform-domain tensors 0.56x the F(2,3) size.
+// Interpolation points 0, +-1, +-2, inf (Lavin & Gray); fp32 rounding error of one conv ~2e-6 rms of the output
+// scale (direct fp32: 1e-7, F(2,3): 3e-7) -- far inside the 1e-3 logit tolerance.  Undilated, stride 1, pad 1 only.
+namespace eosvos {
+namespace w4 {
+__device__ constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                       {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+__device__ constexpr float G[6][3] = {{0.25f, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                      {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+__device__ constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+__device__ __forceinline__ void fma4(float4& acc, float c, const float4& v) {
+  acc.x = fmaf(c, v.x, acc.x); acc.y = fmaf(c, v.y, acc.y); acc.z = fmaf(c, v.z, acc.z); acc.w = fmaf(c, v.w, acc.w);
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+}  // namespace w4
+
+// tile decode shared by the F(4,3) kernels: tile = (image, ty, tx), th x tw tiles of 4x4 outputs per image
+#define W4_TILE_DECODE                                                   \
+  const int c4 = (int)(e % C4);                                          \
+  const long tile = e / C4;                                              \
+  const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+
+// V[p][tile][c] = B^T d B, d = 6x6 patch rows 4ty-1..4ty+4, cols 4tx-1..4tx+4 (zero outside)
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ldx, int C, int B, int H, int W,
+                                                           int th, int tw, long prow, float* __restrict__ V) {
+  const int C4 = C >> 2;
+  const long n = (long)B * th * tw * C4;
+  GRID_STRIDE(e, n) {
+    W4_TILE_DECODE
+    float4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int yy = 4 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int xx = 4 * tx - 1 + j;
+        d[i][j] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                      ? *reinterpret_cast<const float4*>(x + (((long)b * H + yy) * W + xx) * ldx + c4 * 4)
+                      : w4::zero4();
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {          // columns: d[:, j] <- B^T d[:, j]
+      float4 t[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        t[i] = w4::zero4();
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+          if (w4::BT[i][a] != 0.f) w4::fma4(t[i], w4::BT[i][a], d[a][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i][j] = t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {          // rows: V[i, :] = B^T applied along the row
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float4 v = w4::zero4();
+#pragma unroll
+        for (int bb = 0; bb < 6; ++bb)
+          if (w4::BT[j][bb] != 0.f) w4::fma4(v, w4::BT[j][bb], d[i][bb]);
+        *reinterpret_cast<float4*>(V + ((long)(i * 6 + j) * prow + tile) * C + c4 * 4) = v;
+      }
+    }
+  }
+}
+// dM[p][tile][c] = A dY A^T, dY = the tile's 4x4 outputs (zero outside), A = AT^T
+__global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
+                                                          int th, int tw, long prow, float* __restrict__ M) {
+  const int C4 = C >> 2;
+  const long n = (long)B * th * tw * C4;
+  GRID_STRIDE(e, n) {
+    W4_TILE_DECODE
+    float4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int yy = 4 * ty + i, xx = 4 * tx + j;
+        d[i][j] = (yy < H && xx < W) ? *reinterpret_cast<const float4*>(g + (((long)b * H + yy) * W + xx) * ldg + c4 * 4)
+                                     : w4::zero4();
+      }
+    float4 t[6][4];                        // t = A d : t[a][j] = sum_r AT[r][a] d[r][j]
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[a][j] = w4::zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (w4::AT[r][a] != 0.f) w4::fma4(t[a][j], w4::AT[r][a], d[r][j]);
+      }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) {     // dM[a][bb] = sum_r t[a][r] AT[r][bb]
+        float4 v = w4::zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (w4::AT[r][bb] != 0.f) w4::fma4(v, w4::AT[r][bb], t[a][r]);
+        *reinterpret_cast<float4*>(M + ((long)(a * 6 + bb) * prow + tile) * C + c4 * 4) = v;
+      }
+  }
+}
+// U[p][cout][cin] = G (rowscale * w) G^T
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                            const float* __restrict__ rowscale, float* __restrict__ U) {
+  const int C4 = Cin >> 2;
+  const long n = (long)Cout * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4), co = (int)(e / C4);
+    const float rs = rowscale ? rowscale[co] : 1.f;
+    float4 g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float4 v = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
+      v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+      g[t / 3][t % 3] = v;
+    }
+    float4 t[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        t[a][j] = w4::zero4();
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (w4::G[a][r] != 0.f) w4::fma4(t[a][j], w4::G[a][r], g[r][j]);
+      }
+    const size_t ps = (size_t)Cout * Cin;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) {
+        float4 v = w4::zero4();
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (w4::G[bb][r] != 0.f) w4::fma4(v, w4::G[bb][r], t[a][r]);
+        *reinterpret_cast<float4*>(U + (size_t)(a * 6 + bb) * ps + (size_t)co * Cin + c4 * 4) = v;
+      }
+  }
+}
+// y = relu?(scale * (A^T M A) + bias), 4x4 outputs per tile
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
+                                                            int th, int tw, const float* __restrict__ scale,
+                                                            const float* __restrict__ bias, int relu, float* __restrict__ y,
+                                                            int ldy) {
+  const int C4 = C >> 2;
+  const long n = (long)B * th * tw * C4;
+  GRID_STRIDE(e, n) {
+    W4_TILE_DECODE
+    float4 t[4][6];                        // t = A^T m, streamed over the rows a of m
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t[r][j] = w4::zero4();
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float4 m = *reinterpret_cast<const float4*>(M + ((long)(a * 6 + j) * prow + tile) * C + c4 * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (w4::AT[r][a] != 0.f) w4::fma4(t[r][j], w4::AT[r][a], m);
+      }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = w4::zero4();
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
+    if (bias) bi = *reinterpret_cast<const float4*>(bias + c4 * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yy = 4 * ty + r;
+      if (yy >= H) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int xx = 4 * tx + q;
+        if (xx >= W) continue;
+        float4 v = w4::zero4();
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (w4::AT[q][j] != 0.f) w4::fma4(v, w4::AT[q][j], t[r][j]);
+        if (scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+        if (bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(y + (((long)b * H + yy) * W + xx) * ldy + c4 * 4) = v;
+      }
+    }
+  }
+}
+// dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][6x6][cin]) G
+__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ ws, int splits, int Cout, int Cin,
+                                                                  float* __restrict__ dst) {
+  const int C4 = Cin >> 2;
+  const long n = (long)Cout * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4), co = (int)(e / C4);
+    float4 t[3][6];                        // t = G^T u, streamed over the rows a of u (each summed over the splits)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t[r][j] = w4::zero4();
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float4 u = w4::zero4();
+        for (int z = 0; z < splits; ++z) {
+          const float4 v = *reinterpret_cast<const float4*>(ws + (((size_t)z * Cout + co) * 36 + (a * 6 + j)) * Cin + c4 * 4);
+          u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (w4::G[a][r] != 0.f) w4::fma4(t[r][j], w4::G[a][r], u);
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        float4 v = w4::zero4();
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (w4::G[j][q] != 0.f) w4::fma4(v, w4::G[j][q], t[r][j]);
+        *reinterpret_cast<float4*>(dst + ((size_t)co * 9 + r * 3 + q) * Cin + c4 * 4) = v;
+      }
+  }
+}
+// dX = mask?(accum + overlap-add of B dV B^T), gather form: one thread per 4x4 pixel block (= tile position) and 4
+// channels.  Block (k, l) takes patch rows i = 1..4 of tile k, i = 5 of tile k-1 (its row 0) and i = 0 of tile k+1
+// (its row 3); columns likewise.  B[i][a] = BT[a][i].
+__global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
+                                                                  int W, int th, int tw, const float* __restrict__ mask,
+                                                                  int ldmask, int mask_c0, int accum,
+                                                                  float* __restrict__ gx, int ldgx) {
+  const int C4 = C >> 2;
+  const long n = (long)B * th * tw * C4;
+  GRID_STRIDE(e, n) {
+    const int c4 = (int)(e % C4);
+    const long blk = e / C4;
+    const int l = (int)(blk % tw), k = (int)((blk / tw) % th), b = (int)(blk / ((long)tw * th));
+    float4 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[r][q] = w4::zero4();
+#pragma unroll
+    for (int dk = -1; dk <= 1; ++dk) {
+      const int ty = k + dk;
+      if ((unsigned)ty >= (unsigned)th) continue;
+#pragma unroll
+      for (int dl = -1; dl <= 1; ++dl) {
+        const int tx = l + dl;
+        if ((unsigned)tx >= (unsigned)tw) continue;
+        const long tile = ((long)b * th + ty) * tw + tx;
+        // patch rows of this tile that land in the block: dk = -1 -> {5}, 0 -> {1..4}, +1 -> {0}; output row r(i)
+        constexpr int NI_C = 4;
+        const int ni = dk == 0 ? NI_C : 1, nj = dl == 0 ? NI_C : 1;
+        // t[ii][bb] = sum_a B[i][a] dV[a][bb]   for the needed i, streamed over a
+        float4 t[4][6];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int bb = 0; bb < 6; ++bb) t[ii][bb] = w4::zero4();
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          // is row a needed by any of the i rows?  (i = 5: a = 5 only; i = 0: a = 0 only; centre: every a)
+          if (dk < 0 && a != 5) continue;
+          if (dk > 0 && a != 0) continue;
+#pragma unroll
+          for (int bb = 0; bb < 6; ++bb) {
+            if (dl < 0 && bb != 5) continue;
+            if (dl > 0 && bb != 0) continue;
+            const float4 v = *reinterpret_cast<const float4*>(dV + ((long)(a * 6 + bb) * prow + tile) * C + c4 * 4);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+              if (ii >= ni) continue;
+              const int i = dk < 0 ? 5 : (dk > 0 ? 0 : 1 + ii);
+              if (w4::BT[a][i] != 0.f) w4::fma4(t[ii][bb], w4::BT[a][i], v);
+            }
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          if (ii >= ni) continue;
+          const int r = dk < 0 ? 0 : (dk > 0 ? 3 : ii);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            if (jj >= nj) continue;
+            const int j = dl < 0 ? 5 : (dl > 0 ? 0 : 1 + jj);
+            const int q = dl < 0 ? 0 : (dl > 0 ? 3 : jj);
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) {
+              if (dl < 0 && bb != 5) continue;
+              if (dl > 0 && bb != 0) continue;
+              if (w4::BT[bb][j] != 0.f) w4::fma4(acc[r][q], w4::BT[bb][j], t[ii][bb]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yy = 4 * k + r;
+      if (yy >= H) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int xx = 4 * l + q;
+        if (xx >= W) continue;
+        const long pix = ((long)b * H + yy) * W + xx;
+        float4 v = acc[r][q];
+        if (accum) {
+          const float4 o = *reinterpret_cast<const float4*>(gx + pix * ldgx + c4 * 4);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (mask && c4 * 4 >= mask_c0) {
+          const float4 m = *reinterpret_cast<const float4*>(mask + pix * ldmask + c4 * 4);
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(gx + pix * ldgx + c4 * 4) = v;
+      }
+    }
+  }
+}
+#undef W4_TILE_DECODE
+void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V, hipStream_t s) {
+  const long n = (long)B * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, prow, V);
+}
+void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M, hipStream_t s) {
+  const long n = (long)B * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino4_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, prow, M);
+}
+void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s) {
+  const long n = (long)Cout * (Cin / 4);
+  hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U);
+}
+void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+                         const float* bias, int relu, float* y, int ldy, hipStream_t s) {
+  const long n = (long)B * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, scale,
+                     bias, relu, y, ldy);
+}
+void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
+  const long n = (long)Cout * (Cin / 4);
+  hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, ws, splits, Cout, Cin, dst);
+}
+void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
+                               int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s) {
+  const long n = (long)B * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino4_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
+                     mask, ldmask, mask_c0, accum, gx, ldgx);
+}
+}  // namespace eosvos
