@@ -294,12 +294,15 @@ void trace(const char* kind, int ci, long M, long N, long K, int splits) {
 struct WinoGeom { int th, tw, d, tm, np; long ntile, prow; };
 // F(4x4,3x3) (36 positions, 2.25 MACs per output) for undilated convs on maps of >= 64 x 64 outputs -- the decoder --
 // where 4x4 tiles waste little at the border; F(2x2,3x3) (16 positions, 4 MACs per output) otherwise.
+#ifndef EOSVOS_WINO_F4_MINDIM
+#define EOSVOS_WINO_F4_MINDIM 64
+#endif
 bool wino_f4(const ConvL& c, int Ho, int Wo) {
 #ifdef EOSVOS_NO_WINO_F4
   (void)c; (void)Ho; (void)Wo;
   return false;
 #else
-  return c.dil == 1 && Ho >= 64 && Wo >= 64;
+  return c.dil == 1 && Ho >= EOSVOS_WINO_F4_MINDIM && Wo >= EOSVOS_WINO_F4_MINDIM;
 #endif
 }
 WinoGeom wino_geom(const ConvL& c, int B, int Ho, int Wo) {
@@ -328,8 +331,7 @@ bool wino_on(const eosvos_engine* e, int ci, int B, int Ho, int Wo) {
   if (!wino_shape(c)) return false;
   if (ci == e->t.dec_a || ci == e->t.dec_b) return true;
   if (e->wino_V.find(ci) == e->wino_V.end()) return false;            // no buffers were reserved for it
-  const WinoGeom g = wino_geom(c, B, Ho, Wo);
-  return (long long)g.ntile * c.cin * c.cout >= EOSVOS_WINO_MINWORK;
+  return (long long)B * Ho * Wo / 4 * c.cin * c.cout >= EOSVOS_WINO_MINWORK;      // MACs of one F(2,3) position
 #endif
 }
 // The batched GEMM of a Winograd forward: rows = 16 planes x prow tiles of V, weights U[p] per plane -> M planes
@@ -668,7 +670,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     bool reserve = false;
 #ifndef EOSVOS_NO_WINO
     reserve = wino_shape(c) && (ci == t.dec_a || ci == t.dec_b ||
-                                (long long)wino_geom(c, B, Ho, Wo).ntile * c.cin * c.cout >= EOSVOS_WINO_MINWORK);
+                                (long long)B * Ho * Wo / 4 * c.cin * c.cout >= EOSVOS_WINO_MINWORK);
 #endif
     if (reserve) {                     // [final 9-tap slab][Winograd-domain slabs: splits x cout x 16 x cin]
       for (int b = 1; b <= B; ++b) {
