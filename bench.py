@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 H, W, BATCH = 480, 854, 3
 FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
-HOT_KERNEL_TRAFFIC_BYTES = (2 * 210.4e3 + 352.3e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
+HOT_KERNEL_TRAFFIC_BYTES = (2 * 126.9e3 + 220.4e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
 
 
 def cpu_baseline(sd, lrs, x, y, seconds_budget=25.0):
@@ -168,13 +168,13 @@ def main():
     # dominant kernel, timed live with HIP events on the engine's stream
     k_ms, k_flops = eng.time_hot_kernel(BATCH, reps=20)
     achieved = k_flops / (k_ms * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,2>: the largest conv launch of an iteration = batched GEMM '
-                'of decoder.last_conv.0 forward in the Winograd F(2x2,3x3) domain, 16 x [19260 tiles x 304] x [304 x 256] '
-                '(+ its fix-up launch); achieved counts this GEMM\'s own FLOPs (2.25x fewer than the 9-tap form)', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
+    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,2>: batched GEMM of decoder.last_conv.0 forward in the Winograd '
+                'F(4x4,3x3) domain, 36 x [4860 tiles x 304] x [304 x 256] (+ its fix-up launch), the heaviest layer of the '
+                'network; achieved counts this GEMM\'s own FLOPs (4x fewer than the 9-tap form of the layer)', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MATRIX_PEAK,
                 # bytes per launch from the rocprofv3 --pmc passes of this kernel (separate runs,
                 # profiles/r01_pmc_hot_kernel.txt): 2*FETCH_SIZE (gfx950 half-count correction) +
-                # WRITE_SIZE; algorithmic bytes are 376 MB V + 5 MB U in, 317 MB M out
+                # WRITE_SIZE; algorithmic bytes are 213 MB V + 11 MB U in, 179 MB M out
                 'traffic': HOT_KERNEL_TRAFFIC_BYTES if BATCH == 3 else None, 'kernel_ms': k_ms,
                 'flops_per_launch': k_flops,
                 'whole_step_tflops': BATCH * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12}

@@ -1791,18 +1791,24 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
 #pragma unroll
       for (int j = 0; j < 6; ++j) t[r][j] = w4::zero4();
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < 6; ++a) {
+      float4 u[6];                         // one row of dU, its 6 loads per split in flight together
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        float4 u = w4::zero4();
-        for (int z = 0; z < splits; ++z) {
-          const float4 v = *reinterpret_cast<const float4*>(ws + (((size_t)z * Cout + co) * 36 + (a * 6 + j)) * Cin + c4 * 4);
-          u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
-        }
+      for (int j = 0; j < 6; ++j) u[j] = w4::zero4();
+      for (int z = 0; z < splits; ++z) {
+        float4 v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          v[j] = *reinterpret_cast<const float4*>(ws + (((size_t)z * Cout + co) * 36 + (a * 6 + j)) * Cin + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { u[j].x += v[j].x; u[j].y += v[j].y; u[j].z += v[j].z; u[j].w += v[j].w; }
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-          if (w4::G[a][r] != 0.f) w4::fma4(t[r][j], w4::G[a][r], u);
-      }
+          if (w4::G[a][r] != 0.f) w4::fma4(t[r][j], w4::G[a][r], u[j]);
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
