@@ -543,3 +543,22 @@ def test_bptt_schedules_vs_golden(small_engine, weights, golden_dir, tag, bptt, 
         r = g[tag + '_init_grad_fp'][i][1]
         assert abs(l2 - r) <= 1e-2 * r + 1e-9, (n, l2, r)
     eng.load_model_state(*weights)
+
+
+def test_groupnorm_full_size_forward_vs_oracle(weights):
+    """GroupNorm mode at 480x854 (the Winograd F(4x4,3x3) decoder path writes the raw conv output that GroupNorm then
+    normalises): logits vs the CPU oracle."""
+    from eosvos_amd.engine import Engine
+    from oracle import deeplab
+    sd, lrs = weights
+    x, y = synthetic.synthetic_frames(1, *FULL, seed=7)
+    eng = Engine('resnet50', *FULL, max_batch=1, device=DEV, norm='gn')
+    eng.load_model_state(sd, lrs)
+    out = eng.forward(x.to(DEV)).cpu()
+    with torch.no_grad():
+        ref = deeplab.forward(sd, x, norm='gn')
+    assert float((out - ref).abs().max()) < LOGIT_TOL
+    l0 = eng.finetune_step(x.to(DEV), y.to(DEV))
+    l1 = eng.finetune_step(x.to(DEV), y.to(DEV))
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0          # one step on the Winograd gradients lowers the loss
+    eng.close()
