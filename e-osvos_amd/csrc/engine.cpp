@@ -297,12 +297,17 @@ struct WinoGeom { int th, tw, d, tm, np; long ntile, prow; };
 #ifndef EOSVOS_WINO_F4_MINDIM
 #define EOSVOS_WINO_F4_MINDIM 64
 #endif
+#ifndef EOSVOS_WINO_F4_DIL
+#define EOSVOS_WINO_F4_DIL 1
+#endif
 bool wino_f4(const ConvL& c, int Ho, int Wo) {
 #ifdef EOSVOS_NO_WINO_F4
   (void)c; (void)Ho; (void)Wo;
   return false;
 #else
-  return c.dil == 1 && Ho >= EOSVOS_WINO_F4_MINDIM && Wo >= EOSVOS_WINO_F4_MINDIM;
+  // large undilated maps (the decoder), or -- EOSVOS_WINO_F4_DIL -- dilated convs whose sub-grids tile well with 4x4
+  if (c.dil == 1) return Ho >= EOSVOS_WINO_F4_MINDIM && Wo >= EOSVOS_WINO_F4_MINDIM;
+  return EOSVOS_WINO_F4_DIL && (c.dil == 2 || c.dil == 4 || c.dil == 8);
 #endif
 }
 WinoGeom wino_geom(const ConvL& c, int B, int Ho, int Wo) {
@@ -369,7 +374,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     const long prow = wg.prow;
     if (wg.tm == 4) {
       launch_wino4_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
-      launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, prow, e->wino_V[ci], st);
+      launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
     } else {
       launch_wino_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
       launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
@@ -379,7 +384,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
     if (wg.tm == 4)
-      launch_wino4_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
+      launch_wino4_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
                           (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
     else
       launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
@@ -425,7 +430,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
     if (e->wino_dm_batch[ci] != B) {
-      if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Hin, Win, th, tw, prow, e->wino_dM[ci], e->s);
+      if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
       else launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
     }
     e->wino_dm_batch[ci] = 0;
@@ -451,7 +456,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
       launch_conv(m, e->s);
     }
     if (wg.tm == 4)
-      launch_wino4_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
+      launch_wino4_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
     else
       launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
     return;
@@ -495,7 +500,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   const bool wino = wino_on(e, ci, B, Ho, Wo);
   if (wino) {                       // dM feeds this weight gradient (side stream) and the data gradient (main stream)
     const WinoGeom wg = wino_geom(c, B, Ho, Wo);
-    if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.prow, e->wino_dM[ci], e->s);
+    if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
     else launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
     e->wino_dm_batch[ci] = B;
   }
@@ -515,7 +520,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     const long ntile = wg.ntile, prow = wg.prow;
     float* V = e->wino_V[ci];
     if (e->wino_v_batch[ci] != B) {                       // else: V comes from the forward pass
-      if (wg.tm == 4) launch_wino4_input(x, ldx, c.cin, B, Hin, Win, th, tw, prow, V, ws);
+      if (wg.tm == 4) launch_wino4_input(x, ldx, c.cin, B, Hin, Win, th, tw, wg.d, prow, V, ws);
       else launch_wino_input(x, ldx, c.cin, B, Hin, Win, th, tw, wg.d, prow, V, ws);
     }
     float* final_slab = e->ws_wg + e->ws_off[ci];

@@ -104,15 +104,17 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T);
 void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V, hipStream_t s);
 void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M, hipStream_t s);
 void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);
-// Winograd F(4x4,3x3), undilated: 36 planes, th x tw tiles of 4x4 outputs per image
-void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V, hipStream_t s);
-void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M, hipStream_t s);
+// Winograd F(4x4,3x3): 36 planes, th x tw tiles of 4x4 outputs per sub-grid
+void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,
+                        hipStream_t s);
+void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M,
+                       hipStream_t s);
 void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);
-void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                          const float* bias, int relu, float* y, int ldy, hipStream_t s);
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
-void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
-                               int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // U = G (rowscale*w) G^T
+void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
+                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // U = G (rowscale*w) G^T
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,

@@ -1605,26 +1605,29 @@ __device__ __forceinline__ void fma4(float4& acc, float c, const float4& v) {
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 }  // namespace w4
 
-// tile decode shared by the F(4,3) kernels: tile = (image, ty, tx), th x tw tiles of 4x4 outputs per image
-#define W4_TILE_DECODE                                                   \
-  const int c4 = (int)(e % C4);                                          \
-  const long tile = e / C4;                                              \
-  const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th), b = (int)(tile / ((long)tw * th));
+// tile decode shared by the F(4,3) kernels: tile = (image, sy, sx, ty, tx), th x tw tiles of 4x4 outputs per sub-grid
+// of a dilated conv (dil*dil sub-grids; dil = 1: the image itself)
+#define W4_TILE_DECODE                                                                                      \
+  const int c4 = (int)(e % C4);                                                                             \
+  const long tile = e / C4;                                                                                 \
+  const int tx = (int)(tile % tw), ty = (int)((tile / tw) % th);                                            \
+  const int sx = (int)((tile / ((long)tw * th)) % dil), sy = (int)((tile / ((long)tw * th * dil)) % dil);   \
+  const int b = (int)(tile / ((long)tw * th * dil * dil));
 
 // V[p][tile][c] = B^T d B, d = 6x6 patch rows 4ty-1..4ty+4, cols 4tx-1..4tx+4 (zero outside)
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ldx, int C, int B, int H, int W,
-                                                           int th, int tw, long prow, float* __restrict__ V) {
+                                                           int th, int tw, int dil, long prow, float* __restrict__ V) {
   const int C4 = C >> 2;
-  const long n = (long)B * th * tw * C4;
+  const long n = (long)B * dil * dil * th * tw * C4;
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 d[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const int yy = 4 * ty - 1 + i;
+      const int yy = sy + dil * (4 * ty - 1 + i);
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const int xx = 4 * tx - 1 + j;
+        const int xx = sx + dil * (4 * tx - 1 + j);
         d[i][j] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
                       ? *reinterpret_cast<const float4*>(x + (((long)b * H + yy) * W + xx) * ldx + c4 * 4)
                       : w4::zero4();
@@ -1658,9 +1661,9 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
 }
 // dM[p][tile][c] = A dY A^T, dY = the tile's 4x4 outputs (zero outside), A = AT^T
 __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
-                                                          int th, int tw, long prow, float* __restrict__ M) {
+                                                          int th, int tw, int dil, long prow, float* __restrict__ M) {
   const int C4 = C >> 2;
-  const long n = (long)B * th * tw * C4;
+  const long n = (long)B * dil * dil * th * tw * C4;
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 d[4][4];
@@ -1668,7 +1671,7 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int yy = 4 * ty + i, xx = 4 * tx + j;
+        const int yy = sy + dil * (4 * ty + i), xx = sx + dil * (4 * tx + j);
         d[i][j] = (yy < H && xx < W) ? *reinterpret_cast<const float4*>(g + (((long)b * H + yy) * W + xx) * ldg + c4 * 4)
                                      : w4::zero4();
       }
@@ -1734,11 +1737,11 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
 }
 // y = relu?(scale * (A^T M A) + bias), 4x4 outputs per tile
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
-                                                            int th, int tw, const float* __restrict__ scale,
+                                                            int th, int tw, int dil, const float* __restrict__ scale,
                                                             const float* __restrict__ bias, int relu, float* __restrict__ y,
                                                             int ldy) {
   const int C4 = C >> 2;
-  const long n = (long)B * th * tw * C4;
+  const long n = (long)B * dil * dil * th * tw * C4;
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 t[4][6];                        // t = A^T m, streamed over the rows a of m
@@ -1760,11 +1763,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     if (bias) bi = *reinterpret_cast<const float4*>(bias + c4 * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int yy = 4 * ty + r;
+      const int yy = sy + dil * (4 * ty + r);
       if (yy >= H) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int xx = 4 * tx + q;
+        const int xx = sx + dil * (4 * tx + q);
         if (xx >= W) continue;
         float4 v = w4::zero4();
 #pragma unroll
@@ -1825,15 +1828,17 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
 // channels.  Block (k, l) takes patch rows i = 1..4 of tile k, i = 5 of tile k-1 (its row 0) and i = 0 of tile k+1
 // (its row 3); columns likewise.  B[i][a] = BT[a][i].
 __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
-                                                                  int W, int th, int tw, const float* __restrict__ mask,
-                                                                  int ldmask, int mask_c0, int accum,
-                                                                  float* __restrict__ gx, int ldgx) {
+                                                                  int W, int th, int tw, int dil,
+                                                                  const float* __restrict__ mask, int ldmask, int mask_c0,
+                                                                  int accum, float* __restrict__ gx, int ldgx) {
   const int C4 = C >> 2;
-  const long n = (long)B * th * tw * C4;
+  const long n = (long)B * dil * dil * th * tw * C4;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long blk = e / C4;
-    const int l = (int)(blk % tw), k = (int)((blk / tw) % th), b = (int)(blk / ((long)tw * th));
+    const int l = (int)(blk % tw), k = (int)((blk / tw) % th);
+    const int sx = (int)((blk / ((long)tw * th)) % dil), sy = (int)((blk / ((long)tw * th * dil)) % dil);
+    const int b = (int)(blk / ((long)tw * th * dil * dil));
     float4 acc[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1847,7 +1852,7 @@ __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __
       for (int dl = -1; dl <= 1; ++dl) {
         const int tx = l + dl;
         if ((unsigned)tx >= (unsigned)tw) continue;
-        const long tile = ((long)b * th + ty) * tw + tx;
+        const long tile = ((((long)b * dil + sy) * dil + sx) * th + ty) * tw + tx;
         // patch rows of this tile that land in the block: dk = -1 -> {5}, 0 -> {1..4}, +1 -> {0}; output row r(i)
         constexpr int NI_C = 4;
         const int ni = dk == 0 ? NI_C : 1, nj = dl == 0 ? NI_C : 1;
@@ -1896,11 +1901,11 @@ __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int yy = 4 * k + r;
+      const int yy = sy + dil * (4 * k + r);
       if (yy >= H) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int xx = 4 * l + q;
+        const int xx = sx + dil * (4 * l + q);
         if (xx >= W) continue;
         const long pix = ((long)b * H + yy) * W + xx;
         float4 v = acc[r][q];
@@ -1918,32 +1923,34 @@ __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __
   }
 }
 #undef W4_TILE_DECODE
-void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, long prow, float* V, hipStream_t s) {
-  const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, prow, V);
+void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,
+                        hipStream_t s) {
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, dil, prow, V);
 }
-void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, long prow, float* M, hipStream_t s) {
-  const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino4_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, prow, M);
+void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M,
+                       hipStream_t s) {
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino4_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M);
 }
 void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
   hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U);
 }
-void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, const float* scale,
+void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                          const float* bias, int relu, float* y, int ldy, hipStream_t s) {
-  const long n = (long)B * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, scale,
-                     bias, relu, y, ldy);
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
+  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, dil,
+                     scale, bias, relu, y, ldy);
 }
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
   hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, ws, splits, Cout, Cin, dst);
 }
-void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, const float* mask,
-                               int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s) {
-  const long n = (long)B * th * tw * (C / 4);
+void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
+                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s) {
+  const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino4_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
-                     mask, ldmask, mask_c0, accum, gx, ldgx);
+                     dil, mask, ldmask, mask_c0, accum, gx, ldgx);
 }
 }  // namespace eosvos
