@@ -179,7 +179,11 @@ def main():
                 'flops_per_launch': k_flops,
                 'whole_step_tflops': BATCH * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12}
 
-    extra = {'last_loss': last_loss, 'mfma_probe_tflops': eng.mfma_probe()}
+    extra = {'last_loss': last_loss, 'mfma_probe_tflops': eng.mfma_probe(),
+             'conv_algorithms': 'fp32 throughout; 6 of the 63 convs (decoder 3x3 x2, layer4 conv2 x3: Winograd F(4x4,3x3); '
+                                'ASPP d=6: F(2x2,3x3)) run forward, data and weight gradient in the Winograd domain, the rest '
+                                'as implicit GEMM; whole_step_tflops counts 9-tap-equivalent FLOPs; full-size parity margins '
+                                'in profiles/r01_parity_margins_full_size.txt'}
     if not a.no_meta:
         # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4])
         mt = MetaTrainer(eng, dist=dist, meta_batch_size=world)
