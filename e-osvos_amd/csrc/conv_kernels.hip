@@ -14,7 +14,9 @@
 // NHWC activations make the K dimension (input channels of one filter tap) contiguous for
 // the gathered operand, so no im2col buffer is ever materialised and 1x1, 3x3, dilated
 // and strided convolutions (and their data gradients, through the fractional-stride
-// gather) are the same kernel.
+// gather) are the same kernel.  The same kernels also run the batched GEMMs of the
+// Winograd-domain convolutions (ConvArgs::plane_rows, WgradArgs::*_tap_stride; transforms
+// in misc_kernels.hip, selection in engine.cpp wino_on()).
 #include "kernels.h"
 
 #include <vector>

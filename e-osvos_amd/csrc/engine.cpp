@@ -5,7 +5,8 @@
 // Reference semantics (files under /root/reference/src):
 //   forward   networks/deeplabv3plus.py:32-53,84-93,282-301 (+ torchvision ResNet/ASPP)
 //   norm      BatchNorm in eval mode with frozen affine (deeplabv3plus.py:148-155,259-265)
-//             == per-channel a*x+b, fused into every conv epilogue
+//             == per-channel a*x+b, fused into every conv epilogue; GroupNorm(16) mode (:180-191)
+//   convs     implicit GEMM; the heavy 3x3 / stride-1 layers in the Winograd F(4x4,3x3) / F(2x2,3x3) domain
 //   loss      helper_func.py:32-37 (BCEWithLogits, mean)
 //   step      meta_optim/meta_optim.py:177-214 + meta_model.py:78-80
 //   meta-grad util/meta_run.py:109-238 (first-order BPTT, closed form of SURVEY 3.3)
