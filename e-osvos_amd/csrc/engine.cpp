@@ -190,9 +190,10 @@ struct eosvos_engine {
   // Winograd F(2x2,3x3) path of the decoder's 3x3 convs: per conv the transformed input planes V (made by the
   // forward pass, reused by the weight gradient) and transformed weights U; one shared buffer for the
   // output-domain planes (forward: M, backward: dM)
-  std::map<int, float*> wino_V, wino_U, wino_dM;  // dM = A dY A^T: made once per backward, read by wgrad and dgrad
+  std::map<int, float*> wino_V, wino_U, wino_Us, wino_dM;   // Us = a[cout] * U (data gradient), made with U  // dM = A dY A^T: made once per backward, read by wgrad and dgrad
   std::map<int, int> wino_v_batch;                // batch size V was computed for (0 = stale)
   std::map<int, int> wino_dm_batch;               // batch size dM is valid for (0 = stale)
+  std::map<int, int> wino_us_valid;               // Us matches the current weights (set by the forward, cleared by an update)
   float *wino_m = nullptr, *wino_dv = nullptr;    // forward M planes; data-gradient dV planes (transient)
   int64_t wino_m_n = 0;
   int norm_mode = 0;                  // EOSVOS_NORM_BN_FROZEN / EOSVOS_NORM_GN16
@@ -226,6 +227,11 @@ struct eosvos_engine {
 };
 
 namespace {
+
+// the weights changed: the scaled Winograd weights a[cout] * U of the last forward are stale
+void wino_weights_changed(eosvos_engine* e) {
+  for (auto& kv : e->wino_us_valid) kv.second = 0;
+}
 
 int upload_resize(eosvos_engine* e, const HostResize& h, int in, int out, ResizeTab& tab) {
   int* ib = (int*)e->falloc(2 * out + 2 * in);
@@ -373,11 +379,12 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     const WinoGeom wg = wino_geom(c, B, a.Ho, a.Wo);
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
+    e->wino_us_valid[ci] = 1;
     if (wg.tm == 4) {
-      launch_wino4_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
+      launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
       launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
     } else {
-      launch_wino_weight(e->W_(ci), c.cout, c.cin, nullptr, e->wino_U[ci], st);
+      launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
       launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
     }
     e->wino_v_batch[ci] = B;
@@ -435,11 +442,13 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
       else launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
     }
     e->wino_dm_batch[ci] = 0;
-    if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->s);
-    else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->s);
+    if (!e->wino_us_valid[ci]) {                     // no forward since the weights changed: rebuild a[cout] * U
+      if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s);
+      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s);
+    }
     ConvArgs m;
     memset(&m, 0, sizeof(m));
-    m.x = e->wino_dM[ci]; m.w = e->wino_U[ci]; m.y = e->wino_dv; m.ws = e->ws_conv; m.nplanes = wg.np;
+    m.x = e->wino_dM[ci]; m.w = e->wino_Us[ci]; m.y = e->wino_dv; m.ws = e->ws_conv; m.nplanes = wg.np;
     m.B = 1; m.Hi = 1; m.Wi = (int)(wg.np * prow); m.ldx = c.cout; m.Kc = c.cout;
     m.Ho = 1; m.Wo = m.Wi; m.N = c.cin; m.ldy = c.cin; m.KH = m.KW = 1; m.mul = 1;
     m.M = m.Wi; m.wN = c.cout; m.wK = c.cin; m.kmajor = 1; m.plane_rows = (int)prow; m.w_plane = (long)c.cout * c.cin;
@@ -580,6 +589,7 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
     HIPOK(hipMemcpy(d, tab.data(), tab.size() * sizeof(UpdEntry), hipMemcpyHostToDevice));
     e->upd_tab[slot] = d; e->upd_blocks[slot] = blk;
   }
+  if (update) wino_weights_changed(e);
   launch_sgd_update_all(e->upd_tab[slot], hi - lo, e->upd_blocks[slot], e->Wp, e->ws_wg, e->na,
                         update ? e->lr : nullptr, (update && e->lr_level == EOSVOS_LR_PARAM) ? e->lr_elem : nullptr,
                         accumulate ? e->gsum : nullptr, e->keep_grads ? e->gout : nullptr, stream);
@@ -687,6 +697,8 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
       const int64_t prow = gm.prow, np = gm.np;
       e->wino_V[ci] = e->falloc(np * prow * c.cin);
       e->wino_U[ci] = e->falloc(np * c.cout * c.cin);
+      e->wino_Us[ci] = e->falloc(np * c.cout * c.cin);
+      e->wino_us_valid[ci] = 0;
       e->wino_dM[ci] = e->falloc(np * prow * c.cout);
       e->wino_v_batch[ci] = 0; e->wino_dm_batch[ci] = 0;
       e->wino_m_n = max64(e->wino_m_n, np * prow * max64(c.cout, c.cin));
@@ -800,6 +812,7 @@ static void export_params(eosvos_engine* e, const float* src, float* flat, float
 
 int eosvos_set_init(eosvos_engine* e, const float* flat_params) {
   if (!e || !flat_params) return fail("null argument");
+  wino_weights_changed(e);
   import_params(e, flat_params, e->Winit);
   HIPOK(hipMemcpyAsync(e->Wp, e->Winit, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
   HIPOK(hipGetLastError());
@@ -877,6 +890,7 @@ int eosvos_set_lr_state(eosvos_engine* e, int level, int use_log, const float* s
 int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, const float* mean,
                     const float* var, float eps) {
   if (!e || !gamma || !beta || !mean || !var) return fail("null argument");
+  wino_weights_changed(e);
   if (e->gn()) {                  // GroupNorm shares the (frozen) affine only (deeplabv3plus.py:186-188)
     HIPOK(hipMemcpyAsync(e->na, gamma, (size_t)e->t.nnorm * 4, hipMemcpyDeviceToDevice, e->s));
     HIPOK(hipMemcpyAsync(e->nb, beta, (size_t)e->t.nnorm * 4, hipMemcpyDeviceToDevice, e->s));
@@ -888,6 +902,7 @@ int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, con
 }
 int eosvos_reset(eosvos_engine* e) {
   if (!e) return fail("null engine");
+  wino_weights_changed(e);
   HIPOK(hipMemcpyAsync(e->Wp, e->Winit, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
   return 0;
 }
@@ -899,6 +914,7 @@ int eosvos_get_params(eosvos_engine* e, float* out) {
 }
 int eosvos_set_params(eosvos_engine* e, const float* flat) {
   if (!e || !flat) return fail("null argument");
+  wino_weights_changed(e);
   import_params(e, flat, e->Wp);
   HIPOK(hipGetLastError());
   return 0;
@@ -910,6 +926,7 @@ int eosvos_snapshot_params(eosvos_engine* e) {
 }
 int eosvos_restore_params(eosvos_engine* e) {
   if (!e) return fail("null engine");
+  wino_weights_changed(e);
   HIPOK(hipMemcpyAsync(e->Wp, e->Wsnap, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
   return 0;
 }

@@ -103,13 +103,13 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T);
 // dil: dilation of the 3x3 conv = dil*dil interleaved sub-grids; tiles are (image, sy, sx, ty, tx), th x tw per sub-grid
 void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V, hipStream_t s);
 void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M, hipStream_t s);
-void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);
+void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s);   // U = G w G^T, Us = rowscale*U
 // Winograd F(4x4,3x3): 36 planes, th x tw tiles of 4x4 outputs per sub-grid
 void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,
                         hipStream_t s);
 void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M,
                        hipStream_t s);
-void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s);
+void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s);
 void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                          const float* bias, int relu, float* y, int ldy, hipStream_t s);
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);

@@ -1397,20 +1397,18 @@ void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int t
   hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M);
 }
 // U[p][cout][cin] = G w G^T from W[cout][3x3][cin]
+// U = G w G^T; Us (optional) = rowscale[cout] * U, the copy the data gradient multiplies with
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
-                                                           const float* __restrict__ rowscale, float* __restrict__ U) {
+                                                           const float* __restrict__ rowscale, float* __restrict__ U,
+                                                           float* __restrict__ Us) {
   const int C4 = Cin >> 2;
   const long n = (long)Cout * C4;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4), co = (int)(e / C4);
-    const float rs = rowscale ? rowscale[co] : 1.f;      // data gradient: the frozen-norm scale a[cout] folded into U
+    const float rs = rowscale ? rowscale[co] : 1.f;      // data gradient: the frozen-norm scale a[cout] folded into Us
     float4 g[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float4 v = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
-      v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
-      g[t / 3][t % 3] = v;
-    }
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
     float4 t4[4][3];                       // t = G g : rows (g0, .5(g0+g1+g2), .5(g0-g1+g2), g2)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -1423,18 +1421,28 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) {          // U = t G^T : columns likewise
       const float4 a = t4[i][0], b = t4[i][1], c = t4[i][2];
-      float* o = U + ((size_t)(i * 4) * Cout + co) * Cin + c4 * 4;
+      const size_t off = ((size_t)(i * 4) * Cout + co) * Cin + c4 * 4;
       const size_t ps = (size_t)Cout * Cin;
-      *reinterpret_cast<float4*>(o) = a;
-      *reinterpret_cast<float4*>(o + ps) = make_float4(0.5f * (a.x + b.x + c.x), 0.5f * (a.y + b.y + c.y), 0.5f * (a.z + b.z + c.z), 0.5f * (a.w + b.w + c.w));
-      *reinterpret_cast<float4*>(o + 2 * ps) = make_float4(0.5f * (a.x - b.x + c.x), 0.5f * (a.y - b.y + c.y), 0.5f * (a.z - b.z + c.z), 0.5f * (a.w - b.w + c.w));
-      *reinterpret_cast<float4*>(o + 3 * ps) = c;
+      const float4 u0 = a;
+      const float4 u1 = make_float4(0.5f * (a.x + b.x + c.x), 0.5f * (a.y + b.y + c.y), 0.5f * (a.z + b.z + c.z), 0.5f * (a.w + b.w + c.w));
+      const float4 u2 = make_float4(0.5f * (a.x - b.x + c.x), 0.5f * (a.y - b.y + c.y), 0.5f * (a.z - b.z + c.z), 0.5f * (a.w - b.w + c.w));
+      const float4 u3 = c;
+      *reinterpret_cast<float4*>(U + off) = u0;
+      *reinterpret_cast<float4*>(U + off + ps) = u1;
+      *reinterpret_cast<float4*>(U + off + 2 * ps) = u2;
+      *reinterpret_cast<float4*>(U + off + 3 * ps) = u3;
+      if (Us) {
+        *reinterpret_cast<float4*>(Us + off) = make_float4(rs * u0.x, rs * u0.y, rs * u0.z, rs * u0.w);
+        *reinterpret_cast<float4*>(Us + off + ps) = make_float4(rs * u1.x, rs * u1.y, rs * u1.z, rs * u1.w);
+        *reinterpret_cast<float4*>(Us + off + 2 * ps) = make_float4(rs * u2.x, rs * u2.y, rs * u2.z, rs * u2.w);
+        *reinterpret_cast<float4*>(Us + off + 3 * ps) = make_float4(rs * u3.x, rs * u3.y, rs * u3.z, rs * u3.w);
+      }
     }
   }
 }
-void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s) {
+void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U, Us);
 }
 // dX (NHWC, ld ldgx) = mask?( sum over the covering tiles of (B dV B^T)[i][j] ), one thread per 2x2 pixel block and 4
 // channels: the block (2k..2k+1, 2l..2l+1) takes rows i = 3 of tile k-1, i = 1, 2 of tile k and i = 0 of tile k+1
@@ -1699,7 +1707,8 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
 }
 // U[p][cout][cin] = G (rowscale * w) G^T
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
-                                                            const float* __restrict__ rowscale, float* __restrict__ U) {
+                                                            const float* __restrict__ rowscale, float* __restrict__ U,
+                                                            float* __restrict__ Us) {
   const int C4 = Cin >> 2;
   const long n = (long)Cout * C4;
   GRID_STRIDE(e, n) {
@@ -1707,11 +1716,7 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
     const float rs = rowscale ? rowscale[co] : 1.f;
     float4 g[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float4 v = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
-      v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
-      g[t / 3][t % 3] = v;
-    }
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + t) * Cin + c4 * 4);
     float4 t[6][3];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -1732,6 +1737,9 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
         for (int r = 0; r < 3; ++r)
           if (w4::G[bb][r] != 0.f) w4::fma4(v, w4::G[bb][r], t[a][r]);
         *reinterpret_cast<float4*>(U + (size_t)(a * 6 + bb) * ps + (size_t)co * Cin + c4 * 4) = v;
+        if (Us)
+          *reinterpret_cast<float4*>(Us + (size_t)(a * 6 + bb) * ps + (size_t)co * Cin + c4 * 4) =
+              make_float4(rs * v.x, rs * v.y, rs * v.z, rs * v.w);
       }
   }
 }
@@ -1933,9 +1941,9 @@ void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int 
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino4_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M);
 }
-void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, hipStream_t s) {
+void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
-  hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U);
+  hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U, Us);
 }
 void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                          const float* bias, int relu, float* y, int ldy, hipStream_t s) {
