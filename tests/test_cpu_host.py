@@ -133,6 +133,17 @@ def test_meta_optimizer_without_learned_init(golden_dir):
     assert [n for n, _ in mo.named_parameters()] == list(g['nolearn_named'])
 
 
+def test_loop_helpers_vs_golden(golden_dir):
+    """`early_stopping` (helper_func.py:388-397) and `EpochSampler` (:521-545) of the product against the outputs the
+    reference's own functions produced (fixture G9/G10)."""
+    from eosvos_amd.helper_func import EpochSampler, early_stopping
+    g = json.load(open(os.path.join(golden_dir, 'g9_misc.json')))
+    hist = [1.0, 0.5, 0.4, 0.3999, 0.3998, 0.3997, 0.39965]
+    got = [[bool(early_stopping(hist[:n], p, 0.001)) for n in range(1, len(hist) + 1)] for p in (None, 2, 3)]
+    assert got == g['early_stopping']
+    assert [list(EpochSampler([0], False, 3)), list(EpochSampler([0, 1], False, 2))] == g['epoch_sampler']
+
+
 def test_checkpoint_layout_compatible(golden_dir):
     """A `.model` file written by the reference's MetaOptimizer.state_dict() layout loads, and
     our state dict has the same key structure (train_meta.py:277-286)."""
