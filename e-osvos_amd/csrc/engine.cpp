@@ -791,7 +791,13 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   {
     const char* v = getenv("EOSVOS_NO_SIDE_STREAM");
     if (!(v && v[0] == '1')) {
+#ifdef EOSVOS_SIDE_LOWPRIO        // experiment: the side stream yields to the main (critical) chain
+      int plo = 0, phi = 0;
+      HIPOK(hipDeviceGetStreamPriorityRange(&plo, &phi));       // plo = least, phi = greatest priority
+      HIPOK(hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, plo));
+#else
       HIPOK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+#endif
       e->ev.resize(t.convs.size() + 2);
       for (auto& evt : e->ev) HIPOK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
       e->ws_conv2 = e->falloc(conv_ws_floats());
