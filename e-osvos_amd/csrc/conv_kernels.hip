@@ -19,6 +19,8 @@
 // in misc_kernels.hip, selection in engine.cpp wino_on()).
 #include "kernels.h"
 
+#include <stdlib.h>
+
 #include <vector>
 
 namespace eosvos {
@@ -523,6 +525,556 @@ long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vect
   return total;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// fp32 contraction on the bf16 matrix cores ("bf16x6").
+//
+// The fp32 MFMA runs at 1/16 of the bf16 MFMA rate on CDNA4, so every operand is split exactly into three bf16
+// pieces, a = hi + mid + lo (8 + 8 + 8 significand bits, each piece = the truncated top 16 bits of the running
+// remainder: the split of a 24-bit significand is exact), and a*b is accumulated from the six partial products
+//   hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi      (v_mfma_f32_32x32x16_bf16, fp32 accumulate);
+// the dropped mid*lo, lo*mid, lo*lo terms are <= 2^-24 relative, i.e. below one fp32 rounding of the product.
+// bf16 x bf16 products are exact in fp32.  Measured against fp64 (tools/probes/bf16x6_probe.cpp): error relative to
+// sum|a*b| 1.4e-7 (the fp32 MFMA: 2.0e-7), at 1.45-1.6x the fp32-MFMA rate of the same tile structure.
+// Six 32-cycle MFMAs replace eight 64-cycle ones per 16 k of a 32x32 tile: 2.67x the fp32 matrix peak.
+//
+// Tile: 128 x {128,64} x 32 per 256-thread workgroup (2x2 waves, 64 x {64,32} per wave), 2 workgroups per CU.
+// Operands are gathered global -> registers (fp32, prefetched behind the MFMAs) -> split -> one LDS stage of
+// [piece][row][32 k] bf16 rows (80-byte pitch: conflict-free ds_read_b128 fragment reads).  K-major operands
+// (the weights of the data gradient, both operands of the weight gradient) are transposed in registers while
+// staging: a thread loads RPT consecutive k rows of 4 channels and writes one k-run per channel; their LDS rows are
+// de-interleaved (row j*W/4 + c <-> channel 4c + j) so that those writes spread over the banks -- the epilogue maps
+// the MFMA tile coordinates back.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define X6_ROWB 80
+
+__device__ __forceinline__ unsigned x6_pack(float e0, float e1) {      // (top 16 bits of e1) << 16 | top 16 bits of e0
+  return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+}
+__device__ __forceinline__ float x6_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+// four consecutive-k values -> the three pieces, 4 bf16 (8 bytes) each
+__device__ __forceinline__ void x6_split4(float a, float b, float c, float d, uint2 out[3]) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    out[p].x = x6_pack(a, b);
+    out[p].y = x6_pack(c, d);
+    if (p < 2) { a -= x6_trunc(a); b -= x6_trunc(b); c -= x6_trunc(c); d -= x6_trunc(d); }
+  }
+}
+__device__ __forceinline__ void x6_split2(float a, float b, unsigned out[3]) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    out[p] = x6_pack(a, b);
+    if (p < 2) { a -= x6_trunc(a); b -= x6_trunc(b); }
+  }
+}
+__device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+// LDS row of a K-major operand tile of width W <-> channel inside the tile
+__device__ __forceinline__ int x6_row_chan(int R, int W) { return 4 * (R % (W / 4)) + R / (W / 4); }
+
+// one 16-deep k group of a wave's 64 x (32*TN) tile: 6*(2+TN) fragment reads, 12*TN MFMAs
+template <int TM, int TN>
+__device__ __forceinline__ void x6_mma_group(const unsigned char* As, const unsigned char* Bs, int a_rows, int b_rows, int a_row0,
+                                             int b_row0, int g, int r, int h, f32x16 (&acc)[TM][TN]) {
+  bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+      fa[t][p] = *reinterpret_cast<const bf16x8*>(As + (p * a_rows + a_row0 + t * 32 + r) * X6_ROWB + g * 32 + h * 16);
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+      fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * b_rows + b_row0 + t * 32 + r) * X6_ROWB + g * 32 + h * 16);
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      f32x16 c = acc[tm][tn];
+      c = MFMA_BF16(fa[tm][2], fb[tn][0], c);            // smallest terms first
+      c = MFMA_BF16(fa[tm][0], fb[tn][2], c);
+      c = MFMA_BF16(fa[tm][1], fb[tn][1], c);
+      c = MFMA_BF16(fa[tm][1], fb[tn][0], c);
+      c = MFMA_BF16(fa[tm][0], fb[tn][1], c);
+      c = MFMA_BF16(fa[tm][0], fb[tn][0], c);
+      acc[tm][tn] = c;
+    }
+}
+
+template <int BN, bool KMAJOR>
+__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
+  constexpr int BM = 128, BK = 32;
+  constexpr int A_BYTES = 3 * BM * X6_ROWB, B_BYTES = 3 * BN * X6_ROWB, SMEM = A_BYTES + B_BYTES;
+  constexpr int LDC = BN + 4;
+  constexpr int EPASS = (BM * LDC * 4 <= SMEM) ? 1 : 2;      // C-tile staging passes
+  constexpr int EROWS = BM / EPASS;
+  static_assert(EROWS * LDC * 4 <= SMEM, "epilogue staging must fit the operand buffers");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  unsigned char* const As = smem;
+  unsigned char* const Bs = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int T = p.KH * p.KW;
+  const int chunks = (p.Kc + BK - 1) / BK;
+  const int ksteps = T * chunks;
+  const int nt = (p.N + BN - 1) / BN;
+  const int tiles = ((p.M + BM - 1) / BM) * nt;
+  const long U = p.tprefix ? (long)p.tprefix[tiles] : (long)tiles * ksteps;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const long sk0 = (long)p.dp_q * gridDim.x * ksteps;
+  const long u_begin = sk0 + (long)bid * p.per;
+  long u_end = u_begin + p.per;
+  if (u_end > U) u_end = U;
+  int dp_i = 0;
+
+  constexpr int APASS = BM / 32;                         // 8 float4 per 32-k row, 32 rows per pass
+  const int a_c4 = tid & 7, a_r = tid >> 3;
+  // B operand: rows of k (n-major weights, forward) staged like A; k-major weights (data gradient): a thread owns
+  // RPT consecutive k rows x 4 columns
+  constexpr int NQ = BN / 4, RPT = BN / 32;              // K-major: threads per k row, k rows per thread
+  constexpr int BPASS = BN / 32;                         // = RPT: float4 loads per thread in both layouts
+  const int b_c4 = tid & 7, b_r = tid >> 3;
+  const int b_n4 = tid % NQ, b_kq = tid / NQ;
+  const int up = 1 << p.upshift;
+  constexpr int TN = BN / 64;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (p.plane_rows ? (long)p.nplanes : 1L) * p.wN * T * p.wK * 4);
+
+  for (long u = u_begin;;) {
+    int tile, ks_begin, ks_end = ksteps;
+    const bool dp = dp_i < p.dp_q;
+    if (dp) {
+      tile = dp_i * (int)gridDim.x + bid;
+      ks_begin = 0;
+      ++dp_i;
+      if (tile >= tiles) continue;
+    } else if (u < u_end) {
+      if (p.tprefix) {
+        int lo = 0, hi = tiles - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if ((long)p.tprefix[mid] <= u) lo = mid; else hi = mid - 1;
+        }
+        tile = lo;
+        ks_begin = (int)(u - p.tprefix[tile]);
+        ks_end = p.tprefix[tile + 1] - p.tprefix[tile];
+      } else {
+        tile = (int)(u / ksteps);
+        ks_begin = (int)(u - (long)tile * ksteps);
+      }
+      if ((long)ks_end - ks_begin > u_end - u) ks_end = ks_begin + (int)(u_end - u);
+    } else {
+      break;
+    }
+    const int ks_total = p.tprefix ? p.tprefix[tile + 1] - p.tprefix[tile] : ksteps;
+    unsigned long long tappack = 0x876543210ULL;
+    if (p.tprefix) {
+      const int mask = p.tmask[tile];
+      tappack = 0;
+      int nv = 0;
+      for (int t2 = 0; t2 < T; ++t2)
+        if ((mask >> t2) & 1) { tappack |= (unsigned long long)t2 << (4 * nv); ++nv; }
+    }
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+
+    int a_sy0[APASS], a_sx0[APASS], a_img[APASS];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      int m = m0 + a_r + i * 32;
+      if (m < p.M) {
+        if (p.par) m = conv_par_pixel(p.B, p.Ho, p.Wo, m);
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_sy0[i] = oy * p.mul + p.off0;
+        a_sx0[i] = ox * p.mul + p.off0;
+        a_img[i] = b * p.Hi * p.Wi;
+      } else {
+        a_sy0[i] = -(1 << 28);
+        a_sx0[i] = 0;
+        a_img[i] = 0;
+      }
+    }
+    float4 ra[APASS], rb[BPASS];
+    constexpr unsigned OOB = 0x80000000u;
+    int a_off[APASS];
+    int b_off[BPASS];
+    const int wplane = p.plane_rows ? (m0 / p.plane_rows) * (int)p.w_plane : 0;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      if (KMAJOR) {
+        const int n = n0 + b_n4 * 4;
+        b_off[i] = n < p.N ? wplane + (b_kq * RPT + i) * T * p.wK + n : -1;
+      } else {
+        const int n = n0 + b_r + i * 32;
+        b_off[i] = n < p.N ? wplane + n * T * p.wK + b_c4 * 4 : -1;
+      }
+    }
+    int cur_tap = -1;
+    auto load_tiles = [&](int ks) {
+      const int vt = ks / chunks;
+      const int c0 = (ks - vt * chunks) * BK;
+      const int tap = p.tprefix ? (int)((tappack >> (4 * vt)) & 15) : vt;
+      if (tap != cur_tap) {          // wave-uniform
+        cur_tap = tap;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int dy = ky * p.kstep, dx = kx * p.kstep;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+          const int sy = a_sy0[i] + dy, sx = a_sx0[i] + dx;
+          bool ok = sy >= 0 && sx >= 0 && ((sy | sx) & (up - 1)) == 0;
+          const int iy = sy >> p.upshift, ix = sx >> p.upshift;
+          ok = ok && iy < p.Hi && ix < p.Wi;
+          a_off[i] = ok ? (a_img[i] + iy * p.Wi + ix) * p.ldx + a_c4 * 4 : -1;
+        }
+      }
+      const bool cok = (c0 + a_c4 * 4) < p.Kc;
+      float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (KMAJOR && p.kscale && cok) ks4 = ldg4(p.kscale + c0 + a_c4 * 4);
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const unsigned off = (cok && a_off[i] >= 0) ? (unsigned)(a_off[i] + c0) * 4u : OOB;
+        float4 v = bufld4(rx, off);
+        if (KMAJOR) { v.x *= ks4.x; v.y *= ks4.y; v.z *= ks4.z; v.w *= ks4.w; }
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        unsigned off;
+        if (KMAJOR) {
+          const int k = c0 + b_kq * RPT + i;
+          off = (b_off[i] >= 0 && k < p.Kc) ? (unsigned)(b_off[i] + (c0 * T + tap) * p.wK) * 4u : OOB;
+        } else {
+          const int k = c0 + b_c4 * 4;
+          off = (b_off[i] >= 0 && k < p.Kc) ? (unsigned)(b_off[i] + tap * p.wK + c0) * 4u : OOB;
+        }
+        rb[i] = bufld4(rw, off);
+      }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        uint2 pc[3];
+        x6_split4(ra[i].x, ra[i].y, ra[i].z, ra[i].w, pc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(As + (q * BM + a_r + i * 32) * X6_ROWB + a_c4 * 8) = pc[q];
+      }
+      if (!KMAJOR) {
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+          uint2 pc[3];
+          x6_split4(rb[i].x, rb[i].y, rb[i].z, rb[i].w, pc);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(Bs + (q * BN + b_r + i * 32) * X6_ROWB + b_c4 * 8) = pc[q];
+        }
+      } else if (RPT == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {            // column 4*n4 + j of the tile lives in LDS row j*NQ + n4
+          uint2 pc[3];
+          x6_split4(f4c(rb[0], j), f4c(rb[1], j), f4c(rb[RPT == 4 ? 2 : 0], j), f4c(rb[RPT == 4 ? 3 : 0], j), pc);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(Bs + (q * BN + j * NQ + b_n4) * X6_ROWB + b_kq * 8) = pc[q];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned pc[3];
+          x6_split2(f4c(rb[0], j), f4c(rb[1], j), pc);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned*>(Bs + (q * BN + j * NQ + b_n4) * X6_ROWB + b_kq * 4) = pc[q];
+        }
+      }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tiles(ks_begin);
+    __syncthreads();            // previous segment's epilogue reads of smem are done
+    store_tiles();
+    __syncthreads();
+
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const bool more = (ks + 1) < ks_end;
+      if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) x6_mma_group<2, TN>(As, Bs, BM, BN, wm * 64, wn * (BN / 2), g, r, h, acc);
+      __syncthreads();                       // every wave is done reading the stage
+      if (more) store_tiles();
+      __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS tile -> full-row float4 stores ------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+    const bool full = (ks_begin == 0 && ks_end == ks_total);
+    constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
+    const int c_c4 = tid % CF4, c_r = tid / CF4;
+    const int n = n0 + c_c4 * 4;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (full && n < p.N) {
+      if (p.scale) sc = ldg4(p.scale + n);
+      if (p.bias) bi = ldg4(p.bias + n);
+    }
+    const bool use_mask = p.mask && n >= p.mask_c0;
+#pragma unroll
+    for (int ep = 0; ep < EPASS; ++ep) {
+      if (ep) __syncthreads();
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        if (EPASS == 2 && tm != ep) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int Rb = wn * (BN / 2) + tn * 32 + r;
+          const int ncol = KMAJOR ? x6_row_chan(Rb, BN) : Rb;
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            Cs[((EPASS == 1 ? wm * 64 + tm * 32 : wm * 32) + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + ncol] = acc[tm][tn][e];
+        }
+      }
+      __syncthreads();
+      auto trow = [&](int lr) { return EPASS == 1 ? lr : ((lr >> 5) << 6) + (ep << 5) + (lr & 31); };
+      if (full) {
+        if (n < p.N) {
+          constexpr int NIT = EROWS / CROWS, EB = EOSVOS_EB;
+#pragma unroll
+          for (int it0 = 0; it0 < NIT; it0 += EB) {
+            size_t md[EB];
+            bool ok[EB];
+            float4 rs[EB], ac[EB], mk[EB];
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+              const int m = m0 + trow(c_r + (it0 + j) * CROWS);
+              ok[j] = m < p.M;
+              md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
+            }
+            if (p.res) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
+            }
+            if (p.accum) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
+            }
+            if (use_mask) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
+            }
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+              float4 v = *reinterpret_cast<const float4*>(Cs + (c_r + (it0 + j) * CROWS) * LDC + c_c4 * 4);
+              if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+              if (p.bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+              if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
+              if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
+              if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              if (use_mask) {
+                v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
+                v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
+              }
+              if (ok[j]) *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+            }
+          }
+        }
+      } else {
+        float* slab = p.ws + ((size_t)bid * 2 + (u == u_begin ? 0 : 1)) * (BM * BN);
+#pragma unroll 4
+        for (int lr = c_r; lr < EROWS; lr += CROWS)
+          *reinterpret_cast<float4*>(slab + trow(lr) * BN + c_c4 * 4) =
+              *reinterpret_cast<const float4*>(Cs + lr * LDC + c_c4 * 4);
+      }
+    }
+    if (!dp) u += ks_end - ks_begin;
+  }
+}
+
+// Weight gradient on the bf16 matrix cores: same split, both operands K-major (a pixel's channels are contiguous).
+template <int BMO, int BNI>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
+  constexpr int BKP = 32;
+  constexpr int A_BYTES = 3 * BMO * X6_ROWB, B_BYTES = 3 * BNI * X6_ROWB, SMEM = A_BYTES + B_BYTES;
+  constexpr int LDC = BNI + 4;
+  constexpr int EPASS = (BMO * LDC * 4 <= SMEM) ? 1 : 2;
+  constexpr int EROWS = BMO / EPASS;
+  static_assert(EROWS * LDC * 4 <= SMEM, "epilogue staging must fit the operand buffers");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  unsigned char* const As = smem;
+  unsigned char* const Bs = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int T = p.KH * p.KW;
+  const int ct = (p.Cout + BMO - 1) / BMO, it = (p.Cin + BNI - 1) / BNI;
+  const int tiles = ct * it * T;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = bid / tiles;
+  int tile = bid - z * tiles;
+  const int tap = tile % T; tile /= T;
+  const int co0 = (tile / it) * BMO, ci0 = (tile % it) * BNI;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+  const int dyk = ky * p.dil - p.pad, dxk = kx * p.dil - p.pad;
+  auto cdiv = [](int a, int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };
+  auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+  int oy_lo = cdiv(-dyk, p.stride), oy_hi = fdiv(p.Hi - 1 - dyk, p.stride);
+  int ox_lo = cdiv(-dxk, p.stride), ox_hi = fdiv(p.Wi - 1 - dxk, p.stride);
+  if (oy_lo < 0) oy_lo = 0;
+  if (ox_lo < 0) ox_lo = 0;
+  if (oy_hi > p.Ho - 1) oy_hi = p.Ho - 1;
+  if (ox_hi > p.Wo - 1) ox_hi = p.Wo - 1;
+  const int hv = oy_hi - oy_lo + 1 > 0 ? oy_hi - oy_lo + 1 : 0;
+  const int wv = ox_hi - ox_lo + 1 > 0 ? ox_hi - ox_lo + 1 : 0;
+  const int P = p.B * hv * wv;                         // contributing pixels
+  const int steps = (P + BKP - 1) / BKP;
+  const int st_begin = (int)(((long)steps * z) / p.splits);
+  const int st_end = (int)(((long)steps * (z + 1)) / p.splits);
+
+  // a thread owns RPT consecutive pixels x 4 channels of each operand
+  constexpr int ANQ = BMO / 4, ARPT = BMO / 32, BNQ = BNI / 4, BRPT = BNI / 32;
+  const int a_c4 = tid % ANQ, a_kq = tid / ANQ;
+  const int b_c4 = tid % BNQ, b_kq = tid / BNQ;
+  const bool a_cok = (co0 + a_c4 * 4) < p.Cout;
+  const bool b_cok = (ci0 + b_c4 * 4) < p.Cin;
+  float4 ra[ARPT], rb[BRPT];
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.g + tap * p.g_tap_stride, (long)p.B * p.Ho * p.Wo * p.ldg * 4);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + tap * p.x_tap_stride, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
+  const int hw = hv * wv > 0 ? hv * wv : 1, wv1 = wv > 0 ? wv : 1;
+  const float inv_hw = 1.0f / (float)hw, inv_wv = 1.0f / (float)wv1;
+  // contributing pixel q -> (image, row, column) of the rectangle; q < 2^24, so one float multiply +- 1 is exact
+  auto pix = [&](int q, int& img, int& y, int& x) {
+    int b = (int)((float)q * inv_hw);
+    if (b * hw > q) --b; else if ((b + 1) * hw <= q) ++b;
+    const int rem = q - b * hw;
+    int yy = (int)((float)rem * inv_wv);
+    if (yy * wv1 > rem) --yy; else if ((yy + 1) * wv1 <= rem) ++yy;
+    img = b; y = yy; x = rem - yy * wv1;
+  };
+  auto load_tiles = [&](int st) {
+    {
+      int img, y, x;
+      pix(st * BKP + a_kq * ARPT, img, y, x);
+#pragma unroll
+      for (int i = 0; i < ARPT; ++i) {
+        const bool ok = a_cok && img < p.B;
+        const unsigned off = ok ? (unsigned)(((img * p.Ho + oy_lo + y) * p.Wo + ox_lo + x) * p.ldg + co0 + a_c4 * 4) * 4u : OOB;
+        ra[i] = bufld4(rg, off);
+        if (++x >= wv1) { x = 0; if (++y >= hv) { y = 0; ++img; } }
+      }
+    }
+    {
+      int img, y, x;
+      pix(st * BKP + b_kq * BRPT, img, y, x);
+#pragma unroll
+      for (int i = 0; i < BRPT; ++i) {
+        const int iy = (oy_lo + y) * p.stride + dyk, ix = (ox_lo + x) * p.stride + dxk;
+        const bool ok = b_cok && img < p.B;
+        const unsigned off = ok ? (unsigned)(((img * p.Hi + iy) * p.Wi + ix) * p.ldx + ci0 + b_c4 * 4) * 4u : OOB;
+        rb[i] = bufld4(rx, off);
+        if (++x >= wv1) { x = 0; if (++y >= hv) { y = 0; ++img; } }
+      }
+    }
+  };
+  auto store_op = [&](unsigned char* S, const float4* rv, int W, int NQ_, int RPT_, int c4, int kq) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {              // channel 4*c4 + j of the tile lives in LDS row j*NQ + c4
+      if (RPT_ == 4) {
+        uint2 pc[3];
+        x6_split4(f4c(rv[0], j), f4c(rv[1], j), f4c(rv[RPT_ == 4 ? 2 : 0], j), f4c(rv[RPT_ == 4 ? 3 : 0], j), pc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(S + (q * W + j * NQ_ + c4) * X6_ROWB + kq * 8) = pc[q];
+      } else {
+        unsigned pc[3];
+        x6_split2(f4c(rv[0], j), f4c(rv[1], j), pc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned*>(S + (q * W + j * NQ_ + c4) * X6_ROWB + kq * 4) = pc[q];
+      }
+    }
+  };
+
+  constexpr int TM = BMO / 64, TN = BNI / 64;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (st_begin < st_end) {
+    load_tiles(st_begin);
+    store_op(As, ra, BMO, ANQ, ARPT, a_c4, a_kq);
+    store_op(Bs, rb, BNI, BNQ, BRPT, b_c4, b_kq);
+  }
+  __syncthreads();
+  for (int st = st_begin; st < st_end; ++st) {
+    const bool more = (st + 1) < st_end;
+    if (more) load_tiles(st + 1);
+#pragma unroll
+    for (int g = 0; g < BKP / 16; ++g) x6_mma_group<TM, TN>(As, Bs, BMO, BNI, wm * (BMO / 2), wn * (BNI / 2), g, r, h, acc);
+    __syncthreads();
+    if (more) {
+      store_op(As, ra, BMO, ANQ, ARPT, a_c4, a_kq);
+      store_op(Bs, rb, BNI, BNQ, BRPT, b_c4, b_kq);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: accumulators -> LDS tile (channels back in order) -> full-row float4 stores of the slab
+  float* Cs = reinterpret_cast<float*>(smem);
+  float* out = p.ws + (size_t)z * p.Cout * T * p.Cin;
+  constexpr int CF4 = BNI / 4, CROWS = 256 / CF4;
+  const int c_c4 = tid % CF4, c_r = tid / CF4;
+  // tile row (cout) of accumulator element e of sub-tile tm: Ra = wm*(BMO/2) + tm*32 + (e&3) + 8*(e>>2) + 4h,
+  // channel = 4*(Ra % (BMO/4)) + Ra / (BMO/4).  A staging pass ep holds the channels [ep*EROWS, (ep+1)*EROWS).
+#pragma unroll
+  for (int ep = 0; ep < EPASS; ++ep) {
+    if (ep) __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int ncol = x6_row_chan(wn * (BNI / 2) + tn * 32 + r, BNI);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ch = x6_row_chan(wm * (BMO / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, BMO);
+          if (EPASS == 1 || (ch / EROWS) == ep) Cs[(ch - ep * EROWS) * LDC + ncol] = acc[tm][tn][e];
+        }
+      }
+    __syncthreads();
+    const int ci = ci0 + c_c4 * 4;
+    if (ci < p.Cin) {
+#pragma unroll 4
+      for (int lr = c_r; lr < EROWS; lr += CROWS) {
+        const int co = co0 + ep * EROWS + lr;
+        if (co < p.Cout)
+          *reinterpret_cast<float4*>(out + ((size_t)co * T + tap) * p.Cin + ci) = *reinterpret_cast<const float4*>(Cs + lr * LDC + c_c4 * 4);
+      }
+    }
+  }
+}
+
+// EOSVOS_MFMA=f32 selects the fp32-MFMA kernels (A/B and fallback); default: bf16x6
+int conv_mfma_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* v = getenv("EOSVOS_MFMA");
+    mode = (v && v[0] == 'f') ? 0 : 1;
+  }
+  return mode;
+}
+
 #define CONV_MAX_WG (256 * EOSVOS_OCC)
 #define CONV_MAX_WG_DEEP (256 * 3)
 int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG_DEEP * 2 * 128 * 128; }
@@ -536,6 +1088,7 @@ int conv_plan(ConvArgs& a) {
   const int T = a.KH * a.KW;
   long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  const bool x6 = conv_mfma_mode() == 1;
 #ifndef EOSVOS_NO_DEEP
   // 3-workgroups-per-CU kernel for long-K layers with many tiles (measured: decoder 3x3 fwd/dgrad at batch >= 2)
 #ifndef EOSVOS_DEEP_BATCHED
@@ -543,7 +1096,7 @@ int conv_plan(ConvArgs& a) {
 #endif
   const bool batched_deep = a.plane_rows != 0 && (EOSVOS_DEEP_BATCHED == 2 || (EOSVOS_DEEP_BATCHED == 1 && (a.Kc & 31)));
   const bool deep_ok = ksteps >= 64 || batched_deep;
-  a.deep = (bn == 128 && tiles >= EOSVOS_DEEP_TILES && deep_ok && a.total_units <= 0)
+  a.deep = (!x6 && bn == 128 && tiles >= EOSVOS_DEEP_TILES && deep_ok && a.total_units <= 0)
                ? (((a.Kc & 31) || batched_deep) ? 2 : 1) : 0;
 #else
   a.deep = 0;
@@ -582,7 +1135,15 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const int nwg = conv_plan(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   const dim3 grid(nwg), block(256);
-  if (a.deep == 1) {
+  if (conv_mfma_mode() == 1) {
+    if (a.kmajor) {
+      if (bn == 128) hipLaunchKernelGGL((conv_x6_kernel<128, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv_x6_kernel<64, true>), grid, block, 0, s, a);
+    } else {
+      if (bn == 128) hipLaunchKernelGGL((conv_x6_kernel<128, false>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv_x6_kernel<64, false>), grid, block, 0, s, a);
+    }
+  } else if (a.deep == 1) {
     if (a.kmajor) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, false, 1>), grid, block, 0, s, a);
   } else if (a.deep == 2) {
@@ -812,6 +1373,13 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
   const int T = a.KH * a.KW;
   const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * T;
   const dim3 grid(tiles * a.splits), block(256);
+  if (conv_mfma_mode() == 1) {
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_x6_kernel<128, 128>), grid, block, 0, s, a);
+    else if (bm == 128) hipLaunchKernelGGL((wgrad_x6_kernel<128, 64>), grid, block, 0, s, a);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad_x6_kernel<64, 64>), grid, block, 0, s, a);
+    return;
+  }
   if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, block, 0, s, a);
   else if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, block, 0, s, a);
   else if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, block, 0, s, a);
