@@ -17,6 +17,8 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     'eosvos_version': (ctypes.c_char_p, []),
     'eosvos_last_error': (ctypes.c_char_p, []),
+    'eosvos_set_matrix_mode': (ctypes.c_int, [ctypes.c_int]),
+    'eosvos_get_matrix_mode': (ctypes.c_int, []),
     'eosvos_num_convs': (ctypes.c_int, [ctypes.c_int]),
     'eosvos_conv_info': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
     'eosvos_param_count': (ctypes.c_int64, [ctypes.c_int]),
@@ -72,6 +74,10 @@ _SIGNATURES = {
                                         ctypes.c_int] + [ctypes.c_int] * 9 + [c_float_p]),
     'eosvos_test_conv_bwd': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 9 +
                              [c_float_p, c_float_p]),
+    'eosvos_test_conv_algo': (ctypes.c_int, [_E, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                             ctypes.c_int] + [ctypes.c_int] * 9 + [c_float_p]),
+    'eosvos_test_conv_bwd_algo': (ctypes.c_int, [_E, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] +
+                                  [ctypes.c_int] * 9 + [c_float_p, c_float_p]),
 }
 
 _lib = None

@@ -1066,14 +1066,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
 }
 
 // EOSVOS_MFMA=f32 selects the fp32-MFMA kernels (A/B and fallback); default: bf16x6
+static int g_mfma_mode = -1;
 int conv_mfma_mode() {
-  static int mode = -1;
-  if (mode < 0) {
+  if (g_mfma_mode < 0) {
     const char* v = getenv("EOSVOS_MFMA");
-    mode = (v && v[0] == 'f') ? 0 : 1;
+    g_mfma_mode = (v && v[0] == 'f') ? 0 : 1;
   }
-  return mode;
+  return g_mfma_mode;
 }
+void conv_set_mfma_mode(int mode) { g_mfma_mode = mode ? 1 : 0; }
 
 #define CONV_MAX_WG (256 * EOSVOS_OCC)
 #define CONV_MAX_WG_DEEP (256 * 3)

@@ -212,6 +212,7 @@ struct eosvos_engine {
   ResizeTab up_h, up_w, fin_h, fin_w;  // decoder upsample (align_corners) and final resize
   int lastB = 0;
   bool have_loss_grad = false;
+  int force_algo = 0;                 // EOSVOS_ALGO_*: 0 = plan by work size; the op-level parity tests force one path
 
   float* falloc(int64_t n) {
     void* p = nullptr;
@@ -292,8 +293,30 @@ bool trace_on() {
   if (on < 0) { const char* v = getenv("EOSVOS_TRACE"); on = (v && v[0] == '1') ? 1 : 0; }
   return on == 1;
 }
-void trace(const char* kind, int ci, long M, long N, long K, int splits) {
-  if (trace_on()) fprintf(stderr, "EOSVOS_TRACE %s conv=%d M=%ld N=%ld K=%ld splits=%d flops=%.0f\n", kind, ci, M, N, K, splits, 2.0 * M * N * K);
+// `frac`: share of the nominal M*N*K multiply-accumulates the launch executes (filter taps that fall into the padding
+// are skipped by the tap tables / contributing-pixel rectangles): flops = executed, not 9-tap-equivalent
+void trace(const char* kind, int ci, long M, long N, long K, int splits, double frac = 1.0) {
+  if (trace_on()) fprintf(stderr, "EOSVOS_TRACE %s conv=%d M=%ld N=%ld K=%ld splits=%d flops=%.0f\n", kind, ci, M, N, K, splits, 2.0 * M * N * K * frac);
+}
+double conv_exec_frac(const ConvArgs& a) {
+  if (!a.tprefix || a.total_units <= 0) return 1.0;
+  const int bn = (a.N > 64) ? 128 : 64;
+  const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  return (double)a.total_units / (double)(tiles * (long)a.KH * a.KW * ((a.Kc + 31) / 32));
+}
+// weight gradient: only the output pixels whose tap lands inside the input contribute (wgrad kernels' rectangles)
+double wgrad_exec_frac(const WgradArgs& a) {
+  if (a.g_tap_stride) return 1.0;
+  long sum = 0;
+  for (int ky = 0; ky < a.KH; ++ky)
+    for (int kx = 0; kx < a.KW; ++kx) {
+      const int dyk = ky * a.dil - a.pad, dxk = kx * a.dil - a.pad;
+      int hv = 0, wv = 0;
+      for (int oy = 0; oy < a.Ho; ++oy) { const int iy = oy * a.stride + dyk; hv += (iy >= 0 && iy < a.Hi); }
+      for (int ox = 0; ox < a.Wo; ++ox) { const int ix = ox * a.stride + dxk; wv += (ix >= 0 && ix < a.Wi); }
+      sum += (long)hv * wv;
+    }
+  return (double)sum / ((double)a.KH * a.KW * a.Ho * a.Wo);
 }
 
 // Winograd F(2x2,3x3) path (forward, data gradient, weight gradient) of 3x3 / stride 1 convs: 2.25x fewer MACs,
@@ -309,20 +332,22 @@ struct WinoGeom { int th, tw, d, tm, np; long ntile, prow; };
 #ifndef EOSVOS_WINO_F4_DIL
 #define EOSVOS_WINO_F4_DIL 1
 #endif
-bool wino_f4(const ConvL& c, int Ho, int Wo) {
+bool wino_f4(const eosvos_engine* e, const ConvL& c, int Ho, int Wo) {
 #ifdef EOSVOS_NO_WINO_F4
-  (void)c; (void)Ho; (void)Wo;
+  (void)e; (void)c; (void)Ho; (void)Wo;
   return false;
 #else
+  if (e->force_algo == EOSVOS_ALGO_WINO_F2) return false;
+  if (e->force_algo == EOSVOS_ALGO_WINO_F4) return true;
   // large undilated maps (the decoder), or -- EOSVOS_WINO_F4_DIL -- dilated convs whose sub-grids tile well with 4x4
   if (c.dil == 1) return Ho >= EOSVOS_WINO_F4_MINDIM && Wo >= EOSVOS_WINO_F4_MINDIM;
   return EOSVOS_WINO_F4_DIL && (c.dil == 2 || c.dil == 4 || c.dil == 8);
 #endif
 }
-WinoGeom wino_geom(const ConvL& c, int B, int Ho, int Wo) {
+WinoGeom wino_geom(const eosvos_engine* e, const ConvL& c, int B, int Ho, int Wo) {
   WinoGeom g;
   g.d = c.dil;
-  g.tm = wino_f4(c, Ho, Wo) ? 4 : 2;
+  g.tm = wino_f4(e, c, Ho, Wo) ? 4 : 2;
   g.np = (g.tm + 2) * (g.tm + 2);
   g.th = ((Ho + g.d - 1) / g.d + g.tm - 1) / g.tm;       // output tiles per sub-grid of a dilated conv
   g.tw = ((Wo + g.d - 1) / g.d + g.tm - 1) / g.tm;
@@ -342,7 +367,9 @@ bool wino_on(const eosvos_engine* e, int ci, int B, int Ho, int Wo) {
   return false;
 #else
   const ConvL& c = e->t.convs[ci];
+  if (e->force_algo == EOSVOS_ALGO_DIRECT) return false;
   if (!wino_shape(c)) return false;
+  if (e->force_algo == EOSVOS_ALGO_WINO_F2 || e->force_algo == EOSVOS_ALGO_WINO_F4) return e->wino_V.find(ci) != e->wino_V.end();
   if (ci == e->t.dec_a || ci == e->t.dec_b) return true;
   if (e->wino_V.find(ci) == e->wino_V.end()) return false;            // no buffers were reserved for it
   return (long long)B * Ho * Wo / 4 * c.cin * c.cout >= EOSVOS_WINO_MINWORK;      // MACs of one F(2,3) position
@@ -378,7 +405,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   if (!side && wino_on(e, ci, B, a.Ho, a.Wo)) {
     // Winograd forward: U = G w G^T, V = B^T d B (kept for the weight gradient), 16 GEMMs [tiles x cin] x [cin x cout]
     // as one batched launch (2.25x fewer MACs than the 9-tap form), y = epilogue(A^T M A)
-    const WinoGeom wg = wino_geom(c, B, a.Ho, a.Wo);
+    const WinoGeom wg = wino_geom(e, c, B, a.Ho, a.Wo);
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
     e->wino_us_valid[ci] = 1;
@@ -411,7 +438,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
   }
   attach_tap_table(e, ci, 0, B, a);
-  trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a));
+  trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a), conv_exec_frac(a));
   launch_conv(a, st);
   if (gn)
     launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
@@ -436,7 +463,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   if (!add && wino_on(e, ci, B, Hin, Win)) {
     // Winograd data gradient: dV[p] = dM[p] (a[cout] U[p]), 16 GEMMs [tiles x cout] x [cout x cin] in one batched
     // launch, then dX = mask(B dV B^T) gathered per 2x2 pixel block
-    const WinoGeom wg = wino_geom(c, B, Hin, Win);
+    const WinoGeom wg = wino_geom(e, c, B, Hin, Win);
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
     if (e->wino_dm_batch[ci] != B) {
@@ -496,7 +523,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     return;
   }
   attach_tap_table(e, ci, 1, B, a);
-  trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a));
+  trace("dgrad", ci, a.M, a.N, (long)c.T() * c.cout, conv_plan(a), conv_exec_frac(a));
   launch_conv(a, e->s);
 }
 // Weight-gradient launches are queued and forked onto the side stream a few layers at a time: every
@@ -528,7 +555,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   const bool wino = wino_on(e, ci, B, Ho, Wo);
   if (wino) {                       // dM feeds this weight gradient (side stream) and the data gradient (main stream)
-    const WinoGeom wg = wino_geom(c, B, Ho, Wo);
+    const WinoGeom wg = wino_geom(e, c, B, Ho, Wo);
     if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
     else launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
     e->wino_dm_batch[ci] = B;
@@ -538,7 +565,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   int nslabs;
   std::function<void(hipStream_t)> go;
   if (wino) {
-    const WinoGeom wg = wino_geom(c, B, Ho, Wo);
+    const WinoGeom wg = wino_geom(e, c, B, Ho, Wo);
     const long ntile = wg.ntile, prow = wg.prow;
     float* V = e->wino_V[ci];
     const bool need_v = e->wino_v_batch[ci] != B;       // else: V comes from the forward pass
@@ -566,7 +593,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
     a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
     a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T());
-    trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits);
+    trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits, wgrad_exec_frac(a));
     go = [=](hipStream_t ws) { launch_wgrad(a, ws); };
     nslabs = a.splits;
   }
@@ -627,8 +654,15 @@ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 
 extern "C" {
 
-const char* eosvos_version(void) { return "eosvos-mi355x 0.1 (gfx950, fp32 MFMA implicit-GEMM)"; }
+const char* eosvos_version(void) { return "eosvos-mi355x 0.2 (gfx950, fp32 implicit GEMM on the bf16 matrix cores: exact 3-way split, 6 partial products)"; }
 const char* eosvos_last_error(void) { return g_err.c_str(); }
+
+int eosvos_set_matrix_mode(int mode) {
+  if (mode != EOSVOS_MATRIX_F32 && mode != EOSVOS_MATRIX_BF16X6) return fail("unknown matrix mode");
+  conv_set_mfma_mode(mode);
+  return 0;
+}
+int eosvos_get_matrix_mode(void) { return conv_mfma_mode(); }
 
 int eosvos_num_convs(int arch) {
   Topo t;
@@ -715,10 +749,10 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
 #endif
     if (reserve) {                     // [final 9-tap slab][Winograd-domain slabs: splits x cout x 16 x cin]
       for (int b = 1; b <= B; ++b) {
-        const WinoGeom gb = wino_geom(c, b, Ho, Wo);
+        const WinoGeom gb = wino_geom(e, c, b, Ho, Wo);
         slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits((int)gb.ntile, c.cout, c.cin, gb.np) * c.cout * gb.np * c.cin);
       }
-      const WinoGeom gm = wino_geom(c, B, Ho, Wo);
+      const WinoGeom gm = wino_geom(e, c, B, Ho, Wo);
       const int64_t prow = gm.prow, np = gm.np;
       e->wino_V[ci] = e->falloc(np * prow * c.cin);
       e->wino_U[ci] = e->falloc(np * c.cout * c.cin);
@@ -1428,7 +1462,7 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
   if (wino_on(e, t.dec_a, batch, e->h4, e->w4)) {
     // the step runs this layer in the Winograd domain: time its batched GEMM launch (+ fix-up), the largest
     // conv_igemm launch of an iteration, against the GEMM's own FLOPs
-    const WinoGeom wg = wino_geom(c, batch, e->h4, e->w4);
+    const WinoGeom wg = wino_geom(e, c, batch, e->h4, e->w4);
     const long ntile = wg.ntile;
     ConvArgs m = wino_fwd_gemm(e, t.dec_a, wg, e->ws_conv);
     HIPOK(hipEventRecord(a, e->s));
@@ -1569,67 +1603,108 @@ int eosvos_debug_tensor(eosvos_engine* e, const char* name, float** ptr, int64_t
 }
 
 // ---- low-level op entry points for the kernel parity tests -----------------------------------------
-int eosvos_test_conv(eosvos_engine* e, const float* x, const float* w_oihw, const float* scale, const float* bias,
-                     const float* res, int relu, int B, int H, int W, int Cin, int Cout, int k, int stride, int dil,
-                     int pad, float* y) {
+// One convolution through the PRODUCTION paths (conv_fwd / conv_dgrad / conv_wgrad incl. tap tables, tail
+// launches, the coarse-grid stride-2 gradient and -- forced by `algo` -- the Winograd F(2x2,3x3) / F(4x4,3x3)
+// transforms and batched GEMMs): a scratch engine whose topology is that single conv borrows the caller's stream.
+namespace {
+struct ScratchEngine {
+  eosvos_engine t;
+  bool ok = false;
+  ScratchEngine(eosvos_engine* e, int algo, int B, int H, int W, int Cin, int Cout, int k, int stride, int dil, int pad,
+                bool norm) {
+    ConvL c{Cin, Cout, k, stride, dil, pad, norm, false, 0, 0, 0};
+    t.t.convs.push_back(c);
+    t.t.dec_a = t.t.dec_b = -1;
+    t.t.nparam = c.wsize(); t.t.nlr = Cout; t.t.nnorm = Cout;
+    t.arch = e->arch; t.H = H; t.W = W; t.maxB = B; t.dev = e->dev; t.s = e->s; t.s2 = nullptr;
+    t.norm_mode = EOSVOS_NORM_BN_FROZEN;
+    t.force_algo = algo;
+    t.zbuf.assign(1, nullptr); t.gn_stats.assign(1, nullptr);
+    t.ws_off.assign(1, 0); t.upd_splits.assign(1, 1);
+    const int Ho = conv_out(H, k, stride, dil, pad), Wo = conv_out(W, k, stride, dil, pad);
+    t.Wp = t.falloc(c.wsize()); t.na = t.falloc(Cout); t.nb = t.falloc(Cout);
+    t.ws_conv = t.falloc(conv_ws_floats());
+    int64_t slab = 0;
+    for (int b = 1; b <= B; ++b) slab = max64(slab, (int64_t)wgrad_pick_splits(b * Ho * Wo, Cout, Cin, k * k) * c.wsize());
+    const bool wino = algo == EOSVOS_ALGO_WINO_F2 || algo == EOSVOS_ALGO_WINO_F4;
+    if (wino) {
+      if (!wino_shape(c)) return;
+      const WinoGeom g = wino_geom(&t, c, B, Ho, Wo);
+      slab = max64(slab, c.wsize() + (int64_t)wgrad_pick_splits((int)g.ntile, Cout, Cin, g.np) * Cout * g.np * Cin);
+      t.wino_V[0] = t.falloc(g.np * g.prow * Cin);
+      t.wino_U[0] = t.falloc((int64_t)g.np * Cout * Cin);
+      t.wino_Us[0] = t.falloc((int64_t)g.np * Cout * Cin);
+      t.wino_dM[0] = t.falloc(g.np * g.prow * Cout);
+      t.wino_us_valid[0] = 0; t.wino_v_batch[0] = 0; t.wino_dm_batch[0] = 0;
+      t.wino_m_n = g.np * g.prow * max64(Cout, Cin);
+      t.wino_m = t.falloc(t.wino_m_n); t.wino_dv = t.falloc(t.wino_m_n);
+      if (!t.wino_V[0] || !t.wino_U[0] || !t.wino_Us[0] || !t.wino_dM[0] || !t.wino_m || !t.wino_dv) return;
+    }
+    t.ws_wg = t.falloc(slab);
+    ok = t.Wp && t.na && t.nb && t.ws_conv && t.ws_wg;
+  }
+  ~ScratchEngine() {
+    (void)hipStreamSynchronize(t.s);
+    for (void* q : t.allocs) (void)hipFree(q);
+  }
+};
+}  // namespace
+
+int eosvos_test_conv_algo(eosvos_engine* e, int algo, const float* x, const float* w_oihw, const float* scale,
+                          const float* bias, const float* res, int relu, int B, int H, int W, int Cin, int Cout, int k,
+                          int stride, int dil, int pad, float* y) {
   if (!e || !x || !w_oihw || !y) return fail("null argument");
   if (Cin % 4 || Cout % 4) return fail("channels must be multiples of 4");
-  float *w = nullptr, *ws = nullptr;
-  const int T = k * k;
-  HIPOK(hipMalloc((void**)&w, (size_t)Cout * Cin * T * 4));
-  launch_oihw_to_ohwi(w_oihw, w, Cout, Cin, T, e->s);
-  ConvArgs a;
-  memset(&a, 0, sizeof(a));
-  a.x = x; a.w = w; a.y = y;
-  a.B = B; a.Hi = H; a.Wi = W; a.ldx = Cin; a.Kc = Cin;
-  a.Ho = conv_out(H, k, stride, dil, pad); a.Wo = conv_out(W, k, stride, dil, pad);
-  a.N = Cout; a.ldy = Cout; a.KH = a.KW = k; a.mul = stride; a.off0 = -pad; a.kstep = dil;
-  a.M = B * a.Ho * a.Wo; a.wN = Cout; a.wK = Cin; a.scale = scale; a.bias = bias; a.res = res; a.ldres = Cout;
-  a.relu = relu;
-  HIPOK(hipMalloc((void**)&ws, (size_t)conv_ws_floats() * 4));
-  a.ws = ws;
-  launch_conv(a, e->s);
-  HIPOK(hipStreamSynchronize(e->s));
-  (void)hipFree(w);
-  (void)hipFree(ws);
+  if (algo < EOSVOS_ALGO_AUTO || algo > EOSVOS_ALGO_WINO_F4) return fail("unknown conv algorithm");
+  if ((scale == nullptr) != (bias == nullptr)) return fail("scale and bias go together (folded norm)");
+  ScratchEngine se(e, algo, B, H, W, Cin, Cout, k, stride, dil, pad, scale != nullptr);
+  if (!se.ok) return fail("scratch engine: shape not eligible for the requested algorithm, or out of memory");
+  eosvos_engine* t = &se.t;
+  launch_oihw_to_ohwi(w_oihw, t->Wp, Cout, Cin, k * k, t->s);
+  if (scale) {
+    HIPOK(hipMemcpyAsync(t->na, scale, (size_t)Cout * 4, hipMemcpyDeviceToDevice, t->s));
+    HIPOK(hipMemcpyAsync(t->nb, bias, (size_t)Cout * 4, hipMemcpyDeviceToDevice, t->s));
+  }
+  if (res && wino_on(t, 0, B, conv_out(H, k, stride, dil, pad), conv_out(W, k, stride, dil, pad)))
+    return fail("the Winograd output transform has no residual input (the network never needs one)");
+  conv_fwd(t, 0, x, Cin, H, W, y, Cout, B, res, Cout, relu != 0);
+  HIPOK(hipStreamSynchronize(t->s));
   HIPOK(hipGetLastError());
   return 0;
 }
-int eosvos_test_conv_bwd(eosvos_engine* e, const float* x, const float* w_oihw, const float* g, int B, int H, int W,
-                         int Cin, int Cout, int k, int stride, int dil, int pad, float* dx, float* dw_oihw) {
+int eosvos_test_conv_bwd_algo(eosvos_engine* e, int algo, const float* x, const float* w_oihw, const float* g,
+                              const float* scale, const float* mask, int B, int H, int W, int Cin, int Cout, int k, int stride,
+                              int dil, int pad, float* dx, float* dw_oihw) {
   if (!e || !x || !w_oihw || !g || !dx || !dw_oihw) return fail("null argument");
   if (Cin % 4 || Cout % 4) return fail("channels must be multiples of 4");
+  if (algo < EOSVOS_ALGO_AUTO || algo > EOSVOS_ALGO_WINO_F4) return fail("unknown conv algorithm");
+  ScratchEngine se(e, algo, B, H, W, Cin, Cout, k, stride, dil, pad, scale != nullptr);
+  if (!se.ok) return fail("scratch engine: shape not eligible for the requested algorithm, or out of memory");
+  eosvos_engine* t = &se.t;
   const int T = k * k;
-  const int Ho = conv_out(H, k, stride, dil, pad), Wo = conv_out(W, k, stride, dil, pad);
-  float *w = nullptr, *ws = nullptr, *wsw = nullptr, *dw = nullptr;
-  HIPOK(hipMalloc((void**)&w, (size_t)Cout * Cin * T * 4));
-  HIPOK(hipMalloc((void**)&dw, (size_t)Cout * Cin * T * 4));
-  launch_oihw_to_ohwi(w_oihw, w, Cout, Cin, T, e->s);
-  ConvArgs a;
-  memset(&a, 0, sizeof(a));
-  a.x = g; a.w = w; a.y = dx;
-  a.B = B; a.Hi = Ho; a.Wi = Wo; a.ldx = Cout; a.Kc = Cout;
-  a.Ho = H; a.Wo = W; a.N = Cin; a.ldy = Cin; a.KH = a.KW = k; a.mul = 1; a.off0 = pad; a.kstep = -dil;
-  a.upshift = stride == 2 ? 1 : 0;
-  a.M = B * H * W; a.wN = Cout; a.wK = Cin; a.kmajor = 1;
-  HIPOK(hipMalloc((void**)&ws, (size_t)conv_ws_floats() * 4));
-  a.ws = ws;
-  launch_conv(a, e->s);
-  WgradArgs g2;
-  memset(&g2, 0, sizeof(g2));
-  g2.g = g; g2.x = x; g2.B = B; g2.Ho = Ho; g2.Wo = Wo; g2.ldg = Cout; g2.Cout = Cout; g2.Hi = H; g2.Wi = W;
-  g2.ldx = Cin; g2.Cin = Cin; g2.KH = g2.KW = k; g2.stride = stride; g2.pad = pad; g2.dil = dil;
-  g2.splits = wgrad_pick_splits(B * Ho * Wo, Cout, Cin, T);
-  HIPOK(hipMalloc((void**)&wsw, (size_t)g2.splits * Cout * Cin * T * 4));
-  g2.ws = wsw;
-  launch_wgrad(g2, e->s);
+  launch_oihw_to_ohwi(w_oihw, t->Wp, Cout, Cin, T, t->s);
+  if (scale) HIPOK(hipMemcpyAsync(t->na, scale, (size_t)Cout * 4, hipMemcpyDeviceToDevice, t->s));
+  // the order of the backward pass: weight gradient first (it makes the shared Winograd-domain dM), then data gradient
+  const int nslabs = conv_wgrad(t, 0, g, Cout, x, Cin, H, W, B);
+  conv_dgrad(t, 0, g, Cout, H, W, dx, Cin, B, false, mask, Cin, 0);
+  float* dw = t->falloc((int64_t)Cout * Cin * T);
+  if (!dw) return fail("hipMalloc dw");
   const int64_t n = (int64_t)Cout * Cin * T;
-  launch_sgd_update(dw, wsw, g2.splits, n, nullptr, nullptr, nullptr, dw, (int64_t)T * Cin, n, e->s);
-  launch_ohwi_to_oihw(dw, dw_oihw, Cout, Cin, T, 1.f, 0, e->s);
-  HIPOK(hipStreamSynchronize(e->s));
-  (void)hipFree(w); (void)hipFree(ws); (void)hipFree(wsw); (void)hipFree(dw);
+  launch_sgd_update(dw, t->ws_wg, nslabs, n, scale ? t->na : nullptr, nullptr, nullptr, dw, (int64_t)T * Cin, n, t->s);
+  launch_ohwi_to_oihw(dw, dw_oihw, Cout, Cin, T, 1.f, 0, t->s);
+  HIPOK(hipStreamSynchronize(t->s));
   HIPOK(hipGetLastError());
   return 0;
+}
+int eosvos_test_conv(eosvos_engine* e, const float* x, const float* w_oihw, const float* scale, const float* bias,
+                     const float* res, int relu, int B, int H, int W, int Cin, int Cout, int k, int stride, int dil,
+                     int pad, float* y) {
+  return eosvos_test_conv_algo(e, EOSVOS_ALGO_DIRECT, x, w_oihw, scale, bias, res, relu, B, H, W, Cin, Cout, k, stride, dil, pad, y);
+}
+int eosvos_test_conv_bwd(eosvos_engine* e, const float* x, const float* w_oihw, const float* g, int B, int H, int W,
+                         int Cin, int Cout, int k, int stride, int dil, int pad, float* dx, float* dw_oihw) {
+  return eosvos_test_conv_bwd_algo(e, EOSVOS_ALGO_DIRECT, x, w_oihw, g, nullptr, nullptr, B, H, W, Cin, Cout, k, stride, dil, pad, dx,
+                                   dw_oihw);
 }
 
 }  // extern "C"

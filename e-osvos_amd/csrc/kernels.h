@@ -76,6 +76,7 @@ inline int conv_par_pixel(int B, int Ho, int Wo, int m) {
 // fills a.per, launches the stream-K kernel (+ the fix-up kernel when tiles are shared)
 void launch_conv(ConvArgs& a, hipStream_t s);
 int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
+void conv_set_mfma_mode(int mode);
 int conv_mfma_mode();                // 1: bf16x6 split kernels (default), 0: fp32 MFMA kernels (EOSVOS_MFMA=f32)
 // calibration: back-to-back fp32 MFMAs, returns the FLOPs the launch performs
 double launch_mfma_probe(float* scratch, int iters, hipStream_t s);

@@ -24,6 +24,15 @@ LR_LEVELS = {'NEURON': 0, 'TENSOR': 1, 'SINGLE': 2, 'PARAM': 3}      # include/e
 LOSS_KINDS = {'cross_entropy': 0, 'dice': 1, 'cross_entropy_and_dice': 2, 'class_balanced_cross_entropy': 3}
 
 
+def set_matrix_mode(mode):
+    """'bf16x6' (default) or 'f32': how the convolutions' fp32 contractions use the matrix cores (process-wide)."""
+    _ffi.check(_ffi.load().eosvos_set_matrix_mode({'f32': 0, 'bf16x6': 1}[mode]))
+
+
+def get_matrix_mode():
+    return 'bf16x6' if _ffi.load().eosvos_get_matrix_mode() == 1 else 'f32'
+
+
 class Engine:
     def __init__(self, encoder='resnet50', height=480, width=854, max_batch=3, device='cuda:0', norm='bn'):
         if not torch.cuda.is_available():
@@ -284,6 +293,32 @@ class Engine:
         _ffi.check(self.lib.eosvos_test_conv(self.h, _ptr(x_nhwc), _ptr(w_oihw), p(scale), p(bias), p(res),
                                              int(relu), B, H, W, Cin, Cout, k, stride, dil, pad, _ptr(y)))
         return y
+
+    ALGOS = {'auto': 0, 'direct': 1, 'wino_f2': 2, 'wino_f4': 3}          # include/eosvos.h EOSVOS_ALGO_*
+
+    def test_conv_algo(self, algo, x_nhwc, w_oihw, scale, bias, res, relu, stride, dil, pad):
+        """One conv through the production forward path with the algorithm forced."""
+        B, H, W, Cin = x_nhwc.shape
+        Cout, _, k, _ = w_oihw.shape
+        Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        y = torch.empty(B, Ho, Wo, Cout, device=self.device)
+        p = lambda t: _ptr(t) if t is not None else None
+        _ffi.check(self.lib.eosvos_test_conv_algo(self.h, self.ALGOS[algo], _ptr(x_nhwc), _ptr(w_oihw), p(scale), p(bias),
+                                                  p(res), int(relu), B, H, W, Cin, Cout, k, stride, dil, pad, _ptr(y)))
+        return y
+
+    def test_conv_bwd_algo(self, algo, x_nhwc, w_oihw, g_nhwc, stride, dil, pad, scale=None, mask=None):
+        """(dx, dw) through the production weight- / data-gradient paths with the algorithm forced."""
+        B, H, W, Cin = x_nhwc.shape
+        Cout, _, k, _ = w_oihw.shape
+        dx = torch.empty_like(x_nhwc)
+        dw = torch.empty_like(w_oihw)
+        p = lambda t: _ptr(t) if t is not None else None
+        _ffi.check(self.lib.eosvos_test_conv_bwd_algo(self.h, self.ALGOS[algo], _ptr(x_nhwc), _ptr(w_oihw), _ptr(g_nhwc),
+                                                      p(scale), p(mask), B, H, W, Cin, Cout, k, stride, dil, pad, _ptr(dx),
+                                                      _ptr(dw)))
+        return dx, dw
 
     def test_conv_bwd(self, x_nhwc, w_oihw, g_nhwc, stride, dil, pad):
         B, H, W, Cin = x_nhwc.shape

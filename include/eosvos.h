@@ -43,6 +43,16 @@ typedef struct eosvos_engine eosvos_engine;
 const char* eosvos_version(void);
 const char* eosvos_last_error(void);
 
+/* How the fp32 contractions of the convolutions run on the matrix cores (process-wide; results agree to fp32
+ * rounding):
+ *   BF16X6 (default): every fp32 operand is split exactly into three bf16 pieces and the product is accumulated
+ *          in fp32 from the six leading partial products on v_mfma_f32_32x32x16_bf16 (error <= fp32 MFMA's);
+ *   F32:   v_mfma_f32_32x32x2_f32 (1/16 of the bf16 rate on CDNA4).  Also selected by EOSVOS_MFMA=f32. */
+#define EOSVOS_MATRIX_F32 0
+#define EOSVOS_MATRIX_BF16X6 1
+int eosvos_set_matrix_mode(int mode);
+int eosvos_get_matrix_mode(void);
+
 /* Number of convolutions of DeepLabV3+ on `arch` (63 for ResNet-50); -1 on bad arch.
  * Replaces: module enumeration of networks/deeplabv3plus.py:104-155. */
 int eosvos_num_convs(int arch);
@@ -226,7 +236,25 @@ int eosvos_test_conv(eosvos_engine* e, const float* x_nhwc, const float* w_oihw,
                      const float* scale, const float* bias, const float* res_nhwc, int relu,
                      int B, int H, int W, int Cin, int Cout, int k, int stride, int dil, int pad,
                      float* y_nhwc);
-/* dx = conv_dgrad(g), dw = conv_wgrad(g, x) for the same geometry (no norm scale). */
+/* Convolution algorithm of the *_algo entry points.  AUTO plans by work size like the network does. */
+#define EOSVOS_ALGO_AUTO 0
+#define EOSVOS_ALGO_DIRECT 1   /* implicit GEMM (tap tables / parity-major rows / coarse-grid stride-2 gradient included) */
+#define EOSVOS_ALGO_WINO_F2 2  /* Winograd F(2x2,3x3); dilated convs as d*d interleaved sub-grids */
+#define EOSVOS_ALGO_WINO_F4 3  /* Winograd F(4x4,3x3) */
+/* The same convolution through the production forward path with the algorithm forced (3x3 / stride 1 /
+ * pad == dilation <= 8 for the Winograd forms).  torchvision Bottleneck / ASPP / decoder convs, SURVEY 2.2 K3/K4. */
+int eosvos_test_conv_algo(eosvos_engine* e, int algo, const float* x_nhwc, const float* w_oihw,
+                          const float* scale, const float* bias, const float* res_nhwc, int relu,
+                          int B, int H, int W, int Cin, int Cout, int k, int stride, int dil, int pad,
+                          float* y_nhwc);
+/* dx = mask?(dgrad(scale*g)), dw = scale * wgrad(g, x) through the production backward paths; `scale` (per cout,
+ * the folded norm scale) and `mask` (NHWC like x: dx = 0 where mask <= 0, the ReLU mask of the conv input) may be
+ * NULL. */
+int eosvos_test_conv_bwd_algo(eosvos_engine* e, int algo, const float* x_nhwc, const float* w_oihw,
+                              const float* g_nhwc, const float* scale, const float* mask_nhwc, int B, int H, int W,
+                              int Cin, int Cout, int k, int stride, int dil, int pad, float* dx_nhwc,
+                              float* dw_oihw);
+/* dx = conv_dgrad(g), dw = conv_wgrad(g, x) for the same geometry (no norm scale), ALGO_DIRECT. */
 int eosvos_test_conv_bwd(eosvos_engine* e, const float* x_nhwc, const float* w_oihw,
                          const float* g_nhwc, int B, int H, int W, int Cin, int Cout, int k,
                          int stride, int dil, int pad, float* dx_nhwc, float* dw_oihw);

@@ -1,0 +1,157 @@
+"""Op-level parity of every convolution path on the GPU, through the C-ABI (eosvos_test_conv_algo /
+eosvos_test_conv_bwd_algo drive the production conv_fwd / conv_dgrad / conv_wgrad): implicit GEMM, Winograd
+F(2x2,3x3), F(4x4,3x3) and their dilated sub-grid forms, forward + data gradient + weight gradient compared
+ELEMENTWISE with an fp64 torch convolution of the same op (torchvision Bottleneck / ASPP / decoder convs,
+SURVEY 2.2 K3/K4).  Also pins the accuracy claim of the bf16x6 matrix mode against the fp32 MFMA.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from eosvos_amd import engine as engine_mod
+from eosvos_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def eng():
+    e = Engine('resnet50', 96, 160, max_batch=1, device=DEV)
+    yield e
+    e.close()
+
+
+def _maxrel(a, ref):
+    a, ref = a.double().cpu(), ref.double()
+    return float((a - ref).abs().max() / ref.abs().max())
+
+
+def _rmsrel(a, ref):
+    a, ref = a.double().cpu(), ref.double()
+    return float(((a - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+
+
+def _case(case, seed):
+    B, H, W, Ci, Co, d = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    x = x * (torch.rand(B, Ci, H, W, generator=g) > 0.3)          # a ReLU output: exact zeros, mask = x > 0
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    a = torch.rand(Co, generator=g) + 0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    gy = torch.randn(B, Co, H, W, generator=g)
+    return x, w, a, b, gy
+
+
+def _reference(x, w, a, b, gy, d):
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y = F.conv2d(xd, wd, None, 1, d, d)
+    out = F.relu(y * a.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1))
+    y.backward(gy.double() * a.double().view(1, -1, 1, 1))      # engine gradients are w.r.t. the post-norm, pre-ReLU output
+    dx = xd.grad * (x > 0)                                       # ReLU mask of the conv input
+    return out.detach(), dx, wd.grad
+
+
+nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+# (B, H, W, Cin, Cout, dilation)  -- shapes of the network's Winograd layers and awkward borders
+WINO_CASES = [
+    ('wino_f4', (1, 120, 214, 304, 256, 1)),      # decoder.last_conv.0 at 480x854 (tail launch for the 304 input channels)
+    ('wino_f4', (3, 30, 54, 256, 256, 1)),        # batch 3
+    ('wino_f4', (1, 30, 54, 512, 512, 2)),        # layer4 conv2, d = 2, 4, 8: F(4,3) on the d*d sub-grids
+    ('wino_f4', (1, 30, 54, 512, 512, 4)),
+    ('wino_f4', (1, 30, 54, 512, 512, 8)),
+    ('wino_f2', (1, 30, 54, 512, 512, 8)),
+    ('wino_f2', (1, 30, 54, 2048, 256, 6)),       # ASPP d = 6
+    ('wino_f4', (1, 97, 161, 64, 64, 1)),         # 97 = 24*4 + 1, 161 = 40*4 + 1: tiles straddle both borders
+    ('wino_f2', (1, 97, 161, 64, 64, 1)),
+    ('wino_f2', (2, 31, 55, 128, 64, 3)),         # odd sub-grids: (11,10,10) x (19,18,18)
+    ('wino_f4', (1, 33, 57, 64, 128, 2)),
+    ('wino_f2', (1, 5, 7, 64, 64, 1)),            # smaller than one F(4,3) tile row
+    ('direct', (1, 30, 54, 2048, 256, 12)),       # tap tables (d = 12, 18 keep the implicit-GEMM kernel)
+    ('direct', (1, 30, 54, 2048, 256, 18)),
+    ('direct', (1, 120, 214, 304, 256, 1)),
+]
+# measured maxima (profiles/r02_conv_algo_margins.txt): direct 3e-7, F(2,3) 1e-6, F(4,3) 8e-6 of the output scale
+TOL = {'direct': 3e-6, 'wino_f2': 6e-6, 'wino_f4': 2.5e-5}
+
+
+@pytest.mark.parametrize('algo,case', WINO_CASES)
+def test_conv_paths_elementwise_vs_fp64(eng, algo, case):
+    x, w, a, b, gy = _case(case, seed=sum(case))
+    out_ref, dx_ref, dw_ref = _reference(x, w, a, b, gy, case[5])
+    d = case[5]
+    out = eng.test_conv_algo(algo, nhwc(x), w.to(DEV), a.to(DEV), b.to(DEV), None, True, 1, d, d)
+    dx, dw = eng.test_conv_bwd_algo(algo, nhwc(x), w.to(DEV), nhwc(gy), 1, d, d, scale=a.to(DEV), mask=nhwc(x))
+    errs = (_maxrel(out.permute(0, 3, 1, 2), out_ref), _maxrel(dx.permute(0, 3, 1, 2), dx_ref), _maxrel(dw, dw_ref))
+    print(f'MARGIN {algo} {case} fwd {errs[0]:.2e} dx {errs[1]:.2e} dw {errs[2]:.2e}')
+    assert max(errs) <= TOL[algo], errs
+    # ReLU mask of the data gradient is exact
+    assert bool((dx.permute(0, 3, 1, 2).cpu()[x <= 0] == 0).all())
+
+
+def test_forced_algo_rejects_ineligible_shapes(eng):
+    x = torch.randn(1, 8, 8, 64, device=DEV)
+    w = torch.randn(64, 64, 3, 3, device=DEV)
+    from eosvos_amd._ffi import EosvosError
+    with pytest.raises(EosvosError):
+        eng.test_conv_algo('wino_f4', x, w, None, None, None, False, 2, 1, 1)          # stride 2 has no Winograd form
+    w1 = torch.randn(64, 64, 1, 1, device=DEV)
+    with pytest.raises(EosvosError):
+        eng.test_conv_algo('wino_f2', x, w1, None, None, None, False, 1, 1, 0)
+
+
+STRIDED_CASES = [          # (B, H, W, Cin, Cout, k, stride, dil, pad): the non-Winograd production paths
+    (3, 60, 107, 512, 256, 1, 2, 1, 0),           # layer3.0.conv1: coarse-grid gradient scattered to the even pixels
+    (1, 120, 214, 128, 128, 3, 2, 1, 1),          # layer2.0.conv2: parity-major data gradient
+    (2, 30, 54, 1280, 256, 1, 1, 1, 0),           # ASPP projection
+    (1, 120, 214, 256, 48, 1, 1, 1, 0),           # decoder.conv1 (N = 48)
+]
+
+
+@pytest.mark.parametrize('case', STRIDED_CASES)
+def test_strided_and_narrow_paths_elementwise_vs_fp64(eng, case):
+    B, H, W, Ci, Co, k, s, d, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = F.conv2d(xd, wd, None, s, p, d)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.double())
+    out = eng.test_conv_algo('auto', nhwc(x), w.to(DEV), None, None, None, False, s, d, p)
+    dx, dw = eng.test_conv_bwd_algo('auto', nhwc(x), w.to(DEV), nhwc(gy), s, d, p)
+    errs = (_maxrel(out.permute(0, 3, 1, 2), y.detach()), _maxrel(dx.permute(0, 3, 1, 2), xd.grad), _maxrel(dw, wd.grad))
+    print(f'MARGIN auto {case} fwd {errs[0]:.2e} dx {errs[1]:.2e} dw {errs[2]:.2e}')
+    assert max(errs) <= 2e-6, errs
+
+
+def test_bf16x6_is_at_least_as_accurate_as_the_fp32_mfma(eng):
+    """The default matrix mode splits every fp32 operand exactly into 3 bf16 pieces and sums the 6 leading partial
+    products in fp32; its error against fp64 must not exceed the fp32 MFMA's (both ~1e-7 of sum|a*b|)."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Ci, Co = 1, 30, 54, 2048, 512
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    ref = F.conv2d(x.double(), w.double())
+    sabs = F.conv2d(x.double().abs(), w.double().abs())
+    gy = torch.randn(B, Co, H, W, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv2d(xd, wd).backward(gy.double())
+    res = {}
+    try:
+        for mode in ('f32', 'bf16x6'):
+            engine_mod.set_matrix_mode(mode)
+            assert engine_mod.get_matrix_mode() == mode
+            out = eng.test_conv_algo('direct', nhwc(x), w.to(DEV), None, None, None, False, 1, 1, 0).permute(0, 3, 1, 2)
+            dx, dw = eng.test_conv_bwd_algo('direct', nhwc(x), w.to(DEV), nhwc(gy), 1, 1, 0)
+            res[mode] = (float(((out.double().cpu() - ref).abs() / sabs).max()), _rmsrel(out, ref),
+                         _rmsrel(dx.permute(0, 3, 1, 2), xd.grad), _rmsrel(dw, wd.grad))
+    finally:
+        engine_mod.set_matrix_mode('bf16x6')
+    print('MARGIN matrix modes (max err/sum|ab|, rms rel fwd, dx, dw):', res)
+    for i in range(4):
+        assert res['bf16x6'][i] <= 1.25 * res['f32'][i] + 1e-9, res
+    assert res['bf16x6'][0] < 3e-7 and res['bf16x6'][1] < 1e-6

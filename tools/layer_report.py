@@ -12,10 +12,11 @@ from collections import defaultdict
 def main(trace_csv, log, steps=3):
     rows = [r for r in csv.DictReader(open(trace_csv))]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    mf = [r for r in rows if 'conv_igemm_kernel' in r['Kernel_Name'] or 'wgrad_kernel<' in r['Kernel_Name']]
+    is_conv = lambda n: 'conv_igemm_kernel' in n or 'conv_x6_kernel' in n
+    mf = [r for r in rows if is_conv(r['Kernel_Name']) or 'wgrad_kernel<' in r['Kernel_Name'] or 'wgrad_x6_kernel<' in r['Kernel_Name']]
     # fix-up launch that follows a conv launch (same stream order)
     for i, r in enumerate(rows):
-        if 'conv_igemm_kernel' in r['Kernel_Name']:
+        if is_conv(r['Kernel_Name']):
             nx = rows[i + 1] if i + 1 < len(rows) else None
             r['fix_ns'] = (int(nx['End_Timestamp']) - int(nx['Start_Timestamp'])) if nx is not None and 'conv_fixup' in nx['Kernel_Name'] else 0
     launches = []
@@ -40,11 +41,11 @@ def main(trace_csv, log, steps=3):
             a[0] += d; a[1] += fl; a[2] += 1; a[3] = (M, N, K, sp, int(mf[i]['Grid_Size_X']) // 256)
     tot_t = tot_f = 0
     by_kind = defaultdict(lambda: [0.0, 0.0])
-    print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6} {"excess_us@120":>13} {"fixup":>7}')
+    print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6} {"excess_us@200":>13} {"fixup":>7}')
     excess = []
     for (pos, k, ci), (t, f, n, info) in sorted(agg.items()):
         us = t / n / 1e3
-        ex = us - f / n / 120e6        # time above what the layer would take at 120 TFLOP/s
+        ex = us - f / n / 200e6        # time above what the layer would take at 200 TFLOP/s (fp32-equivalent)
         excess.append((ex, pos, k, ci))
         print(f'{pos:3d} {k:6} {ci:4d} {info[0]:7d} {info[1]:6d} {info[2]:6d} {info[3]:3d} {info[4]:5d} {us:8.1f} {f / t / 1e3:6.1f} {ex:13.1f} {fixt[(pos, k, ci)] / n / 1e3:7.1f}')
         tot_t += t / n; tot_f += f / n
@@ -53,7 +54,7 @@ def main(trace_csv, log, steps=3):
     for k, (t, f) in by_kind.items():
         print(f'  {k:6s} {t / 1e6:7.2f} ms {f / t / 1e3:6.1f} TF/s')
     excess.sort(reverse=True)
-    print('largest excess over a 120 TFLOP/s pace: ' + ', '.join(f'{k}{ci}:{ex:.0f}us' for ex, pos, k, ci in excess[:24]))
+    print('largest excess over a 200 TFLOP/s pace: ' + ', '.join(f'{k}{ci}:{ex:.0f}us' for ex, pos, k, ci in excess[:24]))
     print('total excess: %.2f ms' % (sum(e[0] for e in excess if e[0] > 0) / 1e3))
     nsteps = max(1, len(starts))
     byname = defaultdict(lambda: [0, 0])
