@@ -633,13 +633,16 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   int dp_i = 0;
 
   constexpr int APASS = BM / 32;                         // 8 float4 per 32-k row, 32 rows per pass
-  const int a_c4 = tid & 7, a_r = tid >> 3;
+  // row of a staging pass: the two rows of a 16-lane ds_write_b64 group are 4 rows (320 B) apart -> disjoint banks
+  const int a_c4 = tid & 7, a_r = (wave << 3) + (((lane >> 3) & 1) << 2) + (lane >> 4);
   // B operand: rows of k (n-major weights, forward) staged like A; k-major weights (data gradient): a thread owns
   // RPT consecutive k rows x 4 columns
   constexpr int NQ = BN / 4, RPT = BN / 32;              // K-major: threads per k row, k rows per thread
   constexpr int BPASS = BN / 32;                         // = RPT: float4 loads per thread in both layouts
-  const int b_c4 = tid & 7, b_r = tid >> 3;
-  const int b_n4 = tid % NQ, b_kq = tid / NQ;
+  const int b_c4 = a_c4, b_r = a_r;
+  // K-major: a 16-lane write group = 8 columns x 2 k runs (bank-conflict free at the 80-byte pitch)
+  const int b_n4 = RPT == 4 ? ((tid & 7) | (((tid >> 4) & 3) << 3)) : tid % NQ;
+  const int b_kq = RPT == 4 ? (((tid >> 3) & 1) | ((tid >> 6) << 1)) : tid / NQ;
   const int up = 1 << p.upshift;
   constexpr int TN = BN / 64;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
@@ -942,8 +945,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
 
   // a thread owns RPT consecutive pixels x 4 channels of each operand
   constexpr int ANQ = BMO / 4, ARPT = BMO / 32, BNQ = BNI / 4, BRPT = BNI / 32;
-  const int a_c4 = tid % ANQ, a_kq = tid / ANQ;
-  const int b_c4 = tid % BNQ, b_kq = tid / BNQ;
+  const int c4_128 = (tid & 7) | (((tid >> 4) & 3) << 3), kq_128 = ((tid >> 3) & 1) | ((tid >> 6) << 1);   // see conv_x6_kernel
+  const int a_c4 = ARPT == 4 ? c4_128 : tid % ANQ, a_kq = ARPT == 4 ? kq_128 : tid / ANQ;
+  const int b_c4 = BRPT == 4 ? c4_128 : tid % BNQ, b_kq = BRPT == 4 ? kq_128 : tid / BNQ;
   const bool a_cok = (co0 + a_c4 * 4) < p.Cout;
   const bool b_cok = (ci0 + b_c4 * 4) < p.Cin;
   float4 ra[ARPT], rb[BRPT];
@@ -1066,6 +1070,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
 }
 
 // EOSVOS_MFMA=f32 selects the fp32-MFMA kernels (A/B and fallback); default: bf16x6
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && v[0]) ? atoi(v) : dflt;
+}
 static int g_mfma_mode = -1;
 int conv_mfma_mode() {
   if (g_mfma_mode < 0) {
@@ -1122,7 +1130,8 @@ int conv_plan(ConvArgs& a) {
     if ((ksteps <= EOSVOS_MINK + 1 || dp_small) && a.total_units <= 0) {
       per = ksteps; nwg = tiles;                       // no fix-up
     } else {
-      if (U / nwg < EOSVOS_MINK) nwg = U / EOSVOS_MINK > 0 ? U / EOSVOS_MINK : 1;   // >= MINK K-steps per workgroup
+      static const int mink = env_int("EOSVOS_TUNE_MINK", EOSVOS_MINK);
+      if (U / nwg < mink) nwg = U / mink > 0 ? U / mink : 1;   // >= MINK K-steps per workgroup
       per = (U + nwg - 1) / nwg;
       nwg = (U + per - 1) / per;
     }
@@ -1357,7 +1366,8 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
   constexpr int RES = 256 * EOSVOS_WG_OCC;
   int best = 1;
   double best_eff = 0.0;
-  for (int s = 1; s <= 512 && steps / s >= 128 / EOSVOS_WG_BKP; ++s) {
+  static const int minsteps = env_int("EOSVOS_TUNE_WG_MINSTEPS", 128 / EOSVOS_WG_BKP);
+  for (int s = 1; s <= 512 && steps / s >= minsteps; ++s) {
     const long wgs = (long)tiles * s;
     const long rounds = (wgs + RES - 1) / RES;
     const double eff = (double)wgs / (double)(rounds * RES);
