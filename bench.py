@@ -14,6 +14,13 @@ B=1, RCCL all-reduce of the 161 MB meta-gradient + fused RAdam at N > 1);
 `--metric meta` makes that the headline of the JSON line instead (BASELINE configs[3..4]:
 one task per rank per meta-iteration, a step = one meta-iteration).
 
+`roofline` is about the kernel symbol that takes the most time in a step, found and timed live: after the timed
+region the same steps run once more with HIP events around every matrix-core launch, recorded on the stream each
+launch runs on (eosvos_profile_launches); achieved = that kernel's executed fp32-equivalent FLOPs / its summed
+duration.  The arithmetic is fp32 (dtype "f32"): in the default matrix mode every fp32 operand is split exactly into
+three bf16 pieces and each product is accumulated in fp32 from its six leading partial products on the bf16 MFMA
+(error <= the fp32 MFMA's, tests/test_gpu_conv_algos.py), so the roof that bounds it is the dense bf16 MFMA peak / 6.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -29,37 +36,124 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H, W, BATCH = 480, 854, 3
-FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad, no stem dgrad
+FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad as direct convolutions, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
-HOT_KERNEL_TRAFFIC_BYTES = (2 * 126.9e3 + 220.4e3) * 1024   # PMC, see profiles/r01_pmc_hot_kernel.txt
+BF16_DENSE_PEAK = 2500.0            # TFLOP/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_dominant_kernel.json')
 
 
-def cpu_baseline(sd, lrs, x, y, seconds_budget=25.0):
-    """The CPU oracle (oracle/meta.py, torch fp32, all host cores) timed on a bounded sample
-    of the same workload: whole B=3 fine-tune iterations until ~seconds_budget is used."""
+def matrix_peak(mode):
+    """fp32-equivalent TFLOP/s roof of the matrix mode: bf16x6 issues 6 bf16 MFMAs per fp32 multiply-accumulate."""
+    return BF16_DENSE_PEAK / 6.0 if mode == 'bf16x6' else FP32_MATRIX_PEAK
+
+
+def cpu_threads():
+    # oneDNN stops scaling (and thrashes) far below the hardware threads of the GPU box's host
+    return min(os.cpu_count() or 1, 32)
+
+
+def cpu_baseline_finetune(sd, lrs, x, y, seconds_budget=25.0):
+    """The CPU oracle (oracle/meta.py, torch fp32) timed on whole batch-3 fine-tune iterations of the benchmarked
+    workload: 1 warm-up + >= 3 timed iterations (bounded by ~seconds_budget)."""
     from oracle import meta
-    # oneDNN stops scaling (and thrashes) far below the 256 hardware threads of the GPU
-    # box's host; 32 threads is what the timed sample actually uses.
-    cores = min(os.cpu_count() or 1, 32)
+    cores = cpu_threads()
     torch.set_num_threads(cores)
-    P = sd
-    meta.finetune_step(P, lrs, x[:1], y[:1])       # warm-up (oneDNN primitives, page-in)
-    # bounded sample: single-frame (batch 1) iterations of the same network/size; one
-    # batch-3 iteration costs 3 of them, so the batch-3 rate is frames/s / 3
+    _, _, P = meta.finetune_step(sd, lrs, x, y)              # warm-up (oneDNN primitives, page-in)
     n, t0 = 0, time.time()
     while True:
-        _, _, P = meta.finetune_step(P, lrs, x[:1], y[:1])
+        _, _, P = meta.finetune_step(P, lrs, x, y)
         n += 1
         dt = time.time() - t0
-        if dt > seconds_budget or n >= 12:
+        if n >= 3 and (dt > seconds_budget or n >= 8):
             break
-    return {'value': n / dt / x.shape[0], 'unit': 'finetune_iters/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} single-frame fine-tune iterations ({H}x{W}) of the torch-CPU oracle (oracle/meta.py) '
-                      f'on {cores} threads in {dt:.1f}s; value = frames/s / {x.shape[0]} (batch-{x.shape[0]} '
-                      f'iterations/s)'}
+    return {'value': n / dt, 'unit': 'finetune_iters/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} batch-{x.shape[0]} fine-tune iterations ({H}x{W}, the benchmarked workload) of the torch-CPU '
+                      f'oracle (oracle/meta.py) on {cores} threads in {dt:.1f}s after 1 warm-up iteration'}
 
 
-def bench_meta(a, eng, dist, rank, world, sd, lrs, xg, yg, barrier, dev):
+def cpu_baseline_meta(sd, lrs, x1, y1, xm, ym):
+    """One meta task (5 inner steps + meta frame, batch 1) of the CPU oracle after one warm-up inner step."""
+    from oracle import meta
+    cores = cpu_threads()
+    torch.set_num_threads(cores)
+    meta.finetune_step(sd, lrs, x1, y1)
+    t0 = time.time()
+    meta.meta_task(sd, lrs, [(x1, y1)] * 5, (xm, ym))
+    dt = time.time() - t0
+    return {'value': 1.0 / dt, 'unit': 'meta_tasks/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 meta task (5 inner steps + 1 meta frame, batch 1, {H}x{W}) of the torch-CPU oracle '
+                      f'(oracle/meta.py meta_task) on {cores} threads in {dt:.1f}s after 1 warm-up inner step'}
+
+
+def pmc_traffic(kernel, lib_version, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (tools/pmc_dominant.sh), if they were
+    taken for this library version / kernel / batch; else None."""
+    try:
+        p = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None, 'no PMC artifact'
+    if p.get('kernel') != kernel or p.get('lib_version') != lib_version or p.get('batch') != batch:
+        return None, f"PMC artifact is for {p.get('kernel')} / {p.get('lib_version')} / batch {p.get('batch')}"
+    return p['traffic_bytes_per_launch'], p.get('note', '')
+
+
+def profiled_pass(eng, run_step, steps):
+    """Per-kernel totals over `steps` more steps with HIP events around every matrix-core launch."""
+    eng.profile_launches(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    rows = eng.profile_read()
+    eng.profile_launches(False)
+    return rows, dt / steps
+
+
+def roofline_from(rows, steps, mode, lib_version, batch, ms_per_step):
+    mf = {k: v for k, v in rows.items() if 'fixup' not in k}
+    kernel = max(mf, key=lambda k: mf[k][1])
+    launches, ms, flops = mf[kernel]
+    achieved = flops / (ms * 1e-3) / 1e12
+    peak = matrix_peak(mode)
+    total_flops = sum(v[2] for v in mf.values()) / steps
+    traffic, note = pmc_traffic(kernel, lib_version, batch)
+    return {
+        'bound': 'mfma', 'kernel': kernel, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+        'peak_basis': ('dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per fp32 multiply-accumulate (fp32-equivalent)'
+                       if mode == 'bf16x6' else 'fp32 MFMA peak'),
+        'achieved_is': 'executed fp32-equivalent FLOPs of all launches of this kernel symbol in the profiled steps / their '
+                       'summed HIP-event durations (padding taps skipped by the tap tables are not counted)',
+        'launches_per_step': launches / steps, 'avg_launch_us': 1e3 * ms / launches,
+        'flops_per_launch': flops / launches, 'share_of_step_kernel_time': ms / sum(v[1] for v in rows.values()),
+        'executed_bf16_tflops': 6 * achieved if mode == 'bf16x6' else None,
+        'frac_of_fp32_matrix_peak': achieved / FP32_MATRIX_PEAK,
+        'traffic': traffic, 'traffic_note': note,
+        'whole_step_executed_gflop': total_flops / 1e9,
+        'whole_step_executed_tflops': total_flops / (ms_per_step * 1e-3) / 1e12,
+        'whole_step_executed_frac': total_flops / (ms_per_step * 1e-3) / 1e12 / peak,
+        'whole_step_frac_of_fp32_matrix_peak': total_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MATRIX_PEAK,
+        'per_kernel': {k: {'launches_per_step': v[0] / steps, 'ms_per_step': v[1] / steps,
+                           'tflops': (v[2] / (v[1] * 1e-3) / 1e12) if v[1] > 0 else None} for k, v in sorted(rows.items())},
+    }
+
+
+def timed(fn, steps, barrier, dist, dev):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version):
     """meta-tasks/s: every rank runs one task (5 inner steps at batch 1 + the meta frame) per meta-iteration, then
     ONE all-reduce of the 161 MB meta-gradient and the fused RAdam step + lr clamp on every rank."""
     from eosvos_amd.meta_run import MetaTrainer
@@ -67,37 +161,31 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, xg, yg, barrier, dev):
     mt.load_state(sd, lrs)
     x1, y1 = xg[:1].contiguous(), yg[:1].contiguous()
     xm, ym = torch.flip(x1, dims=[3]).contiguous(), torch.flip(y1, dims=[3]).contiguous()
+    losses = []
+
+    def step():
+        losses[:] = mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
     for _ in range(a.warmup):
-        mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    k_ms, k_flops = eng.time_hot_kernel(1, reps=20)
-    achieved = k_flops / (k_ms * 1e-3) / 1e12
+        step()
+    dt = timed(step, a.steps, barrier, dist, dev)
+    ms_per_step = 1e3 * dt / a.steps
+    rows, _ = profiled_pass(eng, step, min(a.steps, 4))
+    roof = roofline_from(rows, min(a.steps, 4), mode, lib_version, 1, ms_per_step)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline_meta(sd, lrs, x[:1], y[:1], torch.flip(x[:1], dims=[3]), torch.flip(y[:1], dims=[3]))
     if rank == 0:
         out = {
             'metric': 'meta_tasks_per_sec', 'value': world * a.steps / dt, 'unit': 'meta_tasks/s', 'n_gpus': world,
-            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'meta-train iteration (BASELINE configs[3..4]): meta_batch_size = number of ranks, one '
                                    f'task per rank = 5 inner fine-tune steps + 1 meta frame at batch 1, {H}x{W}, BCE; one '
                                    'all-reduce(sum) of the 40.3 M-float meta-gradient, RAdam + lr clamp on every rank',
                        'meta_batch_size': world, 'inner_steps': 5, 'height': H, 'width': W,
                        'parallelism': f'tasks sharded x{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,2>: Winograd-domain batched GEMM of decoder.last_conv.0 forward, batch 1 '
-                                   '(own FLOPs)',
-                         'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MATRIX_PEAK, 'traffic': None, 'kernel_ms': k_ms,
-                         'flops_per_launch': k_flops,
-                         'whole_step_tflops': 6 * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12},   # 9-tap-equivalent FLOPs
-            'cpu_baseline': None, 'extra': {'last_meta_loss': losses[-1]},
+            'roofline': roof, 'cpu_baseline': cpu,
+            'extra': {'last_meta_loss': losses[-1], 'matrix_mode': mode, 'lib_version': lib_version},
         }
         print(json.dumps(out), flush=True)
     eng.close()
@@ -108,14 +196,18 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, xg, yg, barrier, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 200 fine-tune iterations / 40 '
+                                                             'meta-iterations, a timed region of about 2 s)')
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meta', action='store_true')
+    ap.add_argument('--no-ab', action='store_true', help='skip the fp32-MFMA-mode comparison in extra')
     ap.add_argument('--metric', choices=['finetune', 'meta'], default='finetune',
                     help="'meta': the JSON line reports meta-tasks/s (BASELINE configs[3..4]: one task per rank per "
                          "meta-iteration, all-reduce + RAdam included); a step is then one meta-iteration")
     a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 200 if a.metric == 'finetune' else 40
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -130,10 +222,13 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
     dev = f'cuda:{local_rank}'
 
-    from eosvos_amd import synthetic
+    from eosvos_amd import _ffi, synthetic
+    from eosvos_amd import engine as engine_mod
     from eosvos_amd.engine import Engine
     from eosvos_amd.meta_run import MetaTrainer
 
+    lib_version = _ffi.load().eosvos_version().decode()
+    mode = engine_mod.get_matrix_mode()
     sd = synthetic.synthetic_state('resnet50')
     lrs = synthetic.synthetic_lrs('resnet50')
     x, y = synthetic.synthetic_frames(BATCH, H, W, seed=7 + rank)
@@ -148,69 +243,58 @@ def main():
         torch.cuda.synchronize()
 
     if a.metric == 'meta':
-        return bench_meta(a, eng, dist, rank, world, sd, lrs, xg, yg, barrier, dev)
+        return bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version)
 
+    step = lambda: eng.finetune_step(xg, yg, sync_loss=False)
     for _ in range(a.warmup):
-        eng.finetune_step(xg, yg, sync_loss=False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        eng.finetune_step(xg, yg, sync_loss=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    last_loss = eng.finetune_step(xg, yg)           # sanity: still finite after K steps
+        step()
+    dt = timed(step, a.steps, barrier, dist, dev)
+    ms_per_step = 1e3 * dt / a.steps
     value = world * a.steps / dt
+    last_loss = eng.finetune_step(xg, yg)           # sanity: still finite after K steps
 
-    # dominant kernel, timed live with HIP events on the engine's stream
-    k_ms, k_flops = eng.time_hot_kernel(BATCH, reps=20)
-    achieved = k_flops / (k_ms * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,false,2>: batched GEMM of decoder.last_conv.0 forward in the Winograd '
-                'F(4x4,3x3) domain, 36 x [4860 tiles x 304] x [304 x 256] (+ its fix-up launch), the heaviest layer of the '
-                'network; achieved counts this GEMM\'s own FLOPs (4x fewer than the 9-tap form of the layer)', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MATRIX_PEAK,
-                # bytes per launch from the rocprofv3 --pmc passes of this kernel (separate runs,
-                # profiles/r01_pmc_hot_kernel.txt): 2*FETCH_SIZE (gfx950 half-count correction) +
-                # WRITE_SIZE; algorithmic bytes are 213 MB V + 11 MB U in, 179 MB M out
-                'traffic': HOT_KERNEL_TRAFFIC_BYTES if BATCH == 3 else None, 'kernel_ms': k_ms,
-                'flops_per_launch': k_flops,
-                'whole_step_tflops': BATCH * FLOPS_PER_FRAME_ITER * a.steps / dt / 1e12}
+    # dominant kernel: the same steps once more with HIP events around every matrix-core launch
+    psteps = min(a.steps, 20)
+    rows, prof_step_s = profiled_pass(eng, step, psteps)
+    roofline = roofline_from(rows, psteps, mode, lib_version, BATCH, ms_per_step)
+    roofline['profiled_pass_ms_per_step'] = 1e3 * prof_step_s
 
-    extra = {'last_loss': last_loss, 'mfma_probe_tflops': eng.mfma_probe(),
-             'conv_algorithms': 'fp32 throughout; 6 of the 63 convs (decoder 3x3 x2, layer4 conv2 x3: Winograd F(4x4,3x3); '
-                                'ASPP d=6: F(2x2,3x3)) run forward, data and weight gradient in the Winograd domain, the rest '
-                                'as implicit GEMM; whole_step_tflops counts 9-tap-equivalent FLOPs; full-size parity margins '
-                                'in profiles/r01_parity_margins_full_size.txt'}
+    extra = {'last_loss': last_loss, 'matrix_mode': mode, 'lib_version': lib_version,
+             'mfma_probe_fp32_tflops': eng.mfma_probe(),
+             'direct_conv_equivalent_tflops': BATCH * FLOPS_PER_FRAME_ITER / (ms_per_step * 1e-3) / 1e12,
+             'conv_algorithms': 'fp32 arithmetic throughout; contractions on the bf16 matrix cores by exact 3-way operand '
+                                'split + 6 partial products (bf16x6); 6 of the 63 convs (decoder 3x3 x2, layer4 conv2 x3: '
+                                'Winograd F(4x4,3x3); ASPP d=6: F(2x2,3x3)) run all three passes in the Winograd domain; '
+                                'direct_conv_equivalent_tflops counts 9-tap-equivalent FLOPs, roofline.* executed FLOPs'}
+    if not a.no_ab and world == 1:
+        # same engine, same buffers, fp32-MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split kernels
+        engine_mod.set_matrix_mode('f32')
+        for _ in range(3):
+            step()
+        dt32 = timed(step, min(a.steps, 30), barrier, dist, dev)
+        engine_mod.set_matrix_mode(mode)
+        eng.reset()
+        extra['fp32_mfma_mode_ms_per_step'] = 1e3 * dt32 / min(a.steps, 30)
     if not a.no_meta:
         # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4])
         mt = MetaTrainer(eng, dist=dist, meta_batch_size=world)
         mt.load_state(sd, lrs)
-        xm, ym = torch.flip(xg[:1], dims=[3]).contiguous(), torch.flip(yg[:1], dims=[3]).contiguous()
-        mt.meta_iteration([(xg[:1].contiguous(), yg[:1].contiguous(), xm, ym)], inner_steps=5)   # warm-up
-        barrier()
-        t1 = time.perf_counter()
-        n_it = 2
-        for _ in range(n_it):
-            mt.meta_iteration([(xg[:1].contiguous(), yg[:1].contiguous(), xm, ym)], inner_steps=5)
-        barrier()
-        dtm = time.perf_counter() - t1
-        if dist is not None:
-            t = torch.tensor([dtm], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtm = float(t.item())
+        x1, y1 = xg[:1].contiguous(), yg[:1].contiguous()
+        xm, ym = torch.flip(x1, dims=[3]).contiguous(), torch.flip(y1, dims=[3]).contiguous()
+        mstep = lambda: mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
+        mstep()                                                             # warm-up
+        n_it = 5
+        dtm = timed(mstep, n_it, barrier, dist, dev)
         extra['meta_tasks_per_sec'] = world * n_it / dtm
         extra['meta_config'] = f'meta_batch_size={world}, 5 inner steps + 1 meta frame, batch 1, {H}x{W}'
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(sd, lrs, x, y)
+        cpu = cpu_baseline_finetune(sd, lrs, x, y)
     if rank == 0:
         out = {
             'metric': 'finetune_iters_per_sec', 'value': value, 'unit': 'finetune_iters/s', 'n_gpus': world,
-            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'e-OSVOS-50 fine-tune iteration (BASELINE configs[1]): DeepLabV3+-ResNet50, '
                                    f'batch {BATCH}, {H}x{W}, BCE, per-neuron-lr SGD; one (sequence, object) per rank',

@@ -68,6 +68,10 @@ _SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]),
     'eosvos_mfma_probe': (ctypes.c_int, [_E, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_double)]),
+    'eosvos_profile_launches': (ctypes.c_int, [_E, ctypes.c_int]),
+    'eosvos_profile_read': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
+                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_int)]),
     'eosvos_debug_tensor': (ctypes.c_int, [_E, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p),
                                            ctypes.POINTER(ctypes.c_int64)]),
     'eosvos_test_conv': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,

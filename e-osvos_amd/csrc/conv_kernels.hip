@@ -965,7 +965,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
     if (yy * wv1 > rem) --yy; else if ((yy + 1) * wv1 <= rem) ++yy;
     img = b; y = yy; x = rem - yy * wv1;
   };
+  // The rectangle is the whole map and source / destination pixels coincide (1x1 stride-1 convs, the Winograd planes):
+  // contributing pixel q is pixel q of both tensors -- no (image, row, column) bookkeeping (wave-uniform branch)
+  const bool linear = hv == p.Ho && wv == p.Wo && p.stride == 1 && dyk == 0 && dxk == 0 && p.Hi == p.Ho && p.Wi == p.Wo;
+  const unsigned a_lin = (unsigned)(co0 + a_c4 * 4) * 4u, b_lin = (unsigned)(ci0 + b_c4 * 4) * 4u;
+  const unsigned a_pitch = (unsigned)p.ldg * 4u, b_pitch = (unsigned)p.ldx * 4u;
   auto load_tiles = [&](int st) {
+    if (linear) {
+      const int qa = st * BKP + a_kq * ARPT, qb = st * BKP + b_kq * BRPT;
+#pragma unroll
+      for (int i = 0; i < ARPT; ++i)
+        ra[i] = bufld4(rg, (a_cok && qa + i < P) ? (unsigned)(qa + i) * a_pitch + a_lin : OOB);
+#pragma unroll
+      for (int i = 0; i < BRPT; ++i)
+        rb[i] = bufld4(rx, (b_cok && qb + i < P) ? (unsigned)(qb + i) * b_pitch + b_lin : OOB);
+      return;
+    }
     {
       int img, y, x;
       pix(st * BKP + a_kq * ARPT, img, y, x);
@@ -1084,6 +1099,83 @@ int conv_mfma_mode() {
 }
 void conv_set_mfma_mode(int mode) { g_mfma_mode = mode ? 1 : 0; }
 
+
+// ---------------------------------------------------------------------------------------
+// Per-launch timing with HIP events on the stream each kernel is launched on (bench.py's roofline: dominant kernel
+// by time, its algorithmic FLOPs / its measured duration).  Off by default; no effect on results.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int kernel; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+const char* const kProfNames[] = {
+    "conv_x6_kernel<128, false>", "conv_x6_kernel<128, true>", "conv_x6_kernel<64, false>", "conv_x6_kernel<64, true>",
+    "wgrad_x6_kernel<128, 128>", "wgrad_x6_kernel<128, 64>", "wgrad_x6_kernel<64, 128>", "wgrad_x6_kernel<64, 64>",
+    "conv_igemm_kernel<128, false, *>", "conv_igemm_kernel<128, true, *>", "conv_igemm_kernel<64, false, 0>", "conv_igemm_kernel<64, true, 0>",
+    "wgrad_kernel<128, 128>", "wgrad_kernel<128, 64>", "wgrad_kernel<64, 128>", "wgrad_kernel<64, 64>",
+    "conv_fixup_kernel"};
+constexpr int kProfKernels = sizeof(kProfNames) / sizeof(kProfNames[0]);
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(int kernel, double flops, hipStream_t st) : s(st), on(g_prof_on) {
+    if (!on) return;
+    ProfRec r{prof_event(), prof_event(), kernel, flops};
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(g_prof.back().b, s); }
+};
+}  // namespace
+void conv_prof_enable(int on) {
+  g_prof_on = on != 0;
+  if (g_prof_on) {
+    for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+    g_prof.clear();
+  }
+}
+// totals per kernel symbol since conv_prof_enable(1); the caller has synchronised the streams
+int conv_prof_read(int max, const char** names, long* counts, double* ms, double* flops) {
+  double t[kProfKernels] = {0}, f[kProfKernels] = {0};
+  long c[kProfKernels] = {0};
+  for (auto& r : g_prof) {
+    float m = 0.f;
+    if (hipEventElapsedTime(&m, r.a, r.b) != hipSuccess) continue;
+    t[r.kernel] += m; f[r.kernel] += r.flops; ++c[r.kernel];
+  }
+  int n = 0;
+  for (int k = 0; k < kProfKernels && n < max; ++k)
+    if (c[k]) { names[n] = kProfNames[k]; counts[n] = c[k]; ms[n] = t[k]; flops[n] = f[k]; ++n; }
+  return n;
+}
+// share of the nominal multiply-accumulates a launch executes (taps skipped by tap tables / pixel rectangles)
+double conv_exec_frac(const ConvArgs& a) {
+  if (!a.tprefix || a.total_units <= 0) return 1.0;
+  const int bn = (a.N > 64) ? 128 : 64;
+  const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  return (double)a.total_units / (double)(tiles * (long)a.KH * a.KW * ((a.Kc + 31) / 32));
+}
+double wgrad_exec_frac(const WgradArgs& a) {
+  if (a.g_tap_stride) return 1.0;
+  long sum = 0;
+  for (int ky = 0; ky < a.KH; ++ky)
+    for (int kx = 0; kx < a.KW; ++kx) {
+      const int dyk = ky * a.dil - a.pad, dxk = kx * a.dil - a.pad;
+      int hv = 0, wv = 0;
+      for (int oy = 0; oy < a.Ho; ++oy) { const int iy = oy * a.stride + dyk; hv += (iy >= 0 && iy < a.Hi); }
+      for (int ox = 0; ox < a.Wo; ++ox) { const int ix = ox * a.stride + dxk; wv += (ix >= 0 && ix < a.Wi); }
+      sum += (long)hv * wv;
+    }
+  return (double)sum / ((double)a.KH * a.KW * a.Ho * a.Wo);
+}
+
 #define CONV_MAX_WG (256 * EOSVOS_OCC)
 #define CONV_MAX_WG_DEEP (256 * 3)
 int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG_DEEP * 2 * 128 * 128; }
@@ -1145,6 +1237,9 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const int nwg = conv_plan(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   const dim3 grid(nwg), block(256);
+  const int pk = (conv_mfma_mode() == 1 ? 0 : 8) + (bn == 128 ? 0 : 2) + (a.kmajor ? 1 : 0);
+  {
+  ProfScope ps(pk, 2.0 * a.M * a.N * a.KH * a.KW * a.Kc * conv_exec_frac(a), s);
   if (conv_mfma_mode() == 1) {
     if (a.kmajor) {
       if (bn == 128) hipLaunchKernelGGL((conv_x6_kernel<128, true>), grid, block, 0, s, a);
@@ -1166,11 +1261,13 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
     if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, block, 0, s, a);
   }
+  }
   const int T = a.KH * a.KW;
   const int bk = a.deep == 2 ? EOSVOS_BK_DEEP : EOSVOS_BK;
   const long ksteps = (long)T * ((a.Kc + bk - 1) / bk);
   const long sk_tiles = tiles - (long)a.dp_q * nwg;
   if (a.per > 0 && sk_tiles > 0 && (a.per % ksteps != 0 || a.tprefix)) {   // some tile is shared between workgroups
+    ProfScope ps(16, 0.0, s);
     if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);
     else hipLaunchKernelGGL((conv_fixup_kernel<64>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);
   }
@@ -1384,6 +1481,8 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
   const int T = a.KH * a.KW;
   const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * T;
   const dim3 grid(tiles * a.splits), block(256);
+  ProfScope ps((conv_mfma_mode() == 1 ? 4 : 12) + (bm == 128 ? 0 : 2) + (bn == 128 ? 0 : 1),
+               2.0 * a.Cout * a.Cin * T * (double)P * wgrad_exec_frac(a), s);
   if (conv_mfma_mode() == 1) {
     if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_x6_kernel<128, 128>), grid, block, 0, s, a);
     else if (bm == 128) hipLaunchKernelGGL((wgrad_x6_kernel<128, 64>), grid, block, 0, s, a);

@@ -298,27 +298,6 @@ bool trace_on() {
 void trace(const char* kind, int ci, long M, long N, long K, int splits, double frac = 1.0) {
   if (trace_on()) fprintf(stderr, "EOSVOS_TRACE %s conv=%d M=%ld N=%ld K=%ld splits=%d flops=%.0f\n", kind, ci, M, N, K, splits, 2.0 * M * N * K * frac);
 }
-double conv_exec_frac(const ConvArgs& a) {
-  if (!a.tprefix || a.total_units <= 0) return 1.0;
-  const int bn = (a.N > 64) ? 128 : 64;
-  const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
-  return (double)a.total_units / (double)(tiles * (long)a.KH * a.KW * ((a.Kc + 31) / 32));
-}
-// weight gradient: only the output pixels whose tap lands inside the input contribute (wgrad kernels' rectangles)
-double wgrad_exec_frac(const WgradArgs& a) {
-  if (a.g_tap_stride) return 1.0;
-  long sum = 0;
-  for (int ky = 0; ky < a.KH; ++ky)
-    for (int kx = 0; kx < a.KW; ++kx) {
-      const int dyk = ky * a.dil - a.pad, dxk = kx * a.dil - a.pad;
-      int hv = 0, wv = 0;
-      for (int oy = 0; oy < a.Ho; ++oy) { const int iy = oy * a.stride + dyk; hv += (iy >= 0 && iy < a.Hi); }
-      for (int ox = 0; ox < a.Wo; ++ox) { const int ix = ox * a.stride + dxk; wv += (ix >= 0 && ix < a.Wi); }
-      sum += (long)hv * wv;
-    }
-  return (double)sum / ((double)a.KH * a.KW * a.Ho * a.Wo);
-}
-
 // Winograd F(2x2,3x3) path (forward, data gradient, weight gradient) of 3x3 / stride 1 convs: 2.25x fewer MACs,
 // paid for with HBM-bound transform passes.  Always on for the decoder's two convs on the stride-4 map (27 % of a
 // batch-3 iteration's FLOPs); for the dilated / undilated conv2 of layer3 / layer4 only when the launch is large
@@ -1448,6 +1427,30 @@ int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi) 
   if (!e || !param) return fail("null argument");
   launch_clamp(param, n, lo, hi, e->s);
   HIPOK(hipGetLastError());
+  return 0;
+}
+
+int eosvos_profile_launches(eosvos_engine* e, int on) {
+  if (!e) return fail("null engine");
+  HIPOK(hipStreamSynchronize(e->s));
+  if (e->s2) HIPOK(hipStreamSynchronize(e->s2));
+  conv_prof_enable(on);
+  return 0;
+}
+int eosvos_profile_read(eosvos_engine* e, int max_kernels, char* names, int64_t* counts, double* ms, double* flops,
+                        int* n_out) {
+  if (!e || !names || !counts || !ms || !flops || !n_out || max_kernels < 1) return fail("bad argument");
+  HIPOK(hipStreamSynchronize(e->s));
+  if (e->s2) HIPOK(hipStreamSynchronize(e->s2));
+  std::vector<const char*> nm(max_kernels);
+  std::vector<long> c(max_kernels);
+  const int n = conv_prof_read(max_kernels, nm.data(), c.data(), ms, flops);
+  for (int i = 0; i < n; ++i) {
+    strncpy(names + 64 * i, nm[i], 63);
+    names[64 * i + 63] = 0;
+    counts[i] = c[i];
+  }
+  *n_out = n;
   return 0;
 }
 

@@ -77,6 +77,11 @@ inline int conv_par_pixel(int B, int Ho, int Wo, int m) {
 void launch_conv(ConvArgs& a, hipStream_t s);
 int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
 void conv_set_mfma_mode(int mode);
+// per-launch HIP-event timing of the MFMA kernels (conv_kernels.hip)
+void conv_prof_enable(int on);
+int conv_prof_read(int max, const char** names, long* counts, double* ms, double* flops);
+double conv_exec_frac(const struct ConvArgs& a);
+double wgrad_exec_frac(const struct WgradArgs& a);
 int conv_mfma_mode();                // 1: bf16x6 split kernels (default), 0: fp32 MFMA kernels (EOSVOS_MFMA=f32)
 // calibration: back-to-back fp32 MFMAs, returns the FLOPs the launch performs
 double launch_mfma_probe(float* scratch, int iters, hipStream_t s);

@@ -260,6 +260,19 @@ class Engine:
         _ffi.check(self.lib.eosvos_bench_conv(self.h, conv_idx, kind, batch, reps, ctypes.byref(ms), ctypes.byref(fl)))
         return ms.value, fl.value / (ms.value * 1e-3) / 1e12
 
+    def profile_launches(self, on=True):
+        """HIP events around every matrix-core kernel launch (on its own stream) from now on."""
+        _ffi.check(self.lib.eosvos_profile_launches(self.h, int(on)))
+
+    def profile_read(self):
+        """{kernel symbol: (launches, total ms, total executed fp32-equivalent FLOPs)} since profile_launches(True)."""
+        mx = 32
+        names = ctypes.create_string_buffer(64 * mx)
+        counts, ms, fl, n = (ctypes.c_int64 * mx)(), (ctypes.c_double * mx)(), (ctypes.c_double * mx)(), ctypes.c_int()
+        _ffi.check(self.lib.eosvos_profile_read(self.h, mx, names, counts, ms, fl, ctypes.byref(n)))
+        return {names.raw[64 * i:64 * i + 64].split(b'\0')[0].decode(): (int(counts[i]), float(ms[i]), float(fl[i]))
+                for i in range(n.value)}
+
     def mfma_probe(self, iters=20000):
         """Sustained fp32 MFMA TFLOP/s of this device (register-only calibration kernel)."""
         ms, fl = ctypes.c_float(), ctypes.c_double()

@@ -229,6 +229,12 @@ int eosvos_mfma_probe(eosvos_engine* e, int iters, float* ms_host, double* flops
 /* Device pointer + {B,H,W,C} of a named internal NHWC activation / gradient buffer of the
  * last forward/backward ("c1","p1","blk<i>.out","cat","proj","dcat","d1","d2","lowlog",
  * "logits", "g_*" ...), for the per-stage parity tests. */
+/* Measurement aid: HIP events around every launch of the matrix-core kernels, on the stream each one runs on.
+ * profile_read returns, per kernel symbol (names: max_kernels x 64 chars), launches, summed duration (ms) and summed
+ * executed fp32-equivalent FLOPs since profile_launches(e, 1).  bench.py's roofline (dominant kernel by time). */
+int eosvos_profile_launches(eosvos_engine* e, int on);
+int eosvos_profile_read(eosvos_engine* e, int max_kernels, char* names, int64_t* counts, double* ms_host,
+                        double* flops_host, int* n_out_host);
 int eosvos_debug_tensor(eosvos_engine* e, const char* name, float** ptr_out, int64_t* dims4_out);
 /* Low-level op entry used by the kernel parity tests: a single NHWC convolution
  * y = relu?(a*conv(x,w)+b (+res)); w is OIHW; all dense tensors; stride/dil/pad as torch. */

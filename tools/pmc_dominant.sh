@@ -1,0 +1,54 @@
+#!/bin/bash
+# PMC passes on the step's dominant kernel symbol (one counter group per pass; gpurun-safe: --pmc with --kernel-trace only)
+#   tools/pmc_dominant.sh OUTDIR "conv_x6_kernel<128, true>" [batch]
+# writes gpurun_out/OUTDIR/pmc_dominant_kernel.json (copied to profiles/ for bench.py's roofline.traffic) + .txt
+O=$PWD/gpurun_out/$1; K="$2"; B=${3:-3}; mkdir -p $O/pmc
+export TMPDIR=/tmp
+run() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $O/pmc/$1 -- python3 tools/step_profile.py $B > $O/pmc/$1.log 2>&1; }
+run fetch "FETCH_SIZE"
+run write "WRITE_SIZE"
+run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES"
+run sq2 "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA"
+run grbm "GRBM_GUI_ACTIVE"
+python3 - "$O" "$K" "$B" <<'PY'
+import csv, glob, json, sys, collections
+O, K, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
+sys.path.insert(0, '.')
+from eosvos_amd import _ffi
+tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
+dur = []
+for p in ('fetch', 'write', 'sq1', 'sq2', 'grbm'):
+    fs = glob.glob(f'{O}/pmc/{p}/**/*counter_collection.csv', recursive=True)
+    if not fs:
+        print(p, 'no counter csv'); continue
+    for r in csv.DictReader(open(fs[0])):
+        if K in r['Kernel_Name']:
+            tot[r['Counter_Name']] += float(r['Counter_Value']); cnt[r['Counter_Name']] += 1
+    if p == 'grbm':
+        for r in csv.DictReader(open(glob.glob(f'{O}/pmc/{p}/**/*kernel_trace.csv', recursive=True)[0])):
+            if K in r['Kernel_Name']:
+                dur.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+avg = {k: tot[k] / cnt[k] for k in tot}
+n = cnt.get('FETCH_SIZE', 0)
+# FETCH_SIZE / WRITE_SIZE are reported in KB; gfx950 tallies wide coalesced reads at half their bytes (MI355X_MICROARCH.md, HBM)
+traffic = (2 * avg.get('FETCH_SIZE', 0) + avg.get('WRITE_SIZE', 0)) * 1024
+out = {'kernel': K, 'batch': B, 'lib_version': _ffi.load().eosvos_version().decode(), 'launches_profiled': n,
+       'fetch_kb_per_launch': avg.get('FETCH_SIZE'), 'write_kb_per_launch': avg.get('WRITE_SIZE'),
+       'traffic_bytes_per_launch': traffic,
+       'note': 'average over every launch of this kernel symbol in tools/step_profile.py (6 steps): 2 x FETCH_SIZE (gfx950 '
+               'half-count correction) + WRITE_SIZE, separate rocprofv3 --pmc passes',
+       'counters_avg_per_launch': avg,
+       'avg_launch_us_under_pmc': (sum(dur) / len(dur) / 1e3) if dur else None}
+json.dump(out, open(f'{O}/pmc_dominant_kernel.json', 'w'), indent=1)
+with open(f'{O}/pmc_dominant_kernel.txt', 'w') as f:
+    f.write(f'PMC, kernel symbol {K!r}, batch {B}, {n} launches ({out["lib_version"]})\n')
+    for k, v in sorted(avg.items()):
+        f.write(f'  {k:28s} {v:16.1f}  (avg per launch)\n')
+    f.write(f'  corrected HBM-side traffic per launch = 2*FETCH_SIZE + WRITE_SIZE = {traffic / 1e6:.1f} MB\n')
+    if 'SQ_INSTS_MFMA' in avg and 'GRBM_GUI_ACTIVE' in avg and dur:
+        cyc = avg['GRBM_GUI_ACTIVE'] / 8
+        f.write(f'  MFMA-busy: {avg["SQ_INSTS_MFMA"] * 32 / 1024 / cyc * 100:.1f} % of {cyc:.0f} cycles per launch '
+                f'(effective clock {cyc / (sum(dur) / len(dur)) :.2f} GHz)\n')
+print(open(f'{O}/pmc_dominant_kernel.txt').read())
+PY
+rm -rf $O/pmc
