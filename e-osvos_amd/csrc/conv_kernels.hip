@@ -529,9 +529,10 @@ long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vect
 // ---------------------------------------------------------------------------------------
 // fp32 contraction on the bf16 matrix cores ("bf16x6").
 //
-// The fp32 MFMA runs at 1/16 of the bf16 MFMA rate on CDNA4, so every operand is split exactly into three bf16
-// pieces, a = hi + mid + lo (8 + 8 + 8 significand bits, each piece = the truncated top 16 bits of the running
-// remainder: the split of a 24-bit significand is exact), and a*b is accumulated from the six partial products
+// The fp32 MFMA runs at 1/16 of the bf16 MFMA rate on CDNA4, so every operand is split into three bf16 pieces,
+// a = hi + mid + lo (each piece = the top 16 bits of the running remainder: 3 x 8 significand bits cover the 24-bit
+// significand, so the split is exact; the remainders are exact fp32 subtractions), and a*b is accumulated from the
+// six partial products
 //   hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi      (v_mfma_f32_32x32x16_bf16, fp32 accumulate);
 // the dropped mid*lo, lo*mid, lo*lo terms are <= 2^-24 relative, i.e. below one fp32 rounding of the product.
 // bf16 x bf16 products are exact in fp32.  Measured against fp64 (tools/probes/bf16x6_probe.cpp): error relative to
@@ -550,24 +551,34 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define X6_ROWB 80
 
-__device__ __forceinline__ unsigned x6_pack(float e0, float e1) {      // (top 16 bits of e1) << 16 | top 16 bits of e0
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// Two fp32 values -> bf16 pieces, packed (e1 << 16 | e0).  Default: the truncated top 16 bits (one v_perm_b32; the
+// 3-way split of a 24-bit significand is then exact).  -DEOSVOS_X6_RNE rounds to nearest even instead
+// (v_cvt_pk_bf16_f32): same parity margins (profiles/r02_parity_margins.txt), 4 % slower step on the same box.
+__device__ __forceinline__ unsigned x6_pack(float e0, float e1) {
+#ifdef EOSVOS_X6_RNE
+  bf16x2 v = {(__bf16)e0, (__bf16)e1};
+  return *reinterpret_cast<unsigned*>(&v);
+#else
   return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+#endif
 }
-__device__ __forceinline__ float x6_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+__device__ __forceinline__ float x6_lo(unsigned pk) { return __uint_as_float(pk << 16); }          // piece of e0 as fp32
+__device__ __forceinline__ float x6_hi(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }  // piece of e1 as fp32
 // four consecutive-k values -> the three pieces, 4 bf16 (8 bytes) each
 __device__ __forceinline__ void x6_split4(float a, float b, float c, float d, uint2 out[3]) {
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
     out[p].x = x6_pack(a, b);
     out[p].y = x6_pack(c, d);
-    if (p < 2) { a -= x6_trunc(a); b -= x6_trunc(b); c -= x6_trunc(c); d -= x6_trunc(d); }
+    if (p < 2) { a -= x6_lo(out[p].x); b -= x6_hi(out[p].x); c -= x6_lo(out[p].y); d -= x6_hi(out[p].y); }
   }
 }
 __device__ __forceinline__ void x6_split2(float a, float b, unsigned out[3]) {
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
     out[p] = x6_pack(a, b);
-    if (p < 2) { a -= x6_trunc(a); b -= x6_trunc(b); }
+    if (p < 2) { a -= x6_lo(out[p]); b -= x6_hi(out[p]); }
   }
 }
 __device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }

@@ -122,6 +122,20 @@ class DAVIS:
         return frames.to(device), [g.to(device) for g in gts]
 
 
+    def frame_names(self, seq_name):
+        """File stems of the frames of `seq_name` (prediction PNG names, `evaluate.py:333-340`)."""
+        return [os.path.splitext(os.path.basename(p))[0] for p in self.seqs[seq_name]['imgs']]
+
+    def label_maps(self, seq_name):
+        """(N,H,W) integer ground-truth label maps of a sequence (object ids as annotated; binary in single-object
+        mode) for the J measure."""
+        out = []
+        for p in self.seqs[seq_name]['labels']:
+            lab = np.atleast_3d(Image.open(p))[..., 0]
+            out.append(lab if self.multi_object else (lab != 0).astype(np.uint8))
+        return np.stack(out)
+
+
 def jaccard(pred, gt):
     """Region similarity J of two binary masks (the `davis` package's db_eval_iou): |A & B| / |A | B|, 1 if both empty."""
     pred, gt = np.asarray(pred).astype(bool), np.asarray(gt).astype(bool)

@@ -14,6 +14,10 @@ Data loading is the caller's business; the first-frame augmentation of round 0
 (`custom_transforms.FirstFrameAugmenter`) when `data_cfg.random_train_transform` is set, or through a
 caller-supplied `augment(frame, gt, batch, seed)`; benchmarks use synthetic frames.
 """
+import os
+import time
+
+import numpy as np
 import torch
 
 from .helper_func import compute_loss, early_stopping, set_random_seeds
@@ -57,12 +61,10 @@ def _repeat_batch(frame, gt, batch, seed):
     return frame.expand(batch, -1, -1, -1).contiguous(), gt.expand(batch, -1, -1, -1).contiguous()
 
 
-def evaluate_sequence(model, meta_optim, meta_optim_state_dict, frames, object_gts, cfg, augment=None,
-                      train_frame_id=0):
-    """frames (N,3,H,W) on the GPU, object_gts: list of (1,H,W) binary masks of the train frame.
-    cfg keys (names of cfgs/meta.yaml): num_epochs.eval, eval_online_adapt.{step,reset_model_mode,
-    num_epochs,min_prop}, data_cfg.batch_sizes.train, seed, loss_func, train_early_stopping_cfg.
-    Returns (labels (N,H,W) uint8, per-object probs list, train loss history per object)."""
+def finetune_object(model, meta_optim, meta_optim_state_dict, frames, gt, cfg, augment=None, train_frame_id=0):
+    """One (sequence, object) work item of `evaluate.py:132-317`: fine-tune on the train frame, predict the following
+    frames, with online adaptation re-fine-tune every `step` frames.  Returns (probs (N,H,W) with the train frame seeded
+    as 2*GT (`:167-168`), train-loss history per round)."""
     if augment is None and cfg['data_cfg'].get('random_train_transform'):
         augment = device_augment(model)
     augment = augment or _repeat_batch
@@ -72,56 +74,148 @@ def evaluate_sequence(model, meta_optim, meta_optim_state_dict, frames, object_g
     bsz = cfg['data_cfg']['batch_sizes']['train']
     es = cfg.get('train_early_stopping_cfg', {'patience': None, 'min_loss_improv': 0.001})
     loss_func = cfg.get('loss_func', 'cross_entropy')
+    gt = gt.to(frames.device).float().view(1, 1, *gt.shape[-2:])
+    masks = torch.zeros(n, 1, *frames.shape[-2:], device=frames.device)
+    masks[train_frame_id] = 2 * gt[0]                               # evaluate.py:167-168
+    hist = []
+    for r, rd in enumerate(online_adapt_schedule(n, train_frame_id, step, bsz)):
+        if r == 0 or ona['reset_model_mode'] == 'FULL':
+            meta_optim.load_state_dict(meta_optim_state_dict)
+            meta_optim.reset()
+            meta_optim.eval()
+        elif ona['reset_model_mode'] == 'FIRST_STEP':
+            meta_optim.load_state_dict(meta_optim_state_dict)
+            if model._dirty:                    # new lrs: push them without touching theta twice
+                model.push_state()
+            model.engine.restore()              # model.load_state_dict(model_state_dict_first_step)
+            meta_optim.eval()
+        num_epochs = cfg['num_epochs']['eval'] if r == 0 else ona['num_epochs']
+        model.train_without_dropout()
+        round_hist = []
+        for epoch in range(1, num_epochs + 1):
+            set_random_seeds(cfg.get('seed', 1) + epoch + r)
+            if r == 0:
+                inputs, gts = augment(frames[train_frame_id:train_frame_id + 1], gt, bsz, cfg.get('seed', 1) + epoch)
+            else:
+                inputs, gts = frames[train_frame_id:train_frame_id + 1], gt
+                for f in rd['propagate_frames']:
+                    pg = masks[f:f + 1].ge(ona['min_prop']).float()
+                    if pg.sum().item() != 0:                        # evaluate.py:239
+                        inputs = torch.cat([inputs, frames[f:f + 1]])
+                        gts = torch.cat([gts, pg])
+                inputs, gts = inputs.contiguous(), gts.contiguous()
+            outputs = model(inputs)
+            train_loss = compute_loss(loss_func, outputs[-1], gts)
+            round_hist.append(train_loss.item())
+            model.zero_grad()
+            meta_optim.set_train_loss(train_loss)
+            meta_optim.step(train_loss)
+            meta_optim.meta_model.detach_param_groups()
+            if early_stopping(round_hist, **es):
+                break
+        hist.append(round_hist)
+        if r == 0:
+            model.engine.snapshot()             # model_state_dict_first_step (evaluate.py:283-287)
+        model.eval()
+        for f in range(rd['eval_min'], rd['eval_max']):
+            masks[f] = model.engine.infer(frames[f:f + 1].contiguous())[0]
+    return masks[:, 0], hist
+
+
+def merge_objects(engine, probs_all):
+    """Per-object probabilities [(N,H,W)] -> label maps (N,H,W) uint8 (`evaluate.py:322-326`)."""
+    stack = torch.stack(list(probs_all), dim=1)                       # (N, n_obj, H, W)
+    return torch.stack([engine.merge_labels(stack[f].contiguous()) for f in range(stack.shape[0])])
+
+
+def evaluate_sequence(model, meta_optim, meta_optim_state_dict, frames, object_gts, cfg, augment=None,
+                      train_frame_id=0):
+    """frames (N,3,H,W) on the GPU, object_gts: list of (1,H,W) binary masks of the train frame.
+    cfg keys (names of cfgs/meta.yaml): num_epochs.eval, eval_online_adapt.{step,reset_model_mode,
+    num_epochs,min_prop}, data_cfg.batch_sizes.train, seed, loss_func, train_early_stopping_cfg.
+    Returns (labels (N,H,W) uint8, per-object probs list, train loss history per object)."""
     probs_all, hist_all = [], []
     for gt in object_gts:
-        gt = gt.to(frames.device).float().view(1, 1, *gt.shape[-2:])
-        masks = torch.zeros(n, 1, *frames.shape[-2:], device=frames.device)
-        masks[train_frame_id] = 2 * gt[0]                               # evaluate.py:167-168
-        hist = []
-        for r, rd in enumerate(online_adapt_schedule(n, train_frame_id, step, bsz)):
-            if r == 0 or ona['reset_model_mode'] == 'FULL':
-                meta_optim.load_state_dict(meta_optim_state_dict)
-                meta_optim.reset()
-                meta_optim.eval()
-            elif ona['reset_model_mode'] == 'FIRST_STEP':
-                meta_optim.load_state_dict(meta_optim_state_dict)
-                if model._dirty:                    # new lrs: push them without touching theta twice
-                    model.push_state()
-                model.engine.restore()              # model.load_state_dict(model_state_dict_first_step)
-                meta_optim.eval()
-            num_epochs = cfg['num_epochs']['eval'] if r == 0 else ona['num_epochs']
-            model.train_without_dropout()
-            round_hist = []
-            for epoch in range(1, num_epochs + 1):
-                set_random_seeds(cfg.get('seed', 1) + epoch + r)
-                if r == 0:
-                    inputs, gts = augment(frames[train_frame_id:train_frame_id + 1], gt, bsz, cfg.get('seed', 1) + epoch)
-                else:
-                    inputs, gts = frames[train_frame_id:train_frame_id + 1], gt
-                    for f in rd['propagate_frames']:
-                        pg = masks[f:f + 1].ge(ona['min_prop']).float()
-                        if pg.sum().item() != 0:                        # evaluate.py:239
-                            inputs = torch.cat([inputs, frames[f:f + 1]])
-                            gts = torch.cat([gts, pg])
-                    inputs, gts = inputs.contiguous(), gts.contiguous()
-                outputs = model(inputs)
-                train_loss = compute_loss(loss_func, outputs[-1], gts)
-                round_hist.append(train_loss.item())
-                model.zero_grad()
-                meta_optim.set_train_loss(train_loss)
-                meta_optim.step(train_loss)
-                meta_optim.meta_model.detach_param_groups()
-                if early_stopping(round_hist, **es):
-                    break
-            hist.append(round_hist)
-            if r == 0:
-                model.engine.snapshot()             # model_state_dict_first_step (evaluate.py:283-287)
-            model.eval()
-            for f in range(rd['eval_min'], rd['eval_max']):
-                masks[f] = model.engine.infer(frames[f:f + 1].contiguous())[0]
-        probs_all.append(masks[:, 0])
+        probs, hist = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gt, cfg, augment, train_frame_id)
+        probs_all.append(probs)
         hist_all.append(hist)
-    stack = torch.stack(probs_all, dim=1)                               # (N, n_obj, H, W)
-    eng = model.engine
-    labels = torch.stack([eng.merge_labels(stack[f].contiguous()) for f in range(n)])
-    return labels, probs_all, hist_all
+    return merge_objects(model.engine, probs_all), probs_all, hist_all
+
+
+def prediction_paths(save_dir, dataset_name, split):
+    """`{save_dir}/best_eval_preds/{name}/{split}` and the `_debug` sibling (`evaluate.py:68-90`)."""
+    return (os.path.join(save_dir, 'best_eval_preds', f'{dataset_name}', f'{split}'),
+            os.path.join(save_dir, 'best_eval_preds_debug', f'{dataset_name}', f'{split}'))
+
+
+def save_label_png(path, labels_hw):
+    """One uint8 label map per frame (`imageio.imsave(pred_path, mask_frame)`, `evaluate.py:338-342`)."""
+    from PIL import Image
+    Image.fromarray(np.asarray(labels_hw, dtype=np.uint8), mode='L').save(path)
+
+
+def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dataset_key, save_dir=None,
+                     meta_iter=None, meta_epoch=None, best_mean_J=0.0, dist=None, device=None, vis_win_names=None,
+                     log=None):
+    """The evaluation worker of `src/util/evaluate.py:111-382` for the DeepLab path: every sequence of `dataset`
+    (an `eosvos_amd.data` reader), every object, fine-tune / online adaptation / inference / merge; prediction PNGs
+    under `{save_dir}/best_eval_preds/{name}/{split}/{seq}/{frame}.png`, J per sequence, and the
+    `last_{key}_meta_iter.model` / `best_{key}_meta_iter.model` checkpoints (`:361-382`).
+
+    With `dist` (torch.distributed, world > 1) the (sequence, object) work items are dealt round-robin over the
+    ranks (they are independent fine-tunes); the only exchange is one all-reduce(sum) per sequence of the
+    zero-initialised per-object probability stack (every slot is written by exactly one rank, so the sum is exact),
+    after which every rank merges the same label maps and rank 0 writes files.
+    Returns dict(J_seq, mean_J, best_mean_J, time_per_frame, labels={seq: (N,H,W) uint8})."""
+    from .checkpoint import save_meta_checkpoint
+    from .data import sequence_J
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    ds_cfg = cfg['datasets'][dataset_key]
+    preds_dir = None
+    if save_dir is not None:
+        preds_dir, _ = prediction_paths(save_dir, ds_cfg['name'], ds_cfg['split'])
+        if rank == 0:
+            for seq in dataset.seqs_names:
+                os.makedirs(os.path.join(preds_dir, seq), exist_ok=True)
+    set_random_seeds(cfg.get('seed', 1))                                        # evaluate.py:42
+    J_seq, labels_out, item, eval_time, num_frames = [], {}, 0, 0.0, 0
+    for seq in dataset.seqs_names:
+        frames, gts = dataset.sequence_tensors(seq, device or model.device)
+        n = frames.shape[0]
+        probs = torch.zeros(len(gts), n, *frames.shape[-2:], device=frames.device)
+        t0 = time.perf_counter()
+        for obj_id, gt in enumerate(gts):
+            if item % world == rank:
+                probs[obj_id], _ = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gt, cfg)
+            item += 1
+        if world > 1:
+            dist.all_reduce(probs)
+        eval_time += time.perf_counter() - t0
+        num_frames += n * len(gts)                                              # per (object, frame), evaluate.py:320
+        if model.engine is None:                                                # this rank had no item yet
+            model._ensure_engine(frames.shape[2], frames.shape[3], 1)
+        labels = merge_objects(model.engine, [probs[o] for o in range(len(gts))]).cpu()
+        labels_out[seq] = labels
+        if rank == 0 and preds_dir is not None:
+            names = dataset.frame_names(seq)
+            for f in range(n):
+                save_label_png(os.path.join(preds_dir, seq, names[f] + '.png'), labels[f].numpy())
+        if dataset.test_mode:
+            J_seq.append(0.0)                                                   # evaluate.py:344-346
+        else:
+            J_seq.append(sequence_J(labels.numpy(), dataset.label_maps(seq), len(gts)))
+        if log is not None and rank == 0:
+            log(f"{dataset_key}: {seq} [{J_seq[-1]}]")
+    mean_J = float(np.mean(J_seq)) if J_seq else 0.0
+    out_best = best_mean_J
+    if rank == 0 and save_dir is not None and not dataset.test_mode:
+        save_meta_checkpoint(os.path.join(save_dir, f'last_{dataset_key}_meta_iter.model'), meta_optim_state_dict,
+                             meta_iter, meta_epoch, vis_win_names)
+    if dataset.test_mode or mean_J > best_mean_J:                               # evaluate.py:368-382
+        out_best = mean_J
+        if rank == 0 and save_dir is not None and not dataset.test_mode:
+            save_meta_checkpoint(os.path.join(save_dir, f'best_{dataset_key}_meta_iter.model'), meta_optim_state_dict,
+                                 meta_iter, meta_epoch, vis_win_names)
+    return {'J_seq': J_seq, 'mean_J': mean_J, 'best_mean_J': out_best, 'labels': labels_out,
+            'time_per_frame': eval_time / max(num_frames, 1), 'meta_iter': meta_iter}

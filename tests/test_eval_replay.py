@@ -1,0 +1,218 @@
+"""A8 / G12: the product's evaluation worker replayed against the event log of the reference's own `evaluate()`
+(`tests/golden/g12_online_adapt.json`, produced by `tests/golden/make_g12.py` running `src/util/evaluate.py`
+UNMODIFIED on stand-in loaders): which frames and pseudo-labels enter every online-adaptation batch, the seeds,
+the inference ranges, when the first-step weights are restored, the merged label maps, the prediction PNG paths and
+the last/best checkpoint files.  CPU only: the engine is the test stand-in of tests/fake_engine.py.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+sys.path.insert(0, HERE)
+
+from g12_scenarios import SCENARIOS, frame_image, object_gt, prob_map  # noqa: E402
+from fake_engine import FakeDeepLab, FakeEngine  # noqa: E402
+
+from eosvos_amd import config as config_mod  # noqa: E402
+from eosvos_amd import evaluate as product_eval  # noqa: E402
+from eosvos_amd.evaluate import online_adapt_schedule  # noqa: E402
+from eosvos_amd.meta_optim import MetaOptimizer  # noqa: E402
+
+HW = (8, 12)
+G12 = json.load(open(os.path.join(HERE, 'golden', 'g12_online_adapt.json')))
+
+
+def parse_reference(events, sc):
+    """Reference event log -> {seq: {'objects': [[round, ...], ...], 'png': [(relpath, labels)]}}, 'saves'."""
+    out, saves = {}, []
+    rounds, cur, seed = [], {'theta': None, 'epochs': []}, None
+    png = []
+    for e in events:
+        k = e[0]
+        if k == 'mo.reset':
+            cur['theta'] = 'init'                 # theta <- learned init
+        elif k == 'model.load_state_dict':
+            cur['theta'] = 'first_step'           # theta <- weights saved after round 0 (FIRST_STEP)
+        elif k == 'seed':
+            seed = e[1]
+        elif k == 'forward':
+            cur['epochs'].append([seed, e[1]])
+        elif k == 'loss':
+            cur['epochs'][-1].append([round(v, 3) for v in e[2]])
+        elif k == 'run_loader':
+            cur['infer'] = e[1]
+            rounds.append(cur)
+            cur = {'theta': None, 'epochs': []}
+        elif k == 'imsave':
+            png.append((e[1], e[2]))
+        elif k == 'torch.save':
+            saves.append((e[1], e[2], e[3]))
+    # rounds -> sequences / objects by the frame counts of the scenario
+    it = iter(rounds)
+    pi = 0
+    for seq, info in sc['seqs'].items():
+        objs = []
+        for _ in range(info['objects']):
+            rs = []
+            while True:
+                r = next(it)
+                rs.append(r)
+                if not r['infer'] or r['infer'][-1] == info['frames'] - 1:
+                    break
+            objs.append(rs)
+        out[seq] = {'objects': objs, 'png': png[pi:pi + info['frames']]}
+        pi += info['frames']
+    return out, saves
+
+
+class ScenarioDataset:
+    """The `eosvos_amd.data` reader interface `evaluate_dataset` uses, on the in-memory scenario."""
+    test_mode = False
+
+    def __init__(self, sc):
+        self.sc = sc
+        self.seqs_names = list(sc['seqs'])
+
+    def sequence_tensors(self, seq, device='cpu'):
+        info = self.sc['seqs'][seq]
+        self.current = seq
+        frames = torch.stack([frame_image(i, HW) for i in range(info['frames'])])
+        return frames, [object_gt(seq, o, HW) for o in range(info['objects'])]
+
+    def frame_names(self, seq):
+        return [f'{i:05d}' for i in range(self.sc['seqs'][seq]['frames'])]
+
+    def label_maps(self, seq):
+        info = self.sc['seqs'][seq]
+        lab = np.zeros((info['frames'],) + HW, np.uint8)
+        for o in range(info['objects']):
+            lab[:, object_gt(seq, o, HW)[0].numpy() > 0] = o + 1
+        return lab
+
+
+def run_product(sc, tmp_path, monkeypatch):
+    cfg = config_mod.parse_cli([])
+    cfg['seed'] = sc['seed']
+    cfg['num_epochs']['eval'] = sc['eval_epochs']
+    cfg['eval_online_adapt'].update(step=sc['step'] or 0, reset_model_mode=sc['reset_model_mode'],
+                                    num_epochs=sc['ona_epochs'], min_prop=0.5)
+    cfg['data_cfg']['batch_sizes']['train'] = sc['batch']
+    cfg['datasets']['val'] = {'name': 'DAVIS-2017', 'split': 'val_seqs', 'eval': True}
+    events = []
+    model = FakeDeepLab('resnet50', num_classes=1, batch_norm=cfg['parent_model']['batch_norm'], max_batch=sc['batch'])
+    model._views['backbone.conv1.weight'].view(-1)[0] = 0.3          # the stand-in network's two parameters
+    meta_optim = MetaOptimizer(model, **cfg['meta_optim_cfg'])
+    msd = meta_optim.state_dict()
+    ds = ScenarioDataset(sc)
+
+    real_loss, real_seed = product_eval.compute_loss, product_eval.set_random_seeds
+
+    def compute_loss(name, out, gts, *a, **k):
+        events.append(['loss', name, [round(float(g.sum()), 3) for g in gts]])
+        return real_loss(name, out, gts, *a, **k)
+    monkeypatch.setattr(product_eval, 'compute_loss', compute_loss)
+    monkeypatch.setattr(product_eval, 'set_random_seeds', lambda s: (events.append(['seed', s]), real_seed(s))[1])
+
+    real_call = FakeDeepLab.__call__
+
+    def logged_call(self, inputs):
+        out = real_call(self, inputs)           # may create the engine and push the state first (theta <- init)
+        events.append(['forward', [round(float(v) * 100) for v in inputs[:, 0, 0, 0]]])
+        self.engine.infer_fn = infer_fn
+        return out
+    monkeypatch.setattr(FakeDeepLab, '__call__', logged_call)
+    for name, tag in (('reset', 'reset'), ('meta_task_begin', 'reset'), ('restore', 'restore'), ('set_init', 'reset')):
+        real = getattr(FakeEngine, name)
+        monkeypatch.setattr(FakeEngine, name, (lambda f, t: (lambda self, *a, **k: (events.append([t]), f(self, *a, **k))[1]))(real, tag))
+
+    def infer_fn(eng, images):
+        f = round(float(images[0, 0, 0, 0]) * 100)
+        gt0 = eng.last_masks[0]
+        obj = 0 if torch.equal(gt0, object_gt(ds.current, 0, HW)) else 1
+        events.append(['infer', f])
+        return prob_map(ds.current, obj, f, HW).view(1, 1, *HW)
+
+    res = product_eval.evaluate_dataset(model, meta_optim, msd, ds, cfg, 'val', save_dir=str(tmp_path), meta_iter=3,
+                                        meta_epoch=1, best_mean_J=0.0)
+    # events -> the same structure as parse_reference
+    out = {}
+    it = iter(events)
+    evs = list(events)
+    pos = 0
+    for seq, info in sc['seqs'].items():
+        n_rounds = len(online_adapt_schedule(info['frames'], sc['train_frame'], sc['step'] or 0, sc['batch']))
+        objs = []
+        for _ in range(info['objects']):
+            rs = []
+            for _r in range(n_rounds):
+                cur = {'theta': None, 'epochs': [], 'infer': []}
+                seed = None
+                while pos < len(evs):
+                    e = evs[pos]
+                    if e[0] == 'infer':
+                        cur['infer'].append(e[1])
+                        pos += 1
+                        if pos >= len(evs) or evs[pos][0] != 'infer':
+                            break
+                        continue
+                    if e[0] == 'reset' and not cur['epochs']:
+                        cur['theta'] = 'init'
+                    elif e[0] == 'restore' and not cur['epochs']:
+                        cur['theta'] = 'first_step'
+                    elif e[0] == 'seed':
+                        seed = e[1]
+                    elif e[0] == 'forward':
+                        cur['epochs'].append([seed, e[1]])
+                    elif e[0] == 'loss':
+                        cur['epochs'][-1].append(e[2])
+                    pos += 1
+                rs.append(cur)
+            objs.append(rs)
+        out[seq] = {'objects': objs}
+    return out, res
+
+
+@pytest.mark.parametrize('sc', SCENARIOS, ids=[s['name'] for s in SCENARIOS])
+def test_evaluation_worker_replays_reference_event_log(sc, tmp_path, monkeypatch):
+    ref, saves = parse_reference(G12[sc['name']]['events'], sc)
+    got, res = run_product(sc, tmp_path, monkeypatch)
+    for seq in sc['seqs']:
+        for o, (r_obj, g_obj) in enumerate(zip(ref[seq]['objects'], got[seq]['objects'])):
+            assert len(r_obj) == len(g_obj), (seq, o)
+            for ri, (r, g) in enumerate(zip(r_obj, g_obj)):
+                where = (sc['name'], seq, o, ri)
+                assert g['infer'] == r['infer'], where                       # inference frame range of the round
+                assert g['epochs'] == r['epochs'], where                     # seeds, batch frames, (pseudo) label sums
+                # the weights every round starts from: the learned init, or (FIRST_STEP) those saved after round 0
+                assert g['theta'] == r['theta'] == ('init' if ri == 0 or sc['reset_model_mode'] == 'FULL' else 'first_step'), where
+        # merged label maps and prediction PNGs
+        for f, (rel, lab) in enumerate(ref[seq]['png']):
+            assert np.array_equal(res['labels'][seq][f].numpy(), np.array(lab, np.uint8)), (seq, f)
+            path = os.path.join(str(tmp_path), rel)
+            assert os.path.exists(path), rel
+            assert np.array_equal(np.array(Image.open(path)), np.array(lab, np.uint8))
+    # last / best checkpoints of the eval worker (evaluate.py:361-382)
+    for rel, keys, meta_iter in saves:
+        ck = torch.load(os.path.join(str(tmp_path), rel), map_location='cpu', weights_only=False)
+        assert sorted(ck.keys()) == keys and ck['meta_iter'] == meta_iter
+    assert {s[0] for s in saves} == {'last_val_meta_iter.model', 'best_val_meta_iter.model'}
+
+
+def test_schedule_function_matches_reference_rounds():
+    """`online_adapt_schedule` alone against the inference ranges / propagated frames of the reference run."""
+    for sc in SCENARIOS:
+        ref, _ = parse_reference(G12[sc['name']]['events'], sc)
+        for seq, info in sc['seqs'].items():
+            sched = online_adapt_schedule(info['frames'], sc['train_frame'], sc['step'] or 0, sc['batch'])
+            rounds = ref[seq]['objects'][0]
+            assert [list(range(r['eval_min'], r['eval_max'])) for r in sched] == [r['infer'] for r in rounds]
+            for r, rr in zip(sched[1:], rounds[1:]):
+                # frames offered for propagation: the reference batch holds the train frame + the non-empty ones
+                assert set(rr['epochs'][0][1][1:]) <= set(r['propagate_frames'])
