@@ -18,7 +18,11 @@ pytestmark = pytest.mark.gpu
 SMALL = (96, 160)
 FULL = (480, 854)
 DEV = 'cuda:0'
-LOGIT_TOL = 1e-3
+LOGIT_TOL = 1e-3               # north_star bound; the tests below use ~10x the measured margins of
+                               # profiles/r02_parity_margins.txt (tools/parity_margins.py)
+LOSS_RTOL, LRGRAD_TOL, INITGRAD_L2_TOL, INITGRAD_EL_TOL = 1e-5, 2.5e-3, 4e-4, 6e-4   # see test_meta_task_vs_golden
+HIER_L2_TOL = 3e-3             # lr-hierarchy fixtures (seed 1302): measured 9.6e-4 on one layer1 tensor (ReLU-gate flips at 96x160)
+FWD_TOL = 1e-4                 # single forward pass: measured 8e-6 (480x854), 5e-6 (96x160)
 
 
 def fp(t):
@@ -100,7 +104,7 @@ def test_forward_small_vs_golden(small_engine, golden_dir):
     small_engine.reset()
     out = small_engine.forward(x.to(DEV)).cpu().numpy()
     ref = g['small_bn_logits']
-    assert np.abs(out - ref).max() < LOGIT_TOL
+    assert np.abs(out - ref).max() < FWD_TOL
     flips = ((out >= 0) != (ref >= 0)).sum()
     assert flips <= (np.abs(ref) < 1e-4).sum()
     for name, key in (('p1', 'stem'), ('blk2.out', 'layer1'), ('blk6.out', 'layer2'), ('blk12.out', 'layer3'),
@@ -115,7 +119,7 @@ def test_forward_full_vs_golden(full_engine, golden_dir):
     x, _ = synthetic.synthetic_frames(1, *FULL, seed=7)
     full_engine.reset()
     out = full_engine.forward(x.to(DEV)).cpu()
-    assert np.abs(out[0, 0, ::8, ::7].numpy() - g['full_bn_logits_sub']).max() < LOGIT_TOL
+    assert np.abs(out[0, 0, ::8, ::7].numpy() - g['full_bn_logits_sub']).max() < FWD_TOL
     mask = np.packbits((out >= 0).numpy().astype(np.uint8))
     diff = int(np.unpackbits(mask ^ g['full_bn_mask']).sum())
     assert diff <= int(g['full_bn_near_zero'][0]), diff
@@ -150,23 +154,23 @@ def test_gradients_and_finetune_small_vs_golden(small_engine, weights, golden_di
         if it == 0:
             grads = eng.get_grads().cpu()
     eng.keep_grads(False)
-    np.testing.assert_allclose(losses, g['small_losses'], rtol=5e-4, atol=1e-5)
+    np.testing.assert_allclose(losses, g['small_losses'], rtol=1e-5)             # measured 5e-7
     offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr])
     for i in g['small_ids']:
         ref = g[f'small_grad_{i}']
         got = grads[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
-        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, tr[i][0]
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, tr[i][0]      # measured 1.6e-4 (ReLU-gate flips)
     ref_fp = g['small_grad_fp']
     for i, (n, s) in enumerate(tr):
         l2 = float(grads[offs[i]:offs[i + 1]].double().norm())
-        assert abs(l2 - ref_fp[i][1]) <= 1e-2 * ref_fp[i][1] + 1e-9, (n, l2, ref_fp[i][1])
+        assert abs(l2 - ref_fp[i][1]) <= 6e-4 * ref_fp[i][1] + 1e-9, (n, l2, ref_fp[i][1])      # measured 6e-5
     params = eng.get_params().cpu()
     for i in g['small_ids']:
         ref = g[f'small_param_{i}']
         got = params[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
-        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), tr[i][0]
+        assert np.abs(got - ref).max() <= 3e-6 * np.abs(ref).max(), tr[i][0]                     # measured 2.5e-7
     out = eng.forward(batches[0][0].to(DEV)).cpu().numpy()
-    assert np.abs(out - g['small_final_logits']).max() < 5e-3
+    assert np.abs(out - g['small_final_logits']).max() < 1e-4                                    # measured 8.6e-6
 
 
 def test_c1_finetune_full_vs_golden(full_engine, golden_dir):
@@ -177,20 +181,56 @@ def test_c1_finetune_full_vs_golden(full_engine, golden_dir):
     xg, yg = x.to(DEV), y.to(DEV)
     eng.reset()
     losses = [eng.finetune_step(xg, yg) for _ in range(10)]
-    np.testing.assert_allclose(losses, g['c1_losses'], rtol=1e-3)
+    np.testing.assert_allclose(losses, g['c1_losses'], rtol=5e-5)                 # measured 4.9e-6
     out = eng.forward(xg).cpu()
     sub = out[0, 0, ::8, ::7].numpy()
-    assert np.abs(sub - g['c1_final_logits_sub']).max() < 2e-2      # 10 SGD steps amplify rounding
+    assert np.abs(sub - g['c1_final_logits_sub']).max() < 5e-4      # measured 4.9e-5 after the 10 SGD steps (north_star: 1e-3)
     mask = np.packbits((out >= 0).numpy().astype(np.uint8))
     diff = int(np.unpackbits(mask ^ g['c1_final_mask']).sum())
-    near = int((np.abs(g['c1_final_logits_sub']) < 2e-2).mean() * out.numel()) + int(g['c1_final_near_zero'][0])
-    assert diff <= max(near, 8), (diff, near)
+    assert diff <= int(g['c1_final_near_zero'][0]), diff            # label bits exact outside |logit| < 1e-3 (measured: 0 differ)
     tr = topology.trainable('resnet50')
     offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr])
     params = eng.get_params().cpu()
     for i in range(len(tr)):
         l2 = float(params[offs[i]:offs[i + 1]].double().norm())
-        assert abs(l2 - g['c1_param_fp'][i][1]) <= 1e-3 * g['c1_param_fp'][i][1], tr[i][0]
+        assert abs(l2 - g['c1_param_fp'][i][1]) <= 5e-6 * g['c1_param_fp'][i][1], tr[i][0]      # measured 3.8e-7
+
+
+def test_c2_full_batch3_vs_golden(full_engine, golden_dir):
+    """BASELINE configs[1] as benchmarked: 480x854, batch 3, T=3 iterations on three different frame triples, against
+    the reference-generated fixture G15 -- loss per iteration, first-step gradients (elementwise on 5 tensors, L2 on all
+    64), parameters after T steps, final logits and label bits of all three frames."""
+    g = np.load(os.path.join(golden_dir, 'g15_c2_full_b3.npz'))
+    eng = full_engine
+    eng.reset()
+    tr = topology.trainable('resnet50')
+    offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr])
+    batches = [synthetic.synthetic_frames(3, *FULL, seed=21 + it) for it in range(3)]
+    eng.keep_grads(True)
+    losses = []
+    for it, (x, y) in enumerate(batches):
+        losses.append(eng.finetune_step(x.to(DEV), y.to(DEV)))
+        if it == 0:
+            grads = eng.get_grads().cpu()
+    eng.keep_grads(False)
+    np.testing.assert_allclose(losses, g['losses'], rtol=2e-5)                                    # measured 1.8e-6
+    for i in g['small_ids']:
+        ref = g[f'grad_{i}']
+        got = grads[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9, tr[i][0]               # measured 1.2e-4
+    for i, (n, s) in enumerate(tr):
+        l2 = float(grads[offs[i]:offs[i + 1]].double().norm())
+        assert abs(l2 - g['grad_fp'][i][1]) <= 3e-4 * g['grad_fp'][i][1] + 1e-9, (n, l2)            # measured 2.7e-5
+    params = eng.get_params().cpu()
+    for i in g['small_ids']:
+        ref = g[f'param_{i}']
+        got = params[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
+        assert np.abs(got - ref).max() <= 3e-6 * np.abs(ref).max(), tr[i][0]                      # measured 2.5e-7
+    out = eng.forward(batches[0][0].to(DEV)).cpu()
+    assert np.abs(out[:, 0, ::8, ::7].numpy() - g['final_logits_sub']).max() < 3e-4               # measured 2e-5
+    mask = np.packbits((out >= 0).numpy().astype(np.uint8))
+    diff = int(np.unpackbits(mask ^ g['final_mask']).sum())
+    assert diff <= int(g['final_near_zero'][0]), diff                                             # measured: 0 of 1.23 M bits
 
 
 def test_full_size_properties(full_engine):
@@ -234,20 +274,20 @@ def test_meta_task_vs_golden(small_engine, weights, golden_dir, K):
     tl = [eng.finetune_step(xg, yg, accumulate=True) for _ in range(K)]
     flat = torch.zeros(eng.n_lr + eng.n_param, device=DEV)
     ml = eng.meta_grad(xm.to(DEV), ym.to(DEV), flat)
-    np.testing.assert_allclose(tl, g[f'k{K}_train_losses'], rtol=5e-4)
-    assert abs(ml - g[f'k{K}_meta_loss'][0]) <= 5e-4 * abs(g[f'k{K}_meta_loss'][0])
+    np.testing.assert_allclose(tl, g[f'k{K}_train_losses'], rtol=1e-5)                       # measured 5e-7
+    assert abs(ml - g[f'k{K}_meta_loss'][0]) <= 3e-5 * abs(g[f'k{K}_meta_loss'][0])            # measured 2.2e-6
     flat = flat.cpu()
     ref = g[f'k{K}_lr_grad']
     lr_g = flat[:eng.n_lr].numpy()
-    assert np.abs(lr_g - ref).max() <= 5e-3 * np.abs(ref).max(), np.abs(lr_g - ref).max() / np.abs(ref).max()
+    assert np.abs(lr_g - ref).max() <= 2.5e-3 * np.abs(ref).max(), np.abs(lr_g - ref).max() / np.abs(ref).max()   # measured 2.2e-4
     tr = topology.trainable('resnet50')
     offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr]) + eng.n_lr
     for i, (n, s) in enumerate(tr):
         l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
         r = g[f'k{K}_init_grad_fp'][i][1]
-        assert abs(l2 - r) <= 1e-2 * r + 1e-9, (n, l2, r)
+        assert abs(l2 - r) <= 4e-4 * r + 1e-9, (n, l2, r)                                         # measured 3.4e-5
     last = flat[offs[-3]:offs[-2]].view(*g[f'k{K}_init_grad_last'].shape).numpy()
-    assert np.abs(last - g[f'k{K}_init_grad_last']).max() <= 5e-3 * np.abs(g[f'k{K}_init_grad_last']).max()
+    assert np.abs(last - g[f'k{K}_init_grad_last']).max() <= 6e-4 * np.abs(g[f'k{K}_init_grad_last']).max()     # measured 5.8e-5
     # adding a second time doubles (the call ADDS into the flat buffer)
     eng.load_model_state(*weights)
 
@@ -277,7 +317,7 @@ def test_lr_hierarchy_vs_golden(small_engine, weights, golden_dir, level, use_lo
         assert ns == flat_store.numel()
         flat = torch.zeros(ns + eng.n_param, device=DEV)
         ml = eng.meta_grad(xm.to(DEV), ym.to(DEV), flat)
-        np.testing.assert_allclose(tl, g[tag + '_train_losses'], rtol=5e-4)
+        np.testing.assert_allclose(tl, g[tag + '_train_losses'], rtol=LOSS_RTOL)
         assert abs(ml - g[tag + '_meta_loss'][0]) <= 5e-4 * abs(g[tag + '_meta_loss'][0])
         flat = flat.cpu()
         tr = topology.trainable('resnet50')
@@ -287,21 +327,21 @@ def test_lr_hierarchy_vs_golden(small_engine, weights, golden_dir, level, use_lo
             for i, (n, s) in enumerate(tr):
                 l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
                 r = g[tag + '_lr_grad_fp'][i][1]
-                assert abs(l2 - r) <= 1e-2 * r + 1e-12, (n, l2, r)
+                assert abs(l2 - r) <= HIER_L2_TOL * r + 1e-12, (n, l2, r)
             for idx, key in ((-5, '_lr_grad_dec1'), (-2, '_lr_grad_last')):
                 ref = g[tag + key]
                 i = len(tr) + idx
                 got = flat[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
-                assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max()
+                assert np.abs(got - ref).max() <= LRGRAD_TOL * np.abs(ref).max()
         else:
             ref = g[tag + '_lr_grad']
             got = flat[:ns].numpy()
-            assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+            assert np.abs(got - ref).max() <= LRGRAD_TOL * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
         offs = np.cumsum([0] + sizes) + ns
         for i, (n, s) in enumerate(tr):
             l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
             r = g[tag + '_init_grad_fp'][i][1]
-            assert abs(l2 - r) <= 1e-2 * r + 1e-9, (n, l2, r)
+            assert abs(l2 - r) <= HIER_L2_TOL * r + 1e-9, (n, l2, r)
     finally:
         eng.load_model_state(*weights)          # back to the NEURON lrs the other tests expect
 
@@ -469,11 +509,11 @@ def test_meta_task_with_dice_loss_vs_oracle(small_engine, weights):
         tl = [eng.finetune_step(x.to(DEV), y.to(DEV), accumulate=True) for _ in range(2)]
         flat = torch.zeros(eng.n_lr + eng.n_param, device=DEV)
         ml = eng.meta_grad(xm.to(DEV), ym.to(DEV), flat)
-        np.testing.assert_allclose(tl, ref['train_losses'], rtol=5e-4)
+        np.testing.assert_allclose(tl, ref['train_losses'], rtol=LOSS_RTOL)
         assert abs(ml - ref['meta_loss']) <= 5e-4 * abs(ref['meta_loss'])
         r = torch.cat([t.flatten() for t in ref['g_lr']]).numpy()
         got = flat[:eng.n_lr].cpu().numpy()
-        assert np.abs(got - r).max() <= 5e-3 * np.abs(r).max()
+        assert np.abs(got - r).max() <= LRGRAD_TOL * np.abs(r).max()
     finally:
         eng.set_loss('cross_entropy')
         eng.load_model_state(*weights)
@@ -535,13 +575,13 @@ def test_bptt_schedules_vs_golden(small_engine, weights, golden_dir, tag, bptt, 
     flat = mt.grad.cpu()
     ref = g[tag + '_lr_grad']
     got = flat[:eng.n_lr].numpy()
-    assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    assert np.abs(got - ref).max() <= LRGRAD_TOL * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
     tr = topology.trainable('resnet50')
     offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr]) + eng.n_lr
     for i, (n, s) in enumerate(tr):
         l2 = float(flat[offs[i]:offs[i + 1]].double().norm())
         r = g[tag + '_init_grad_fp'][i][1]
-        assert abs(l2 - r) <= 1e-2 * r + 1e-9, (n, l2, r)
+        assert abs(l2 - r) <= INITGRAD_L2_TOL * r + 1e-9, (n, l2, r)
     eng.load_model_state(*weights)
 
 
