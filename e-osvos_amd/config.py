@@ -3,8 +3,8 @@
 The reference wires `cfgs/meta.yaml` + `cfgs/torch.yaml` as base config and four named configs
 (`train_meta.py:21-27`) and is driven as
     python src/train_meta.py with DAVIS-2017 e-OSVOS-OnA key=val ...
-Sacred is not installed in the target image, so this module keeps the same *keys* (only those
-the hot path reads, same names and nesting as cfgs/meta.yaml), the same named configs and the
+Sacred is not installed in the target image, so this module keeps the same *keys* (same names and
+nesting as cfgs/meta.yaml), the same named configs and the
 same `with <named...> <dotted.key=value...>` command-line grammar; an external YAML file in the
 reference's format can be merged with `load_yaml`.  Values below are the reference defaults,
 except that the hot-path model/loss are selected (`parent_model.architecture=DeepLabV3Plus`,
@@ -26,7 +26,10 @@ BASE = {
     'save_dir': 'models',
     'resume_meta_run_epoch_mode': None,
     'increase_seed_per_meta_run': True,
+    'random_frame_transform_per_task': True,
     'multi_step_bptt_loss': False,
+    'random_frame_epsilon': None,
+    'random_object_id_sub_group': False,
     'num_epochs': {'train': 5, 'eval': 10},
     'bptt_epochs': 5,
     'eval_online_adapt': {'step': 0, 'reset_model_mode': 'FIRST_STEP', 'num_epochs': 10, 'min_prop': 0.5},
@@ -43,15 +46,25 @@ BASE = {
     'parent_model': {'architecture': 'DeepLabV3Plus', 'train_encoder': True,
                      'batch_norm': {'accum_stats': False, 'learn_weight': False, 'learn_bias': False},
                      'replace_batch_with_group_norms': False, 'decoder_norm_layer': 'BatchNorm2d',
-                     'eval_augment_rpn_proposals_mode': None, 'roi_pool_output_sizes': None,
-                     'maskrcnn_loss': None, 'box_nms_thresh': None, 'encoder': 'resnet50'},
+                     'eval_augment_rpn_proposals_mode': None, 'roi_pool_output_sizes': {'box': 7, 'mask': 28},
+                     'maskrcnn_loss': None, 'box_nms_thresh': None, 'encoder': 'resnet50',
+                     # per-dataset parent checkpoints (`init_parent_model(**datasets)`, helper_func.py:339-385)
+                     'train': {'paths': [], 'val_split_files': ['data/DAVIS-2017/train_val_seqs.txt']},
+                     'val': {'paths': [], 'val_split_files': ['data/DAVIS-2017/train_val_seqs.txt']},
+                     'test': {'paths': [], 'val_split_files': ['data/DAVIS-2017/test-dev_seqs.txt']}},
     'train_early_stopping_cfg': {'patience': None, 'min_loss_improv': 0.001},
+    'single_obj_seq_mode': 'KEEP',
+    'random_flip_label': False,
+    'random_no_label': False,
+    'random_box_coord_perm': False,
     'data_cfg': {'multi_object': False, 'random_train_transform': False, 'num_workers': 0, 'pin_memory': False,
                  'normalize': False, 'full_resolution': False,
                  'frame_ids': {'train': 0, 'test': None, 'meta': None},
                  'batch_sizes': {'train': 1, 'test': 1, 'meta': 1},
-                 'shuffles': {'train': True, 'test': False, 'meta': False}},
-    'torch_cfg': {'print_config': False},
+                 'shuffles': {'train': True, 'test': False, 'meta': False},
+                 'crop_sizes': {'train': None, 'test': None, 'meta': None}},
+    'torch_cfg': {'print_config': False, 'device': None, 'deterministic': True, 'benchmark': False,
+                  'vis': {'port': 8090, 'server': 'http://localhost'}},
 }
 
 # named configs of train_meta.py:24-27 (hot-path keys of cfgs/meta_davis-2017.yaml,
@@ -65,7 +78,13 @@ NAMED = {
                                            'split': ['train_dev_random_123_train_seqs', 'train_seqs'], 'eval': False},
                                  'val': {'name': 'YouTube-VOS', 'split': 'valid-all-frames_seqs', 'eval': False},
                                  'test': {'name': 'YouTube-VOS', 'split': None, 'eval': False},
+                                 'train_dev_train_val': {'name': 'YouTube-VOS', 'split': 'train_dev_random_123_train_val_seqs',
+                                                         'eval': False},
+                                 'train_dev_val': {'name': 'YouTube-VOS', 'split': 'train_dev_random_123_val_seqs', 'eval': False},
+                                 'val_davis16': {'name': 'DAVIS-2016', 'split': 'val_seqs', 'eval': False},
                                  'val_davis17': {'name': 'DAVIS-2017', 'split': 'val_seqs', 'eval': True}},
+                    'parent_model': {'train': {'paths': [], 'val_split_files': []}, 'val': {'paths': [], 'val_split_files': []},
+                                     'test': {'paths': [], 'val_split_files': []}},
                     'data_cfg': {'multi_object': 'single_id'}},
     # the iteration counts come from the command line as in the reference README
     # (`with DAVIS-2017 e-OSVOS num_epochs.eval=50`, `... e-OSVOS-OnA num_epochs.eval=100`)

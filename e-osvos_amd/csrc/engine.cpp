@@ -214,9 +214,11 @@ struct eosvos_engine {
   bool have_loss_grad = false;
   int force_algo = 0;                 // EOSVOS_ALGO_*: 0 = plan by work size; the op-level parity tests force one path
 
+  int64_t max_alloc_floats = 0;      // largest single allocation (every conv operand is one of them)
   float* falloc(int64_t n) {
     void* p = nullptr;
     if (n < 1) n = 1;
+    if (n > max_alloc_floats) max_alloc_floats = n;
     if (hipMalloc(&p, (size_t)n * sizeof(float)) != hipSuccess) return nullptr;
     allocs.push_back(p);
     return (float*)p;
@@ -666,6 +668,19 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   if (!out) return fail("null out");
   if (norm_mode != EOSVOS_NORM_BN_FROZEN && norm_mode != EOSVOS_NORM_GN16) return fail("unknown norm mode");
   if (height < 32 || width < 32 || max_batch < 1) return fail("bad geometry");
+  {
+    // The conv kernels address every operand through a buffer descriptor of at most 2^31 - 1 bytes with 32-bit byte
+    // offsets (conv_kernels.hip make_rsrc): beyond that the hardware range check would zero-fill instead of failing.
+    // The largest operands are the Winograd-domain planes of the decoder (36 x tiles x 304 floats) and the stem output.
+    const int64_t h2 = conv_out(height, 7, 2, 1, 3), w2 = conv_out(width, 7, 2, 1, 3);
+    const int64_t h4 = conv_out((int)h2, 3, 2, 1, 1), w4 = conv_out((int)w2, 3, 2, 1, 1);
+    const int64_t tiles = ((int64_t)max_batch * ((h4 + 3) / 4) * ((w4 + 3) / 4) + 127) / 128 * 128;
+    const int64_t worst = std::max<int64_t>({36 * tiles * 304, (int64_t)max_batch * h4 * w4 * 304, (int64_t)max_batch * h2 * w2 * 64,
+                                            (int64_t)max_batch * (height + 6) * (width + 6) * 3});
+    if (worst * 4 > 0x7fffffffLL)
+      return fail("frame size x max_batch too large: a conv operand of " + std::to_string(worst * 4) +
+                  " bytes exceeds the 2 GiB buffer-descriptor range of the kernels (reduce max_batch or the frame size)");
+  }
   eosvos_engine* e = new eosvos_engine();
   if (!build_topo(arch, e->t)) { delete e; return fail("bad arch"); }
   e->norm_mode = norm_mode;
@@ -816,6 +831,12 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
       e->ws_conv2 = e->falloc(conv_ws_floats());
       if (!e->ws_conv2) { eosvos_destroy(e); return fail("hipMalloc side workspace"); }
     }
+  }
+  if (e->max_alloc_floats * 4 > 0x7fffffffLL && e->max_alloc_floats != wsw && e->max_alloc_floats != wsc) {
+    // belt and braces for topologies / sizes the estimate above does not cover (slab arenas are plain pointers)
+    const int64_t bytes = e->max_alloc_floats * 4;
+    eosvos_destroy(e);
+    return fail("internal buffer of " + std::to_string(bytes) + " bytes exceeds the 2 GiB buffer-descriptor range");
   }
   // identity norm until eosvos_set_norm
   launch_fill(e->na, t.nnorm, 1.f, e->s);

@@ -57,6 +57,8 @@ class Engine:
                                           self.device.index or 0, ctypes.c_void_p(self.stream.cuda_stream)))
         self.h = h
         self._loss = torch.zeros(1, device=self.device)
+        # host-side view of the engine's state (networks.DeepLabV3Plus carries it across an engine re-creation)
+        self.steps_since_reset, self.has_snapshot, self.in_meta_task = 0, False, False
 
     def close(self):
         if getattr(self, 'h', None):
@@ -75,6 +77,7 @@ class Engine:
         assert flat.numel() == self.n_param
         _ffi.check(self.lib.eosvos_set_init(self.h, _ptr(flat)))
         self.synchronize()
+        self.steps_since_reset = 0
 
     def set_lr(self, flat):
         flat = _dev_f32(flat, self.device)
@@ -125,6 +128,7 @@ class Engine:
 
     def reset(self):
         _ffi.check(self.lib.eosvos_reset(self.h))
+        self.steps_since_reset, self.in_meta_task = 0, False
 
     def get_params(self):
         out = torch.empty(self.n_param, device=self.device)
@@ -138,12 +142,21 @@ class Engine:
 
     def snapshot(self):
         _ffi.check(self.lib.eosvos_snapshot_params(self.h))
+        self.has_snapshot = True
 
     def restore(self):
         _ffi.check(self.lib.eosvos_restore_params(self.h))
 
     # ---- hot loop -------------------------------------------------------------------
+    def _check_stream(self):
+        """The engine launches on the stream that was current when it was built; tensors the caller produces or
+        consumes on another torch stream would be unordered with those launches."""
+        if torch.cuda.current_stream(self.device) != self.stream:
+            raise _ffi.EosvosError('the current torch stream is not the stream this engine is bound to: call it under '
+                                   '`with torch.cuda.stream(engine.stream)` (or build the engine on this stream)')
+
     def _check_images(self, images):
+        self._check_stream()
         assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
         b, c, h, w = images.shape
         assert c == 3 and h == self.height and w == self.width and 1 <= b <= self.max_batch, images.shape
@@ -186,11 +199,14 @@ class Engine:
         return loss
 
     def backward_step(self, accumulate=False):
+        self._check_stream()
         _ffi.check(self.lib.eosvos_backward_step(self.h, int(accumulate)))
+        self.steps_since_reset += 1
 
     def finetune_step(self, images, masks, accumulate=False, sync_loss=True):
         b = self._check_images(images)
         assert masks.is_cuda and masks.is_contiguous() and masks.shape[0] == b
+        self.steps_since_reset += 1
         if sync_loss:
             l = ctypes.c_float()
             _ffi.check(self.lib.eosvos_finetune_step(self.h, _ptr(images), _ptr(masks), b, int(accumulate),
@@ -225,6 +241,7 @@ class Engine:
     # ---- meta-training ----------------------------------------------------------------
     def meta_task_begin(self):
         _ffi.check(self.lib.eosvos_meta_task_begin(self.h))
+        self.steps_since_reset, self.in_meta_task = 0, True
 
     def meta_grad(self, images, masks, flat_meta_grad, weight=1.0, init_grad=True, new_segment=False):
         """ADDS weight * task meta-gradient into flat_meta_grad ([lr state | init]); returns the meta loss.

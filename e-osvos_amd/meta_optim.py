@@ -138,7 +138,7 @@ class MetaOptimizer:
     def init_zero_grad(self):
         eng = self.model.engine
         dev = eng.device if eng is not None else self.model.device
-        n = self._lr_flat.numel() + self.model._flat.numel()
+        n = self._lr_flat.numel() + (self.model._flat.numel() if self._learn_model_init else 0)
         self._grad_flat = torch.zeros(n, device=dev)
         off = 0
         for p in self._params.values():
@@ -170,7 +170,9 @@ class MetaOptimizer:
     # ---- inner loop ------------------------------------------------------------------------------
     def reset(self, keep_state=False):
         if keep_state:
+            self._first_segment = False      # detached: nothing after this reaches log_init_lr_* / model_init_*
             return
+        self._first_segment = True
         m = self.model
         if m.engine is not None:
             if m._dirty:
@@ -190,18 +192,25 @@ class MetaOptimizer:
         eng = getattr(train_loss, '_eosvos_engine', None)
         if eng is None:
             raise RuntimeError('step() needs the loss returned by eosvos_amd.helper_func.compute_loss')
-        eng.backward_step(accumulate=self.training)
+        eng.backward_step(accumulate=self.training and getattr(self, '_first_segment', True))
         self.state['num_steps'] += 1
 
-    def meta_backward(self, meta_inputs, meta_gts, loss_func='cross_entropy'):
-        """`bptt_loss.backward()` for one meta frame batch: returns the meta loss (float) and ADDS the
-        task's meta-gradient into `.grad` of named_parameters()."""
+    def meta_backward(self, meta_inputs, meta_gts, loss_func='cross_entropy', weight=1.0):
+        """`(weight * meta_loss).backward()` for one meta frame batch (`meta_run.py:155-214`): returns the meta loss
+        (float) and ADDS `weight` x the task's meta-gradient into `.grad` of named_parameters().  `weight` is the
+        per-step factor of `multi_step_bptt_loss`.  After `reset(keep_state=True)` the graph to the learned tensors is
+        cut, so only the loss value is computed."""
         if self._grad_flat is None:
             self.init_zero_grad()
         eng = self.model._ensure_engine(meta_inputs.shape[2], meta_inputs.shape[3], meta_inputs.shape[0])
         eng.set_loss(loss_func)
-        task = torch.zeros_like(self._grad_flat)
-        loss = eng.meta_grad(meta_inputs.contiguous(), meta_gts.contiguous(), task)
+        if not getattr(self, '_first_segment', True):
+            eng.forward(meta_inputs.contiguous(), want_logits=False)
+            return float(eng.loss(loss_func, meta_gts.contiguous().float()))
+        task = torch.zeros(self._lr_flat.numel() + self.model._flat.numel(), device=self._grad_flat.device)
+        loss = eng.meta_grad(meta_inputs.contiguous(), meta_gts.contiguous(), task, weight=weight,
+                             init_grad=self._learn_model_init)
         if not math.isnan(loss):
-            self._grad_flat.add_(task)
+            n = self._grad_flat.numel()             # learn_model_init False: only the lr slice is a Parameter
+            self._grad_flat.add_(task[:n])
         return loss

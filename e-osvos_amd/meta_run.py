@@ -22,7 +22,7 @@ from .topology import neuron_lr_shape, trainable
 class MetaTrainer:
     def __init__(self, engine, dist=None, meta_batch_size=4, model_init_lr=1e-5, log_init_lr_lr=1e-5,
                  model_init_weight_decay=1e-3, grad_clip=None, max_lr=None, lr_hierarchy_level='NEURON',
-                 use_log_init_lr=False, loss_func='cross_entropy'):
+                 use_log_init_lr=False, loss_func='cross_entropy', learn_model_init=True, freeze_encoder=False):
         self.eng = engine
         self.level, self.use_log = lr_hierarchy_level, bool(use_log_init_lr)
         self.n_lr = engine.lr_store_count(lr_hierarchy_level)        # NotImplementedError for unknown levels
@@ -32,6 +32,20 @@ class MetaTrainer:
         self.meta_batch_size = meta_batch_size
         self.model_init_lr, self.log_init_lr_lr = model_init_lr, log_init_lr_lr
         self.wd, self.grad_clip, self.max_lr = model_init_weight_decay, grad_clip, max_lr
+        # `learn_model_init: False`: model_init_* are no Parameters (meta_optim.py:76-78) -- no meta-gradient, no RAdam
+        # step, not in the state dict.  `freeze_encoder` (train_meta.py:120-121): lr = 0 for every learned tensor whose
+        # name contains 'backbone' (log_init_lr_backbone-* and model_init_backbone-*).
+        self.learn_model_init, self.freeze_encoder = bool(learn_model_init), bool(freeze_encoder)
+        tr = trainable(engine.encoder)
+        nb = sum(1 for n_, _ in tr if n_.startswith('backbone'))
+        assert all(n_.startswith('backbone') for n_, _ in tr[:nb])      # the backbone tensors come first
+        self._backbone_param = sum(math.prod(s) for _, s in tr[:nb])
+        if lr_hierarchy_level == 'NEURON':
+            self._backbone_lr = sum(math.prod(neuron_lr_shape(s)) for _, s in tr[:nb])
+        elif lr_hierarchy_level == 'PARAM':
+            self._backbone_lr = self._backbone_param
+        else:
+            self._backbone_lr = 0            # one `log_init_lr` Parameter: its name has no 'backbone'
         n = self.n_lr + engine.n_param
         dev = engine.device
         self.state = torch.zeros(n, device=dev)
@@ -68,6 +82,8 @@ class MetaTrainer:
                 k = math.prod(s)
                 out['log_init_lr_' + n.replace('.', '-')] = self.state[off:off + k].view(s)
                 off += k
+        if not self.learn_model_init:
+            return out
         for n, shape in tr:
             k = math.prod(shape)
             out['model_init_' + n.replace('.', '-')] = self.state[off:off + k].view(shape)
@@ -97,7 +113,8 @@ class MetaTrainer:
 
         def meta_frame(weight, boundary):
             if first_segment:
-                return eng.meta_grad(x_meta, y_meta, self.task_grad, weight=weight, init_grad=True, new_segment=boundary)
+                return eng.meta_grad(x_meta, y_meta, self.task_grad, weight=weight, init_grad=self.learn_model_init,
+                                     new_segment=boundary)
             eng.forward(x_meta, want_logits=False)                     # detached segment: loss value only
             return float(eng.loss(self.loss_func, y_meta))
 
@@ -137,7 +154,16 @@ class MetaTrainer:
         nl = self.n_lr
         scale = 1.0 / self.meta_batch_size
         clip = float(self.grad_clip) if self.grad_clip is not None else 0.0
-        for lo, hi, lr, wd in ((0, nl, self.log_init_lr_lr, 0.0), (nl, self.state.numel(), self.model_init_lr, self.wd)):
+        ranges = []                                          # (lo, hi, lr, weight decay): the reference's per-tensor groups
+        fl, fp = (self._backbone_lr, self._backbone_param) if self.freeze_encoder else (0, 0)
+        if fl:
+            ranges.append((0, fl, 0.0, 0.0))
+        ranges.append((fl, nl, self.log_init_lr_lr, 0.0))
+        if self.learn_model_init:
+            if fp:
+                ranges.append((nl, nl + fp, 0.0, self.wd))
+            ranges.append((nl + fp, self.state.numel(), self.model_init_lr, self.wd))
+        for lo, hi, lr, wd in ranges:
             eng.radam_step(self.state[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                            lr, wd, self.step, grad_scale=scale, grad_clip=clip)
         if self.use_log:                                    # clamp_init_lr, meta_optim.py:116-133

@@ -147,10 +147,27 @@ class DeepLabV3Plus:
     def _ensure_engine(self, height, width, batch):
         e = self.engine
         if e is None or e.height != height or e.width != width or batch > e.max_batch:
+            carry = None
             if e is not None:
+                # A new frame size / larger batch needs a new engine.  Fine-tuned weights travel with it; state that
+                # cannot (the FIRST_STEP snapshot, the sum_k g_k of a running meta task) makes it an error instead of
+                # silently restarting from the learned init.
+                if e.in_meta_task and e.steps_since_reset > 0:
+                    raise _ffi.EosvosError('frame size / batch changed in the middle of a meta task (sum_k g_k would be lost): '
+                                           'size max_batch for the largest batch of the task up front')
+                if e.has_snapshot:
+                    raise _ffi.EosvosError('frame size / batch changed while a first-step snapshot is held (online adaptation): '
+                                           'size max_batch for the adaptation batches up front')
+                if e.steps_since_reset > 0 and not self._dirty:
+                    carry = e.get_params()
                 e.close()
             self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm)
+            self.max_batch = max(batch, self.max_batch)
             self._dirty = True
+            if carry is not None:
+                self.push_state()
+                self.engine.set_params(carry)
+                self.engine.steps_since_reset = 1
         if self._dirty:
             self.push_state()
         if getattr(self, '_pending_task_begin', False):

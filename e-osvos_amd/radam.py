@@ -37,23 +37,30 @@ class RAdam:
                     p.grad.zero_()
 
     def step(self, grad_scale=1.0, grad_clip=0.0):
+        """All tensors' kernels are enqueued on the engine's stream first, then ONE synchronisation, then the
+        write-back (not one stream sync per tensor: the reference builds 128 single-tensor groups)."""
         dev = self.engine.device
-        for g in self.param_groups:
-            for p in g['params']:
-                if getattr(p, 'grad', None) is None:
-                    continue
-                st = self.state.setdefault(id(p), {})
-                if not st:
-                    st['step'] = 0
-                    st['param'] = p.data.detach().to(dev, torch.float32).contiguous().clone()
-                    st['exp_avg'] = torch.zeros_like(st['param'])
-                    st['exp_avg_sq'] = torch.zeros_like(st['param'])
-                else:
-                    st['param'].copy_(p.data)
-                st['step'] += 1
-                grad = p.grad.detach().to(dev, torch.float32).contiguous()
-                self.engine.radam_step(st['param'], grad, st['exp_avg'], st['exp_avg_sq'], g['lr'], g['weight_decay'],
-                                       st['step'], grad_scale=grad_scale, grad_clip=grad_clip, betas=g['betas'],
-                                       eps=g['eps'])
-                self.engine.synchronize()
+        done = []
+        with torch.cuda.stream(self.engine.stream):
+            for g in self.param_groups:
+                for p in g['params']:
+                    if getattr(p, 'grad', None) is None:
+                        continue
+                    st = self.state.setdefault(id(p), {})
+                    if not st:
+                        st['step'] = 0
+                        st['param'] = p.data.detach().to(dev, torch.float32).contiguous().clone()
+                        st['exp_avg'] = torch.zeros_like(st['param'])
+                        st['exp_avg_sq'] = torch.zeros_like(st['param'])
+                    else:
+                        st['param'].copy_(p.data)
+                    st['step'] += 1
+                    st['grad'] = p.grad.detach().to(dev, torch.float32).contiguous()     # kept alive until the sync
+                    self.engine.radam_step(st['param'], st['grad'], st['exp_avg'], st['exp_avg_sq'], g['lr'],
+                                           g['weight_decay'], st['step'], grad_scale=grad_scale, grad_clip=grad_clip,
+                                           betas=g['betas'], eps=g['eps'])
+                    done.append((p, st))
+            self.engine.synchronize()
+            for p, st in done:
                 p.data.copy_(st['param'])
+                st.pop('grad', None)

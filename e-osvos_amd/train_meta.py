@@ -87,7 +87,8 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2):
                      log_init_lr_lr=oc['log_init_lr_lr'], model_init_weight_decay=oc['model_init_weight_decay'],
                      grad_clip=oc['grad_clip'], max_lr=cfg['meta_optim_cfg']['max_lr'],
                      lr_hierarchy_level=cfg['meta_optim_cfg']['lr_hierarchy_level'],
-                     use_log_init_lr=cfg['meta_optim_cfg']['use_log_init_lr'], loss_func=cfg['loss_func'])
+                     use_log_init_lr=cfg['meta_optim_cfg']['use_log_init_lr'], loss_func=cfg['loss_func'],
+                     learn_model_init=cfg['meta_optim_cfg']['learn_model_init'], freeze_encoder=oc['freeze_encoder'])
     mt.load_state(model.state_dict(), [p.data for n, p in meta_optim.named_parameters() if n.startswith('log_init_lr')])
     for it in range(num_meta_iters):
         tasks = []

@@ -16,3 +16,14 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests skip (instead of erroring in their fixtures) on a host without a GPU."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='needs a real MI355X (no GPU visible)')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)

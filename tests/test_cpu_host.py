@@ -236,3 +236,32 @@ def test_outer_step_two_ranks_gloo(tmp_path):
         else:
             np.testing.assert_allclose(two.numpy(), res[0]['state'].numpy(), rtol=1e-6, atol=1e-8)
             assert float(res[0]['state'][:8].min()) >= 0
+
+
+def test_config_accepts_every_reference_key(golden_dir):
+    """G16: every key of cfgs/meta.yaml + cfgs/torch.yaml exists in config.BASE (Sacred rejects unknown keys, so a
+    `with key=val` of the reference must stay valid) and the four named configs carry exactly the reference's values."""
+    import json
+    from eosvos_amd import config
+    g = json.load(open(os.path.join(golden_dir, 'g16_cfg_keys.json')))
+
+    def flat(d, p=''):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict) and v:
+                out.update(flat(v, p + k + '.'))
+            else:
+                out[p + k] = v
+        return out
+    base = flat(config.BASE)
+    assert sorted(base) == sorted(g['base_keys'])
+    for key in g['base_keys']:
+        cfg = config.parse_cli(['with', f'{key}=1'])           # the CLI grammar accepts an override of any of them
+        assert flat(cfg)[key] == 1
+    for name, vals in g['named'].items():
+        assert flat(config.NAMED[name]) == vals, name
+        cfg = flat(config.parse_cli(['with', name]))
+        for k, v in vals.items():
+            assert cfg[k] == v, (name, k)
+    with pytest.raises(KeyError):
+        config.parse_cli(['with', 'not_a_reference_key=1'])

@@ -269,3 +269,59 @@ def test_run_frames_metrics(model_and_optim):
         assert float((accs - ref_acc).abs().max()) < 2e-3
     none = run_frames(model, x.to(DEV))
     assert none[0] is None and none[2].shape == (3, 1, *SMALL)
+
+
+@pytest.mark.parametrize('tag,bptt,multi', [('trunc', 2, None), ('multi', 4, [0.1, 0.2, 0.3, 0.4]), ('both', 2, [0.1, 0.2, 0.3, 0.4])])
+def test_dropin_bptt_schedules_vs_golden(golden_dir, tag, bptt, multi):
+    """The reference's own task loop (`meta_run.py:154-221`: `reset(keep_state=True)` between segments, per-step
+    `multi_step_bptt_loss` weights) written against the drop-in MetaOptimizer, vs the reference autograd (fixture G14)."""
+    from eosvos_amd.helper_func import compute_loss, init_parent_model
+    from eosvos_amd.meta_optim import MetaOptimizer
+    g = np.load(os.path.join(golden_dir, 'g14_bptt.npz'))
+    model, _ = init_parent_model(architecture='DeepLabV3Plus', encoder='resnet50', train_encoder=True,
+                                 decoder_norm_layer='BatchNorm2d', replace_batch_with_group_norms=False,
+                                 batch_norm=BN_CFG, roi_pool_output_sizes=None, eval_augment_rpn_proposals_mode=None,
+                                 box_nms_thresh=None, maskrcnn_loss=None)
+    model.to(DEV)
+    sd = synthetic.synthetic_state('resnet50')
+    model.load_state_dict(sd)
+    mo = MetaOptimizer(model, **MO_CFG)
+    msd = {}
+    for (n, _), lr in zip(topology.trainable('resnet50'), synthetic.synthetic_lrs('resnet50')):
+        msd['log_init_lr_' + n.replace('.', '-')] = lr.clone()
+    for n, _ in topology.trainable('resnet50'):
+        msd['model_init_' + n.replace('.', '-')] = sd[n].clone()
+    mo.init_zero_grad()
+    mo.load_state_dict(msd)
+    mo.reset()
+    mo.zero_grad()
+    mo.train()
+    model.train_without_dropout()
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1404)
+    xg, yg = x.to(DEV), y.to(DEV)
+    xm, ym = torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()
+    K, meta_losses = 4, []
+    for epoch in range(1, K + 1):
+        loss = compute_loss('cross_entropy', model(xg)[-1], yg)
+        mo.set_train_loss(loss)
+        mo.step(loss)
+        if multi:
+            meta_losses.append(mo.meta_backward(xm, ym, weight=multi[epoch - 1]))
+        stop = epoch == K
+        if not epoch % bptt or stop:
+            if not multi:
+                meta_losses.append(mo.meta_backward(xm, ym))
+            if not stop:
+                mo.reset(keep_state=True)
+    np.testing.assert_allclose(meta_losses, g[tag + '_meta_losses'], rtol=3e-5)
+    params = dict(mo.named_parameters())
+    got = torch.cat([p.grad.flatten() for n, p in params.items() if n.startswith('log_init_lr_')]).cpu().numpy()
+    ref = g[tag + '_lr_grad']
+    assert np.abs(got - ref).max() <= 2.5e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    init_g = [p.grad for n, p in params.items() if n.startswith('model_init_')]
+    for i, gi in enumerate(init_g):
+        r = g[tag + '_init_grad_fp'][i][1]
+        assert abs(float(gi.double().norm()) - r) <= 4e-4 * r + 1e-9, i
+    last = init_g[-2].cpu().numpy()
+    assert np.abs(last - g[tag + '_init_grad_last']).max() <= 6e-4 * np.abs(g[tag + '_init_grad_last']).max()
+    model.engine.close()

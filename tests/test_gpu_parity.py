@@ -555,6 +555,13 @@ def test_edge_cases_and_error_behaviour(small_engine, weights):
     # the engine is still usable after the failed calls
     assert np.isfinite(eng.finetune_step(xg, torch.zeros(2, 1, *SMALL, device=DEV)))
     eng.load_model_state(*weights)
+    # shapes whose largest conv operand would not fit the kernels' 2 GiB buffer descriptors are refused at creation
+    # (beyond it the hardware range check would silently zero-fill): 480x854 needs 213 MB of Winograd planes per 3 frames
+    h = ctypes.c_void_p()
+    rc = lib.eosvos_create(ctypes.byref(h), 50, 0, 480, 854, 40, 0, None)
+    assert rc != 0 and b'2 GiB' in lib.eosvos_last_error()
+    rc = lib.eosvos_create(ctypes.byref(h), 50, 0, 4000, 6000, 1, 0, None)
+    assert rc != 0 and b'2 GiB' in lib.eosvos_last_error()
 
 
 @pytest.mark.parametrize('tag,bptt,multi', [('trunc', 2, None), ('multi', 4, [0.1, 0.2, 0.3, 0.4]),

@@ -10,16 +10,19 @@ for n in (1, 2, 3):
     for i in range(n):
         with torch.cuda.stream(torch.cuda.Stream()):
             e = Engine("resnet50", 480, 854, max_batch=B)
-        e.load_model_state(synthetic.synthetic_state("resnet50"), synthetic.synthetic_lrs("resnet50"))
+            e.load_model_state(synthetic.synthetic_state("resnet50"), synthetic.synthetic_lrs("resnet50"))
         engs.append(e)
+    def step(e):
+        with torch.cuda.stream(e.stream):          # an engine is called on the stream it is bound to
+            e.finetune_step(xg, yg, sync_loss=False)
     x, y = synthetic.synthetic_frames(B, 480, 854); xg, yg = x.cuda(), y.cuda()
     torch.cuda.synchronize()
     for _ in range(3):
-        for e in engs: e.finetune_step(xg, yg, sync_loss=False)
+        for e in engs: step(e)
     for e in engs: e.synchronize()
     t0 = time.perf_counter()
     for _ in range(10):
-        for e in engs: e.finetune_step(xg, yg, sync_loss=False)
+        for e in engs: step(e)
     t1 = time.perf_counter()
     for e in engs: e.synchronize()
     dt = time.perf_counter() - t0
