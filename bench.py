@@ -100,7 +100,7 @@ def pmc_traffic(kernel, lib_version, batch):
 def profiled_pass(eng, run_step, steps):
     """Per-kernel totals over `steps` more steps with HIP events around every matrix-core launch."""
     eng.profile_launches(True)
-    torch.cuda.synchronize()
+    eng.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         run_step()
@@ -193,7 +193,9 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, m
         dist.destroy_process_group()
 
 
-def main():
+def main(argv=None, engine_factory=None, device=None, backend='nccl'):
+    """`engine_factory` / `device` / `backend`: the gloo CPU tests of this control flow pass a stand-in engine, 'cpu' and
+    'gloo' (tests/test_multiprocess.py); the benchmark itself always runs the HIP engine on cuda under RCCL."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 200 fine-tune iterations / 40 '
@@ -205,7 +207,7 @@ def main():
     ap.add_argument('--metric', choices=['finetune', 'meta'], default='finetune',
                     help="'meta': the JSON line reports meta-tasks/s (BASELINE configs[3..4]: one task per rank per "
                          "meta-iteration, all-reduce + RAdam included); a step is then one meta-iteration")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     if a.steps is None:
         a.steps = 200 if a.metric == 'finetune' else 40
 
@@ -218,9 +220,12 @@ def main():
         dist = dist_
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
-    dev = f'cuda:{local_rank}'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        else:
+            dist.init_process_group(backend)
+    dev = device or f'cuda:{local_rank}'
 
     from eosvos_amd import _ffi, synthetic
     from eosvos_amd import engine as engine_mod
@@ -232,15 +237,17 @@ def main():
     sd = synthetic.synthetic_state('resnet50')
     lrs = synthetic.synthetic_lrs('resnet50')
     x, y = synthetic.synthetic_frames(BATCH, H, W, seed=7 + rank)
-    eng = Engine('resnet50', H, W, max_batch=BATCH, device=dev)
+    eng = (engine_factory or Engine)('resnet50', H, W, max_batch=BATCH, device=dev)
     eng.load_model_state(sd, lrs)
     xg, yg = x.to(dev), y.to(dev)
 
     def barrier():
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     if a.metric == 'meta':
         return bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version)

@@ -6,29 +6,36 @@
 
 What is kept from the reference: config keys / named configs (config.py), the MetaOptimizer state
 layout and the checkpoint files `{save_dir}/{env_suffix}/last_meta_iter.model`
-(`train_meta.py:277-286`), `meta_optim_model_file` warm start (`:101-103`),
-`resume_meta_run_epoch_mode: LAST` (`:70-77`), EVAL mode when `num_meta_processes_per_gpu == 0`
-(`:148-153`), the outer step (`:361-373`).  What is replaced: the spawn + shared-CPU-memory
-worker protocol (`:155-201`, `meta_run.py:88-99,237-243`) -> one process per GPU under
-torch.distributed (RCCL), tasks sharded over ranks, one all-reduce per meta-iteration.
-The dataset layer (DAVIS / YouTube-VOS loaders, augmentation) is the next scope row
-(SURVEY.md 8f.2): until it lands this entry point runs on the seeded synthetic sequences of
-synthetic.py (`data=synthetic` in the log line).
+(`train_meta.py:277-286`), `last_{key}_meta_iter.model` / `best_{key}_meta_iter.model` and the prediction PNGs
+`{save_dir}/{run}/best_eval_preds/{name}/{split}/{seq}/{frame}.png` of the eval workers (`evaluate.py:68-90,332-382`),
+`meta_optim_model_file` warm start (`:101-103`), `resume_meta_run_epoch_mode: LAST` (`:70-77`), EVAL mode when
+`num_meta_processes_per_gpu == 0` (`:148-153`), the outer step (`:361-373`), the concurrent validation process
+(`:175-186`).  What is replaced: the spawn + shared-CPU-memory worker protocol (`:155-201`,
+`meta_run.py:88-99,237-243`) -> one process per GPU under torch.distributed (RCCL), tasks sharded over ranks, one
+all-reduce per meta-iteration; evaluation work items (sequence, object) sharded over ranks.
+
+Data: `datasets.*` are read from `{data_root}/{name}` (DAVIS-2016 / DAVIS-2017 / YouTube-VOS layouts, data.py) when
+that directory exists; otherwise the seeded synthetic sequences of synthetic.py (`data=synthetic` in the log line) --
+no dataset is reachable from the build or bench boxes.
 """
 import json
 import os
+import random
+import subprocess
 import sys
 import time
 
 import torch
 
 from . import config as config_mod
+from . import data as data_mod
 from . import synthetic
 from .checkpoint import checkpoint_names, load_meta_checkpoint, save_meta_checkpoint
-from .evaluate import evaluate_sequence
-from .helper_func import init_parent_model
+from .evaluate import evaluate_dataset
+from .helper_func import init_parent_model, set_random_seeds
 from .meta_optim import MetaOptimizer
-from .meta_run import MetaTrainer, shard_tasks
+from .meta_run import MetaTrainer
+from .meta_tasksets import ConcatTaskset, MetaTaskset, task_order
 
 
 def _dist():
@@ -38,22 +45,72 @@ def _dist():
     import torch.distributed as dist
     local = int(os.environ.get('LOCAL_RANK', 0))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    torch.cuda.set_device(local)
-    dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+    backend = os.environ.get('EOSVOS_DIST_BACKEND', 'nccl')      # 'gloo' for the CPU tests of the host logic
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+    else:
+        dist.init_process_group(backend)
     return dist, dist.get_rank(), world, local
 
 
-def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2):
+def _train_tasksets(cfg, data_root):
+    """MetaTaskset(s) of `datasets.train` (`meta_run.py:41-66`), or None when no dataset root exists."""
+    tr = cfg['datasets']['train']
+    names = tr['name'] if isinstance(tr['name'], list) else [tr['name']]
+    splits = tr['split'] if isinstance(tr['split'], list) else [tr['split']]
+    if not all(os.path.isdir(os.path.join(data_root, n)) for n in names):
+        return None
+    dc = cfg['data_cfg']
+    sets = [MetaTaskset(data_mod.open_dataset(n, s, data_root, multi_object=dc['multi_object'], normalize=dc['normalize'],
+                                              full_resolution=dc['full_resolution']), dc,
+                        cfg['random_frame_transform_per_task'], cfg['random_flip_label'], cfg['random_no_label'],
+                        cfg['single_obj_seq_mode'], cfg['random_box_coord_perm'], cfg['random_frame_epsilon'],
+                        cfg['random_object_id_sub_group']) for n, s in zip(names, splits)]
+    return ConcatTaskset(sets)
+
+
+def _start_eval_process(cfg, run_dir, device, data_root, height, width, num_frames, eval_cmd):
+    """Child process for the datasets with `eval: True` (train_meta.py:175-186).  Must run before this process
+    initialises the GPU."""
+    os.makedirs(run_dir, exist_ok=True)
+    for f in ('eval_stop', 'eval_snapshot.model'):
+        if os.path.exists(os.path.join(run_dir, f)):
+            os.remove(os.path.join(run_dir, f))
+    cfg_path = os.path.join(run_dir, 'config.json')
+    json.dump(cfg, open(cfg_path, 'w'))
+    cmd = list(eval_cmd) if eval_cmd else [sys.executable, '-m', 'eosvos_amd.eval_worker']
+    cmd += ['--run-dir', run_dir, '--config', cfg_path, '--device', device, '--data-root', data_root,
+            '--height', str(height), '--width', str(width), '--num-frames', str(num_frames)]
+    return subprocess.Popen(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data_root='data', eval_cmd=None,
+         device=None):
     cfg = config_mod.parse_cli(sys.argv[1:] if argv is None else argv)
-    dist, rank, world, local = _dist()
-    dev = f'cuda:{local}'
     run = cfg['env_suffix'] or 'run'
+    run_dir = os.path.join(cfg['save_dir'], run)
+    meta_mode = cfg['num_meta_processes_per_gpu'] != 0
+    world_env, rank_env = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0))
+    # configs[4]: the validation process runs beside the meta ranks.  It is started first, while this process has not
+    # touched the GPU yet; by default it shares the last GPU of the node with that rank's meta process.
+    eval_proc = None
+    has_eval = cfg['eval_datasets'] and any(d.get('eval') for d in cfg['datasets'].values())
+    if meta_mode and has_eval and rank_env == 0 and eval_cmd is not False:      # eval_cmd=False: no validation process
+        n_local = int(os.environ.get('LOCAL_WORLD_SIZE', world_env))
+        eval_dev = device or (f'cuda:{cfg["num_eval_gpus"] - 1}' if cfg['num_eval_gpus'] else f'cuda:{max(n_local - 1, 0)}')
+        eval_proc = _start_eval_process(cfg, run_dir, eval_dev, data_root, height, width, num_frames, eval_cmd)
+
+    dist, rank, world, local = _dist()
+    dev = device or f'cuda:{local}'
     ck_last = checkpoint_names(cfg['save_dir'], run)['last']
 
     pm = dict(cfg['parent_model'])
     model, _ = init_parent_model(**pm)
     model.to(dev)
+    model.max_batch = max(model.max_batch, *cfg['data_cfg']['batch_sizes'].values())
     model.load_state_dict(synthetic.synthetic_state(pm['encoder']))       # no pretrained weights offline
+    set_random_seeds(cfg['seed'])      # every rank draws the SAME initial lrs (the reference builds them once, in main)
     meta_optim = MetaOptimizer(model, **cfg['meta_optim_cfg'])
     meta_iter = 0
     if cfg['meta_optim_model_file']:
@@ -64,25 +121,40 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2):
         meta_optim.load_state_dict(sd)
         meta_iter = info['meta_iter'] or 0
 
-    if cfg['num_meta_processes_per_gpu'] == 0:                              # EVAL modus
-        frames, gt = synthetic.synthetic_frames(1, height, width, seed=cfg['seed'], second_object=True)
-        seq = torch.cat([torch.roll(frames, shifts=4 * i, dims=3) for i in range(num_frames)]).to(dev)
-        objs = [(gt[0] * (torch.arange(height).view(-1, 1) < height // 2)).float(),
-                (gt[0] * (torch.arange(height).view(-1, 1) >= height // 2)).float()]
+    if not meta_mode:                                                       # EVAL modus (train_meta.py:148-153)
+        results = {}
         t0 = time.time()
-        labels, _, hist = evaluate_sequence(model, meta_optim, meta_optim.state_dict(), seq, objs, cfg)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
+        readers = {}
+        for key, ds in cfg['datasets'].items():
+            if cfg['eval_datasets'] and ds.get('eval') and not isinstance(ds['name'], list) and ds.get('split') and \
+                    os.path.isdir(os.path.join(data_root, ds['name'])):
+                dc = cfg['data_cfg']
+                readers[key] = data_mod.open_dataset(ds['name'], ds['split'], data_root, multi_object=dc['multi_object'],
+                                                     normalize=dc['normalize'], full_resolution=dc['full_resolution'])
+        data_tag = 'files' if readers else 'synthetic'
+        if not readers:
+            cfg['datasets']['val'] = dict(cfg['datasets'].get('val', {}), name='synthetic', split='val', eval=True)
+            readers['val'] = data_mod.SyntheticSequences(1, num_frames, height, width, seed=cfg['seed'])
+        for key, reader in readers.items():
+            results[key] = evaluate_dataset(model, meta_optim, meta_optim.state_dict(), reader, cfg, key, save_dir=run_dir,
+                                            meta_iter=meta_iter, meta_epoch=0, dist=dist if world > 1 else None, device=dev)
+        if dev.startswith('cuda'):
+            torch.cuda.synchronize()
         if rank == 0:
-            print(json.dumps({'mode': 'eval', 'data': 'synthetic', 'frames': num_frames, 'objects': len(objs),
-                              'seconds_per_frame': dt / num_frames, 'final_train_loss': [h[0][-1] for h in hist],
-                              'labels_present': sorted(int(v) for v in labels.unique().tolist())}))
-        return labels
+            print(json.dumps({'mode': 'eval', 'data': data_tag, 'seconds': time.time() - t0,
+                              'datasets': {k: {'mean_J': r['mean_J'], 'J_seq': r['J_seq'], 'time_per_frame': r['time_per_frame'],
+                                               'labels_present': sorted({int(v) for l in r['labels'].values() for v in l.unique().tolist()})}
+                                           for k, r in results.items()}}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return results
 
     # meta-training: tasks sharded over ranks, all-reduce + fused RAdam
+    if cfg['meta_batch_size'] % world:
+        raise ValueError('meta_batch_size must be a multiple of the number of ranks (train_meta.py:150)')
+    sub = cfg['meta_batch_size'] // world
     oc = cfg['meta_optim_optim_cfg']
-    x0, _ = synthetic.synthetic_frames(1, height, width, seed=1)
-    eng = model._ensure_engine(height, width, cfg['data_cfg']['batch_sizes']['train'])
+    eng = model._ensure_engine(height, width, max(cfg['data_cfg']['batch_sizes'].values()))
     mt = MetaTrainer(eng, dist=dist, meta_batch_size=cfg['meta_batch_size'], model_init_lr=oc['model_init_lr'],
                      log_init_lr_lr=oc['log_init_lr_lr'], model_init_weight_decay=oc['model_init_weight_decay'],
                      grad_clip=oc['grad_clip'], max_lr=cfg['meta_optim_cfg']['max_lr'],
@@ -90,19 +162,41 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2):
                      use_log_init_lr=cfg['meta_optim_cfg']['use_log_init_lr'], loss_func=cfg['loss_func'],
                      learn_model_init=cfg['meta_optim_cfg']['learn_model_init'], freeze_encoder=oc['freeze_encoder'])
     mt.load_state(model.state_dict(), [p.data for n, p in meta_optim.named_parameters() if n.startswith('log_init_lr')])
+    if dist is not None:               # one learned state everywhere (the reference workers read main's shared tensors)
+        dist.broadcast(mt.state, src=0)
+        mt._push_state()
+    set_random_seeds(cfg['seed'] + rank)                                    # meta_run.py:30
+    tasksets = _train_tasksets(cfg, data_root)
+    order, epoch = [], 0
     for it in range(num_meta_iters):
         tasks = []
-        for t in shard_tasks(cfg['meta_batch_size'], rank, world):
-            x, y = synthetic.synthetic_frames(1, height, width, seed=1000 + t + cfg['meta_batch_size'] * (meta_iter + it))
-            xg, yg = x.to(dev), y.to(dev)
-            tasks.append((xg, yg, torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()))
+        if tasksets is not None:
+            if not order:                                                   # one worker's shuffled DataLoader, meta_run.py:76-85
+                order = task_order(len(tasksets), sub, cfg['seed'] + rank, epoch)
+                epoch += 1
+            for idx in order.pop(0):
+                ts, i = tasksets.locate(idx)
+                tasks.append(ts.task_tensors(ts[i], eng, dev))
+        else:
+            for t in range(rank, cfg['meta_batch_size'], world):           # synthetic: task t of the meta-batch
+                x, y = synthetic.synthetic_frames(1, height, width, seed=1000 + t + cfg['meta_batch_size'] * (meta_iter + it))
+                xg, yg = x.to(dev), y.to(dev)
+                tasks.append((xg, yg, torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()))
         losses = mt.meta_iteration(tasks, inner_steps=cfg['num_epochs']['train'], bptt_epochs=cfg['bptt_epochs'],
                                    multi_step_bptt_loss=cfg['multi_step_bptt_loss'] or None)
+        done = meta_iter + it + 1
         if rank == 0:
-            print(json.dumps({'mode': 'meta', 'meta_iter': meta_iter + it + 1, 'meta_losses': losses,
-                              'skipped_tasks': mt.skipped_tasks}))
-            if (meta_iter + it + 1) % cfg['vis_interval'] == 0 or it == num_meta_iters - 1:
-                save_meta_checkpoint(ck_last, mt.state_dict(), meta_iter + it + 1, 0)
+            print(json.dumps({'mode': 'meta', 'data': 'files' if tasksets is not None else 'synthetic', 'meta_iter': done,
+                              'meta_losses': losses, 'skipped_tasks': mt.skipped_tasks}))
+            if done % cfg['vis_interval'] == 0 or it == num_meta_iters - 1:
+                save_meta_checkpoint(ck_last, mt.state_dict(), done, 0)
+                if eval_proc is not None:                                   # snapshot for the validation process (atomic)
+                    tmp = os.path.join(run_dir, 'eval_snapshot.tmp')
+                    save_meta_checkpoint(tmp, mt.state_dict(), done, 0)
+                    os.replace(tmp, os.path.join(run_dir, 'eval_snapshot.model'))
+    if eval_proc is not None:
+        open(os.path.join(run_dir, 'eval_stop'), 'w').close()
+        eval_proc.wait()
     if dist is not None:
         dist.destroy_process_group()
     return mt

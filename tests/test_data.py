@@ -60,3 +60,77 @@ def test_jaccard():
     assert jaccard(a, b) == pytest.approx(4 / 12)
     labels = np.zeros((4, 4, 4), np.uint8); labels[:, :2] = 1
     assert sequence_J(labels, labels, 1) == 1.0
+
+
+@pytest.fixture()
+def youtube_root(tmp_path):
+    """YouTube-VOS layout: root/train/{JPEGImages,Annotations}/<seq>/, root/train/meta.json, root/train_seqs.txt; object ids
+    are not 1..n and the second object of 'b01' first appears in frame 2."""
+    import json
+    root = tmp_path / 'YouTube-VOS'
+    rng = np.random.default_rng(1)
+    meta = {'videos': {}}
+    for seq, objs in (('a00', {'3': [0, 1, 2, 3, 4]}), ('b01', {'1': [0, 1, 2, 3, 4], '4': [2, 3, 4]})):
+        (root / 'train' / 'JPEGImages' / seq).mkdir(parents=True)
+        (root / 'train' / 'Annotations' / seq).mkdir(parents=True)
+        for f in range(5):
+            Image.fromarray(rng.integers(0, 256, (40, 64, 3), dtype=np.uint8)).save(root / 'train' / 'JPEGImages' / seq / f'{5 * f:05d}.jpg')
+            lab = np.zeros((40, 64), np.uint8)
+            for k, frames in objs.items():
+                if f in frames:
+                    o = int(k)
+                    lab[4 * o:4 * o + 8, 6 * o + f:6 * o + 12 + f] = o
+            Image.fromarray(lab, mode='L').save(root / 'train' / 'Annotations' / seq / f'{5 * f:05d}.png')
+        meta['videos'][seq] = {'objects': {k: {'category': 'x', 'frames': [f'{5 * f:05d}' for f in v]} for k, v in objs.items()}}
+    (root / 'train' / 'meta.json').write_text(json.dumps(meta))
+    (root / 'train_seqs.txt').write_text('a00\nb01\n')
+    return str(tmp_path)
+
+
+def test_youtube_reader_and_meta_taskset(youtube_root):
+    import random
+    from eosvos_amd import config as config_mod
+    from eosvos_amd.data import YouTube, open_dataset
+    from eosvos_amd.meta_tasksets import ColorJitterParams, ConcatTaskset, MetaTaskset, task_order
+    ds = open_dataset('YouTube-VOS', 'train_seqs', youtube_root, multi_object='single_id')
+    assert isinstance(ds, YouTube) and ds.seqs_names == ['a00', 'b01'] and not ds.test_mode and not ds.all_frames
+    ds.set_seq('b01')
+    assert ds.num_objects == 2 and ds._multi_object_id_to_label == [1, 4] and ds.num_object_groups == 2
+    assert ds.get_gt_frame_id(0) == (0, 0) and ds.get_gt_frame_id(1) == (2, 2)      # object 4 first annotated in frame 2
+    ds.multi_object_id = 1
+    ds.set_gt_frame_id()
+    assert (ds.frame_id, ds._label_id) == (2, 2)
+    ds._label_id = None
+    assert ds.make_img_label_pair(0)[1].sum() == 0 and ds.make_img_label_pair(3)[1].sum() == 8 * 12   # id 4 -> binary mask
+    assert not ds.has_frame_object(0) and ds.has_frame_object(3)
+    cfg = config_mod.parse_cli(['with', 'YouTube-VOS'])
+    ts = MetaTaskset(ds, cfg['data_cfg'], random_frame_transform_per_task=True, single_obj_seq_mode='KEEP')
+    assert ts.object_groups == [('a00', 0), ('b01', 0), ('b01', 1)]
+    assert MetaTaskset(ds, cfg['data_cfg'], single_obj_seq_mode='IGNORE').object_groups == [('b01', 0), ('b01', 1)]
+    torch.manual_seed(3)
+    random.seed(3)
+    for _ in range(6):
+        item = ts[2]                                        # object 4 of b01: only frames 2..4 carry it
+        assert item['seq_name'] == 'b01' and item['obj_id'] == 1 and item['train_frame'] in (2, 3, 4)
+        assert all(f in (2, 3, 4) for f in item['meta_frames']) and len(item['meta_frames']) == 1
+        tr = item['transform']
+        assert isinstance(tr['flip'], bool) and sorted(n for n, _ in tr['color'].ops) == ['brightness', 'contrast', 'hue', 'saturation']
+    ts_eps = MetaTaskset(ds, cfg['data_cfg'], random_frame_transform_per_task=False, random_frame_epsilon=5)
+    for _ in range(6):
+        item = ts_eps[0]
+        assert abs(item['meta_frames'][0] - item['train_frame']) <= 1 and item['transform'] is None    # 5-frame stride
+    with pytest.raises(NotImplementedError):
+        MetaTaskset(ds, cfg['data_cfg'], random_box_coord_perm=True)
+    # colour jitter: factors within the torchvision ranges, image stays in [0, 1]
+    cj = ColorJitterParams(.2, .2, .2, .1, rng=random.Random(0))
+    img = np.random.default_rng(0).random((8, 8, 3)).astype(np.float32)
+    out = cj(img)
+    assert out.shape == img.shape and 0.0 <= out.min() and out.max() <= 1.0 and np.abs(out - img).max() < 0.5
+    for name, f in cj.ops:
+        assert (-0.1 <= f <= 0.1) if name == 'hue' else (0.8 <= f <= 1.2)
+    # a worker's shuffled sub-batches cover every task once per pass
+    both = ConcatTaskset([ts, ts_eps])
+    assert len(both) == 6 and both.locate(4) == (ts_eps, 1)
+    order = task_order(len(both), 4, seed=5, epoch=0)
+    assert sorted(i for b in order for i in b) == list(range(6)) and [len(b) for b in order] == [4, 2]
+    assert order != task_order(len(both), 4, seed=6, epoch=0)

@@ -181,10 +181,18 @@ def test_online_adaptation_sequence(model_and_optim):
 def test_train_meta_entry_points(tmp_path):
     from eosvos_amd import train_meta
     from eosvos_amd.checkpoint import load_meta_checkpoint
-    labels = train_meta.main(['with', 'DAVIS-2017', 'e-OSVOS', 'num_epochs.eval=2'], height=96, width=160, num_frames=3)
-    assert labels.shape == (3, 96, 160)
+    res = train_meta.main(['with', 'DAVIS-2017', 'e-OSVOS', 'num_epochs.eval=2', f'save_dir={tmp_path}', 'env_suffix=e'],
+                          height=96, width=160, num_frames=3, data_root=str(tmp_path / 'no_data'))
+    labels = res['val']['labels']['synthetic00']
+    assert labels.shape == (3, 96, 160) and set(labels.unique().tolist()) <= {0, 1, 2}
+    # prediction PNGs and eval checkpoints of the eval worker (evaluate.py:332-382)
+    assert os.path.exists(os.path.join(str(tmp_path), 'e', 'best_eval_preds', 'synthetic', 'val', 'synthetic00', '00002.png'))
+    assert os.path.exists(os.path.join(str(tmp_path), 'e', 'last_val_meta_iter.model'))
+    # the validation child process is exercised on CPU (tests/test_multiprocess.py) and by tools/concurrent_eval_smoke.py;
+    # here the pytest process has already initialised the GPU, so none is spawned from it
     mt = train_meta.main(['with', 'YouTube-VOS', 'meta_batch_size=2', 'num_epochs.train=2', f'save_dir={tmp_path}',
-                          'env_suffix=t'], height=96, width=160, num_meta_iters=1)
+                          'env_suffix=t'], height=96, width=160, num_meta_iters=1, data_root=str(tmp_path / 'no_data'),
+                         eval_cmd=False)
     sd, info = load_meta_checkpoint(os.path.join(str(tmp_path), 't', 'last_meta_iter.model'))
     assert info['meta_iter'] == 1 and len(sd) == 128
     assert list(sd)[0] == 'log_init_lr_backbone-conv1-weight' and list(sd)[64] == 'model_init_backbone-conv1-weight'

@@ -1,0 +1,83 @@
+"""The N > 1 paths on CPU (gloo, world_size 2) with the stand-in engine of tests/fake_engine.py, so that the first real
+multi-GPU run is not the first execution of this host code:
+  * `train_meta.main` in meta-train mode: tasks sharded over the ranks, one all-reduce per meta-iteration, identical
+    RAdam state on every rank, `last_meta_iter.model`, and the concurrent validation CHILD PROCESS
+    (`eval_worker`, BASELINE configs[4]) reading the checkpoint snapshots;
+  * `bench.py`'s control flow for both metrics under torch.distributed;
+  * `evaluate_dataset` with the (sequence, object) work items dealt over the ranks == the single-process result.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+W = os.path.join(HERE, 'mp_workers')
+
+
+def launch(script, args, world, port, timeout=900):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='2', WORLD_SIZE=str(world),
+               LOCAL_WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(W, script)] + args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=timeout) == 0
+
+
+def test_train_meta_two_ranks_with_concurrent_eval_process(tmp_path):
+    out, save_dir = str(tmp_path / 'res'), str(tmp_path / 'models')
+    launch('train_meta_worker.py', [out, save_dir], 2, 29541)
+    r0, r1 = (torch.load(f'{out}.{r}', weights_only=False) for r in (0, 1))
+    assert r0['step'] == r1['step'] == 2
+    assert torch.equal(r0['state'], r1['state'])                       # all-reduce + identical outer step, no broadcast
+    run = os.path.join(save_dir, 'mp')
+    ck = torch.load(os.path.join(run, 'last_meta_iter.model'), weights_only=False)
+    assert ck['meta_iter'] == 2 and len(ck['meta_optim_state_dict']) == 128
+    # the validation process evaluated at least the final snapshot and wrote the reference's files
+    lines = [json.loads(l) for l in open(os.path.join(run, 'eval_log.jsonl'))]
+    assert lines and lines[-1]['meta_iter'] == 2 and lines[-1]['dataset'] == 'val_davis17'
+    assert os.path.exists(os.path.join(run, 'last_val_davis17_meta_iter.model'))
+    # (best_* is only written when mean J improves on the best so far, evaluate.py:370; the stand-in network scores J = 0)
+    assert (lines[-1]['mean_J'] > 0) == os.path.exists(os.path.join(run, 'best_val_davis17_meta_iter.model'))
+    assert os.path.exists(os.path.join(run, 'best_eval_preds', 'DAVIS-2017', 'val_seqs', 'synthetic00', '00003.png'))
+    # a single process computes the same update (sharding + sum == serial accumulation, up to fp32 summation order)
+    out1 = str(tmp_path / 'res1')
+    env = dict(os.environ, OMP_NUM_THREADS='2', WORLD_SIZE='1', RANK='0')
+    env.pop('MASTER_ADDR', None)
+    p = subprocess.Popen([sys.executable, os.path.join(W, 'train_meta_worker.py'), out1, str(tmp_path / 'models1')], env=env)
+    assert p.wait(timeout=900) == 0
+    s1 = torch.load(f'{out1}.0', weights_only=False)['state']
+    assert torch.allclose(s1, r0['state'], rtol=1e-5, atol=1e-8)
+    assert float((s1 - r0['state']).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('metric', ['meta', 'finetune'])
+def test_bench_control_flow_two_ranks(tmp_path, metric):
+    out = str(tmp_path / 'bench')
+    launch('bench_worker.py', [out, metric], 2, 29543 if metric == 'meta' else 29545)
+    line = json.loads(open(f'{out}.0').read().strip().splitlines()[-1])
+    assert open(f'{out}.1').read().strip() == ''                        # rank 0 prints the ONE line
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1 and line['scaling'] == 'weak'
+    assert line['metric'] == ('meta_tasks_per_sec' if metric == 'meta' else 'finetune_iters_per_sec')
+    assert line['value'] > 0 and abs(line['value'] - 2 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+    assert line['roofline']['kernel'] == 'stand_in_kernel' and line['cpu_baseline'] is None and line['vs_baseline'] is None
+    if metric == 'finetune':
+        assert line['extra']['meta_tasks_per_sec'] > 0
+
+
+def test_evaluation_sharded_over_ranks_equals_single_process(tmp_path):
+    out2, out1 = str(tmp_path / 'e2'), str(tmp_path / 'e1')
+    launch('eval_shard_worker.py', [out2, str(tmp_path / 's2')], 2, 29547)
+    env = dict(os.environ, OMP_NUM_THREADS='2', WORLD_SIZE='1', RANK='0')
+    assert subprocess.Popen([sys.executable, os.path.join(W, 'eval_shard_worker.py'), out1, str(tmp_path / 's1')],
+                            env=env).wait(timeout=900) == 0
+    a, b, one = (torch.load(p, weights_only=False) for p in (f'{out2}.0', f'{out2}.1', f'{out1}.0'))
+    # three (sequence, object) items dealt round-robin: rank 0 takes items 0 and 2, rank 1 item 1
+    assert a['items'] == [('bear', 0), ('cows', 0)] and b['items'] == [('bear', 1)]
+    for seq in one['labels']:
+        assert torch.equal(a['labels'][seq], one['labels'][seq]) and torch.equal(b['labels'][seq], one['labels'][seq])
+    assert a['J_seq'] == one['J_seq']
+    assert os.path.exists(os.path.join(str(tmp_path / 's2'), 'best_eval_preds', 'DAVIS-2017', 'val_seqs', 'bear', '00000.png'))
