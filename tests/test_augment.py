@@ -146,3 +146,47 @@ def test_first_frame_augmenter_matches_reference_sequence():
     loss = eng.finetune_step(images, labels)
     assert math.isfinite(loss)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_meta_taskset_materialises_tasks_on_the_device(tmp_path):
+    """`MetaTaskset.task_tensors`: train frame x batch + meta frames in HBM, ONE flip / scale-rotate per task applied to
+    frames (bicubic) and labels (nearest) alike (`meta_tasksets.py:111-137`, deterministic transforms)."""
+    import random
+    import numpy as np
+    from PIL import Image
+    from eosvos_amd import config as config_mod
+    from eosvos_amd.data import DAVIS
+    from eosvos_amd.engine import Engine
+    from eosvos_amd.meta_tasksets import MetaTaskset
+    root = tmp_path / 'DAVIS-2017'
+    rng = np.random.default_rng(0)
+    (root / 'JPEGImages' / '480p' / 'bear').mkdir(parents=True)
+    (root / 'Annotations' / '480p' / 'bear').mkdir(parents=True)
+    for f in range(4):
+        Image.fromarray(rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)).save(root / 'JPEGImages' / '480p' / 'bear' / f'{f:05d}.jpg')
+        lab = np.zeros((96, 160), np.uint8)
+        lab[30:60, 50 + f:100 + f] = 1
+        Image.fromarray(lab, mode='L').save(root / 'Annotations' / '480p' / 'bear' / f'{f:05d}.png')
+    (root / 'train_seqs.txt').write_text('bear\n')
+    ds = DAVIS('train_seqs', str(root), multi_object='single_id')
+    cfg = config_mod.parse_cli(['with', 'DAVIS-2017'])
+    eng = Engine('resnet50', 96, 160, max_batch=1, device='cuda:0')
+    ts = MetaTaskset(ds, cfg['data_cfg'], random_frame_transform_per_task=True)
+    torch.manual_seed(0)
+    random.seed(0)
+    item = ts[0]
+    xt, yt, xm, ym = ts.task_tensors(item, eng, 'cuda:0')
+    assert xt.shape == (1, 3, 96, 160) and yt.shape == (1, 1, 96, 160) and xm.shape == (1, 3, 96, 160) and xt.is_cuda
+    assert set(yt.unique().tolist()) <= {0.0, 1.0} and 0 < float(yt.sum()) < yt.numel()          # the object survives the warp
+    assert 0 < float(ym.sum()) < ym.numel() and float(xt.min()) >= -0.2 and float(xt.max()) <= 1.2
+    tr = item['transform']
+    assert item['train_frame'] in tr['rot_sc'] and all(0.75 <= sc <= 1.25 and -30 <= rot <= 30 for rot, sc in tr['rot_sc'].values())
+    # without the per-task transform the tensors are the decoded frame / mask themselves
+    ts0 = MetaTaskset(ds, cfg['data_cfg'], random_frame_transform_per_task=False)
+    it0 = ts0[0]
+    x0, y0, _, _ = ts0.task_tensors(it0, eng, 'cuda:0')
+    ds.multi_object_id = 0
+    img, lab = ds.make_img_label_pair(it0['train_frame'])
+    assert torch.equal(x0[0].cpu(), torch.from_numpy(img.transpose(2, 0, 1))) and torch.equal(y0[0, 0].cpu(), torch.from_numpy(lab))
+    eng.close()
