@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -25,6 +26,8 @@ __device__ __forceinline__ unsigned pack_hi(float e0, float e1) {      // (bf16 
 }
 __device__ __forceinline__ float trunc_bf16(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 
+__device__ const unsigned short* g_Bsplit;
+__device__ const unsigned short* g_Asplit;      // VAR 4: B pre-split into 3 bf16 planes [3][N][K]
 template <int MODE, int VAR>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ C, int M, int N, int K) {
@@ -44,12 +47,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
   const int c4 = tid & 7, row = tid >> 3;            // 8 float4 per 32-k row, 32 rows per pass
 
   float4 ra[4], rb[4];
+  uint2 rbs[4][3], ras[4][3];
+  const unsigned short* Bsp = g_Bsplit;
+  const unsigned short* Asp = g_Asplit;
   auto load = [&](int ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
-      rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      if (VAR == 5) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          ras[i][p] = *reinterpret_cast<const uint2*>(Asp + ((size_t)p * M + m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      } else {
+        ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      }
+      if (VAR >= 4) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          rbs[i][p] = *reinterpret_cast<const uint2*>(Bsp + ((size_t)p * N + n0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      } else {
+        rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      }
     }
+  };
+  auto store_presplit_a = [&](unsigned char* S) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + (p * BM + row + 32 * i) * ROWB + c4 * 8) = ras[i][p];
+  };
+  auto store_presplit = [&](unsigned char* S) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + (p * BM + row + 32 * i) * ROWB + c4 * 8) = rbs[i][p];
   };
   auto store_op = [&](unsigned char* S, const float4* rv) {
 #pragma unroll
@@ -65,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
           w.x = pack_hi(v.x, v.y);
           w.y = pack_hi(v.z, v.w);
           *reinterpret_cast<uint2*>(S + (p * BM + rr) * ROWB + c4 * 8) = w;
-          if (p + 1 < NP) {
+          if (p + 1 < NP && VAR != 6) {
             v.x -= trunc_bf16(v.x); v.y -= trunc_bf16(v.y); v.z -= trunc_bf16(v.z); v.w -= trunc_bf16(v.w);
           }
         }
@@ -102,12 +132,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
 
   const int nk = K / BK;
   load(0);
-  store_op(As, ra);
-  store_op(Bs, rb);
+  if (VAR == 5) store_presplit_a(As); else store_op(As, ra);
+  if (VAR >= 4) store_presplit(Bs); else store_op(Bs, rb);
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const bool more = ks + 1 < nk;
-    if (more) load(ks + 1);
+    if (more && VAR != 7) load(ks + 1);
+    if (VAR == 7) { for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(ra[i].x), "+v"(rb[i].x)); } }
     if (MODE == 0) {
 #pragma unroll
       for (int kk = 0; kk < BK / 8; ++kk) {
@@ -157,14 +188,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
           }
       }
     }
-    if (MODE != 0 && VAR >= 1 && more) {
+    if (MODE != 0 && (VAR == 1 || VAR == 2) && more) {
       if (VAR == 1) split_op(pa, ra);
       split_op(pb, rb);
     }
     __syncthreads();
     if (more) {
-      if (MODE != 0 && VAR >= 1) { write_op(As, pa); write_op(Bs, pb); }
-      else { store_op(As, ra); store_op(Bs, rb); }
+      if (MODE != 0 && (VAR == 1 || VAR == 2)) { write_op(As, pa); write_op(Bs, pb); }
+      else {
+        if (VAR == 5) store_presplit_a(As); else store_op(As, ra);
+        if (VAR >= 4) store_presplit(Bs); else store_op(Bs, rb);
+      }
     }
     __syncthreads();
   }
@@ -180,6 +214,228 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
       }
 }
 
+
+// Wave-specialised variant: 512 threads = 4 consumer waves (MFMA only) + 4 producer waves (global -> split -> LDS),
+// two LDS stages, one barrier per K step, one workgroup per CU.
+__global__ __launch_bounds__(512, 1) void gemm_ws_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int K) {
+  constexpr int BM = 128, BN = 128, BK = 32, NP = 3, ROWB = 80;
+  constexpr int OP_BYTES = NP * BM * ROWB, STAGE = 2 * OP_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int cw = wave & 3, wm = cw >> 1, wn = cw & 1, r = lane & 31, h = lane >> 5;
+  const int nt = N / BN;
+  const int ptid = tid & 255;
+  const int c4 = ptid & 7, row = (((ptid >> 6) << 3) + (((lane >> 3) & 1) << 2) + (lane >> 4));
+  const int nk = K / BK;
+  const int tiles = (M / BM) * nt;
+  f32x16 acc[2][2];
+  float4 ra[4], rb[4];
+  for (int tile = xcd_remap(blockIdx.x, gridDim.x); tile < tiles; tile += gridDim.x) {
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    auto load = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+        rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      }
+    };
+    auto store = [&](int buf) {
+      unsigned char* As = smem + buf * STAGE;
+      unsigned char* Bs = As + OP_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 v = ra[i], w = rb[i];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          uint2 a2, b2;
+          a2.x = pack_hi(v.x, v.y); a2.y = pack_hi(v.z, v.w);
+          b2.x = pack_hi(w.x, w.y); b2.y = pack_hi(w.z, w.w);
+          *reinterpret_cast<uint2*>(As + (p * BM + row + 32 * i) * ROWB + c4 * 8) = a2;
+          *reinterpret_cast<uint2*>(Bs + (p * BM + row + 32 * i) * ROWB + c4 * 8) = b2;
+          if (p + 1 < NP) {
+            v.x -= trunc_bf16(v.x); v.y -= trunc_bf16(v.y); v.z -= trunc_bf16(v.z); v.w -= trunc_bf16(v.w);
+            w.x -= trunc_bf16(w.x); w.y -= trunc_bf16(w.y); w.z -= trunc_bf16(w.z); w.w -= trunc_bf16(w.w);
+          }
+        }
+      }
+    };
+    if (!producer) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    if (producer) {
+      load(0);
+      store(0);
+      if (nk > 1) load(1);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+      const int buf = ks & 1;
+      if (producer) {
+        if (ks + 1 < nk) {
+          store(buf ^ 1);
+          if (ks + 2 < nk) load(ks + 2);
+        }
+      } else {
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + OP_BYTES;
+#pragma unroll
+        for (int g = 0; g < BK / 16; ++g) {
+          bf16x8 fa[2][NP], fb[2][NP];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              fa[t][p] = *reinterpret_cast<const bf16x8*>(As + (p * BM + wm * 64 + t * 32 + r) * ROWB + g * 32 + h * 16);
+              fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * BM + wn * 64 + t * 32 + r) * ROWB + g * 32 + h * 16);
+            }
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+              f32x16 c = acc[tm][tn];
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][2], fb[tn][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], fb[tn][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], fb[tn][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][0], c, 0, 0, 0);
+              acc[tm][tn] = c;
+            }
+        }
+      }
+      __syncthreads();
+    }
+    if (!producer) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int n = n0 + wn * 64 + tn * 32 + r;
+            C[(size_t)m * N + n] = acc[tm][tn][e];
+          }
+    }
+  }
+}
+
+// In-wave pipelined variant: 512 threads = 8 waves, every wave does BOTH jobs -- MFMAs on LDS stage `buf` interleaved with
+// the split + LDS store of the next K step into stage `buf ^ 1` -- one barrier per K step, one workgroup per CU.
+//   TILE_M = 128: waves 2(M) x 4(N), 64 x 32 each, BK = 32;   TILE_M = 256: waves 4(M) x 2(N), 64 x 64 each, BK = 16.
+template <int TILE_M>
+__global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                           float* __restrict__ C, int M, int N, int K) {
+  constexpr int BM = TILE_M, BN = 128, BK = TILE_M == 128 ? 32 : 16, NP = 3, ROWB = BK * 2 + 16;
+  constexpr int A_BYTES = NP * BM * ROWB, B_BYTES = NP * BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int TN = TILE_M == 128 ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = TILE_M == 128 ? wave >> 2 : wave >> 1, wn = TILE_M == 128 ? wave & 3 : wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int nt = N / BN, tiles = (M / BM) * nt, nk = K / BK;
+  // staging: rows of BK floats = BK/4 float4 per row
+  constexpr int F4R = BK / 4, ROWS_PP = 512 / F4R;          // float4 per row, rows per pass
+  constexpr int APASS = BM / ROWS_PP, BPASS = BN / ROWS_PP;
+  const int c4 = tid % F4R, row = tid / F4R;
+  f32x16 acc[2][TN];
+  float4 ra[APASS], rb[BPASS];
+  for (int tile = xcd_remap(blockIdx.x, gridDim.x); tile < tiles; tile += gridDim.x) {
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    auto load = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + ROWS_PP * i) * K + ks * BK + c4 * 4);
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + ROWS_PP * i) * K + ks * BK + c4 * 4);
+    };
+    auto put = [&](unsigned char* S, int rows, int rr, float4 v) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        uint2 w;
+        w.x = pack_hi(v.x, v.y); w.y = pack_hi(v.z, v.w);
+        *reinterpret_cast<uint2*>(S + (p * rows + rr) * ROWB + c4 * 8) = w;
+        if (p + 1 < NP) { v.x -= trunc_bf16(v.x); v.y -= trunc_bf16(v.y); v.z -= trunc_bf16(v.z); v.w -= trunc_bf16(v.w); }
+      }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) put(smem + buf * STAGE, BM, row + ROWS_PP * i, ra[i]);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) put(smem + buf * STAGE + A_BYTES, BN, row + ROWS_PP * i, rb[i]);
+    };
+    auto mma = [&](int buf, int g) {
+      const unsigned char* As = smem + buf * STAGE;
+      const unsigned char* Bs = As + A_BYTES;
+      bf16x8 fa[2][NP], fb[TN][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[t][p] = *reinterpret_cast<const bf16x8*>(As + (p * BM + wm * 64 + t * 32 + r) * ROWB + g * 32 + h * 16);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * BN + wn * 32 * TN + t * 32 + r) * ROWB + g * 32 + h * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          f32x16 c = acc[tm][tn];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][2], fb[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], fb[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], fb[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][0], c, 0, 0, 0);
+          acc[tm][tn] = c;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    load(0);
+    store_a(0); store_b(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+      const int buf = ks & 1;
+      const bool more = ks + 1 < nk;
+      if (BK == 32) {
+        mma(buf, 0);
+        if (more) store_a(buf ^ 1);
+        mma(buf, 1);
+        if (more) store_b(buf ^ 1);
+      } else {
+        mma(buf, 0);
+        if (more) { store_a(buf ^ 1); store_b(buf ^ 1); }
+      }
+      if (ks + 2 < nk) load(ks + 2);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int n = n0 + wn * 32 * TN + tn * 32 + r;
+          C[(size_t)m * N + n] = acc[tm][tn][e];
+        }
+    __syncthreads();
+  }
+}
+
 template <int MODE, int VAR>
 static void run(const char* name, const float* dA, const float* dB, float* dC, int M, int N, int K, const std::vector<float>& hA,
                 const std::vector<float>& hB) {
@@ -187,11 +443,17 @@ static void run(const char* name, const float* dA, const float* dB, float* dC, i
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_kernel<MODE, VAR>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K);
+  auto go = [&]() {
+    if (VAR == 9) hipLaunchKernelGGL(gemm_ws_kernel, dim3(tiles < 256 ? tiles : 256), dim3(512), 0, 0, dA, dB, dC, M, N, K);
+    else if (VAR == 10) hipLaunchKernelGGL((gemm_pipe_kernel<128>), dim3(tiles < 256 ? tiles : 256), dim3(512), 0, 0, dA, dB, dC, M, N, K);
+    else if (VAR == 11) hipLaunchKernelGGL((gemm_pipe_kernel<256>), dim3(tiles / 2 < 256 ? tiles / 2 : 256), dim3(512), 0, 0, dA, dB, dC, M, N, K);
+    else hipLaunchKernelGGL((gemm_kernel<MODE, VAR >= 9 ? 0 : VAR>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K);
+  };
+  for (int i = 0; i < 2; ++i) go();
   CK(hipDeviceSynchronize());
   const int reps = 10;
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_kernel<MODE, VAR>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K);
+  for (int i = 0; i < reps; ++i) go();
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -235,8 +497,35 @@ int main() {
     run<0, 0>("fp32 mfma", dA, dB, dC, M, N, K, hA, hB);
     run<3, 0>("bf16 x3", dA, dB, dC, M, N, K, hA, hB);
     run<6, 0>("bf16 x6 v0", dA, dB, dC, M, N, K, hA, hB);
-    run<6, 1>("bf16 x6 v1", dA, dB, dC, M, N, K, hA, hB);
-    run<6, 2>("bf16 x6 v2", dA, dB, dC, M, N, K, hA, hB);
+    run<6, 9>("bf16 x6 ws", dA, dB, dC, M, N, K, hA, hB);
+    run<6, 10>("x6 pipe 128x128", dA, dB, dC, M, N, K, hA, hB);
+    run<6, 11>("x6 pipe 256x128", dA, dB, dC, M, N, K, hA, hB);
+    {
+      auto mk = [&](const std::vector<float>& h, size_t n) {
+        std::vector<unsigned short> sp(3 * n);
+        for (size_t i = 0; i < n; ++i) {
+          float v = h[i];
+          for (int p = 0; p < 3; ++p) {
+            unsigned u; memcpy(&u, &v, 4); u &= 0xffff0000u;
+            sp[(size_t)p * n + i] = (unsigned short)(u >> 16);
+            float t; memcpy(&t, &u, 4); v -= t;
+          }
+        }
+        unsigned short* d;
+        CK(hipMalloc(&d, sp.size() * 2));
+        CK(hipMemcpy(d, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
+        return d;
+      };
+      unsigned short* dS = mk(hB, (size_t)N * K);
+      unsigned short* dT = mk(hA, (size_t)M * K);
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_Bsplit), &dS, sizeof(dS)));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_Asplit), &dT, sizeof(dT)));
+      run<6, 6>("x6 no-resid  ", dA, dB, dC, M, N, K, hA, hB);
+      run<6, 7>("x6 no-gloads ", dA, dB, dC, M, N, K, hA, hB);
+      run<6, 4>("x6 B-presplit", dA, dB, dC, M, N, K, hA, hB);
+      run<6, 5>("x6 AB-presplt", dA, dB, dC, M, N, K, hA, hB);
+      CK(hipFree(dS)); CK(hipFree(dT));
+    }
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
   }
   return 0;
