@@ -153,18 +153,38 @@ def timed(fn, steps, barrier, dist, dev):
     return dt
 
 
-def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version):
-    """meta-tasks/s: every rank runs one task (5 inner steps at batch 1 + the meta frame) per meta-iteration, then
-    ONE all-reduce of the 161 MB meta-gradient and the fused RAdam step + lr clamp on every rank."""
+def meta_setup(eng, dist, world, rank, sd, lrs, dev, tasks_per_rank, engine_factory):
+    """MetaTrainer with `tasks_per_rank` tasks per meta-iteration on this GPU, in flight together on as many engines (each
+    on its own stream), and the step function of one meta-iteration."""
+    from eosvos_amd import synthetic
     from eosvos_amd.meta_run import MetaTrainer
-    mt = MetaTrainer(eng, dist=dist, meta_batch_size=world)
+    extra = []
+    for _ in range(tasks_per_rank - 1):
+        if torch.cuda.is_available():
+            with torch.cuda.stream(torch.cuda.Stream()):
+                extra.append(engine_factory('resnet50', H, W, max_batch=1, device=dev))
+        else:
+            extra.append(engine_factory('resnet50', H, W, max_batch=1, device=dev))
+    mt = MetaTrainer(eng, dist=dist, meta_batch_size=world * tasks_per_rank, extra_engines=extra)
     mt.load_state(sd, lrs)
-    x1, y1 = xg[:1].contiguous(), yg[:1].contiguous()
-    xm, ym = torch.flip(x1, dims=[3]).contiguous(), torch.flip(y1, dims=[3]).contiguous()
+    tasks = []
+    for t in range(tasks_per_rank):
+        x, y = synthetic.synthetic_frames(1, H, W, seed=1000 + rank * tasks_per_rank + t)
+        x, y = x.to(dev), y.to(dev)
+        tasks.append((x, y, torch.flip(x, dims=[3]).contiguous(), torch.flip(y, dims=[3]).contiguous()))
     losses = []
 
     def step():
-        losses[:] = mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
+        losses[:] = mt.meta_iteration(tasks, inner_steps=5)
+    return mt, step, losses, extra
+
+
+def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version, engine_factory):
+    """meta-tasks/s: every rank runs `--tasks-per-rank` tasks (5 inner steps at batch 1 + the meta frame each) per
+    meta-iteration, in flight together on one engine each, then ONE all-reduce of the 161 MB meta-gradient and the fused
+    RAdam step + lr clamp on every rank."""
+    tpr = a.tasks_per_rank
+    mt, step, losses, extra = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory)
     for _ in range(a.warmup):
         step()
     dt = timed(step, a.steps, barrier, dist, dev)
@@ -174,15 +194,18 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, m
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_meta(sd, lrs, x[:1], y[:1], torch.flip(x[:1], dims=[3]), torch.flip(y[:1], dims=[3]))
+    for e in extra:
+        e.close()
     if rank == 0:
         out = {
-            'metric': 'meta_tasks_per_sec', 'value': world * a.steps / dt, 'unit': 'meta_tasks/s', 'n_gpus': world,
+            'metric': 'meta_tasks_per_sec', 'value': world * tpr * a.steps / dt, 'unit': 'meta_tasks/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'meta-train iteration (BASELINE configs[3..4]): meta_batch_size = number of ranks, one '
-                                   f'task per rank = 5 inner fine-tune steps + 1 meta frame at batch 1, {H}x{W}, BCE; one '
-                                   'all-reduce(sum) of the 40.3 M-float meta-gradient, RAdam + lr clamp on every rank',
-                       'meta_batch_size': world, 'inner_steps': 5, 'height': H, 'width': W,
+            'config': {'workload': f'meta-train iteration (BASELINE configs[3..4]): meta_batch_size = {tpr} x ranks, {tpr} tasks per '
+                                   f'rank in flight together (one engine each), a task = 5 inner fine-tune steps + 1 meta frame at '
+                                   f'batch 1, {H}x{W}, BCE; one all-reduce(sum) of the 40.3 M-float meta-gradient, RAdam + lr clamp '
+                                   'on every rank',
+                       'meta_batch_size': world * tpr, 'tasks_per_rank': tpr, 'inner_steps': 5, 'height': H, 'width': W,
                        'parallelism': f'tasks sharded x{world}'},
             'roofline': roof, 'cpu_baseline': cpu,
             'extra': {'last_meta_loss': losses[-1], 'matrix_mode': mode, 'lib_version': lib_version},
@@ -204,6 +227,9 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meta', action='store_true')
     ap.add_argument('--no-ab', action='store_true', help='skip the fp32-MFMA-mode comparison in extra')
+    ap.add_argument('--tasks-per-rank', type=int, default=4,
+                    help='meta metric: tasks per GPU per meta-iteration, run concurrently on one engine each (default 4: '
+                         'measured 26.8 / 31.0 / 34.2 / 34.2 tasks/s with 1 / 3 / 4 / 6 in flight)')
     ap.add_argument('--metric', choices=['finetune', 'meta'], default='finetune',
                     help="'meta': the JSON line reports meta-tasks/s (BASELINE configs[3..4]: one task per rank per "
                          "meta-iteration, all-reduce + RAdam included); a step is then one meta-iteration")
@@ -250,7 +276,8 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
             torch.cuda.synchronize()
 
     if a.metric == 'meta':
-        return bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version)
+        return bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version,
+                          engine_factory or Engine)
 
     step = lambda: eng.finetune_step(xg, yg, sync_loss=False)
     for _ in range(a.warmup):
@@ -283,17 +310,17 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         eng.reset()
         extra['fp32_mfma_mode_ms_per_step'] = 1e3 * dt32 / min(a.steps, 30)
     if not a.no_meta:
-        # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4])
-        mt = MetaTrainer(eng, dist=dist, meta_batch_size=world)
-        mt.load_state(sd, lrs)
-        x1, y1 = xg[:1].contiguous(), yg[:1].contiguous()
-        xm, ym = torch.flip(x1, dims=[3]).contiguous(), torch.flip(y1, dims=[3]).contiguous()
-        mstep = lambda: mt.meta_iteration([(x1, y1, xm, ym)], inner_steps=5)
+        # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4]), tasks in flight together
+        tpr = a.tasks_per_rank
+        mt, mstep, _, extra_eng = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory or Engine)
         mstep()                                                             # warm-up
-        n_it = 5
+        n_it = 4
         dtm = timed(mstep, n_it, barrier, dist, dev)
-        extra['meta_tasks_per_sec'] = world * n_it / dtm
-        extra['meta_config'] = f'meta_batch_size={world}, 5 inner steps + 1 meta frame, batch 1, {H}x{W}'
+        extra['meta_tasks_per_sec'] = world * tpr * n_it / dtm
+        extra['meta_config'] = (f'meta_batch_size={world * tpr} ({tpr} tasks per GPU in flight on one engine each), 5 inner steps + '
+                                f'1 meta frame, batch 1, {H}x{W}')
+        for e in extra_eng:
+            e.close()
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

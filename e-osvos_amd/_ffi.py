@@ -33,6 +33,7 @@ _SIGNATURES = {
     'eosvos_lr_store_count': (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     'eosvos_set_lr_state': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, c_float_p]),
     'eosvos_set_loss': (ctypes.c_int, [_E, ctypes.c_int]),
+    'eosvos_last_loss': (ctypes.c_int, [_E, c_float_p]),
     'eosvos_loss_tensors': (ctypes.c_int, [_E, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int64, c_float_p]),
     'eosvos_warp_affine': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_int, c_float_p, ctypes.POINTER(ctypes.c_int)]),

@@ -1232,6 +1232,11 @@ int eosvos_loss(eosvos_engine* e, int kind, const float* masks, int batch, float
   HIPOK(hipGetLastError());
   return 0;
 }
+int eosvos_last_loss(eosvos_engine* e, float* loss_out) {
+  if (!e || !loss_out) return fail("null argument");
+  HIPOK(hipMemcpyAsync(loss_out, e->loss_dev, 4, hipMemcpyDeviceToDevice, e->s));
+  return 0;
+}
 int eosvos_set_loss(eosvos_engine* e, int kind) {
   if (!e) return fail("null engine");
   if (kind < EOSVOS_LOSS_BCE || kind > EOSVOS_LOSS_CLASS_BALANCED_BCE) return fail("unknown loss kind");

@@ -243,13 +243,20 @@ class Engine:
         _ffi.check(self.lib.eosvos_meta_task_begin(self.h))
         self.steps_since_reset, self.in_meta_task = 0, True
 
-    def meta_grad(self, images, masks, flat_meta_grad, weight=1.0, init_grad=True, new_segment=False):
+    def meta_grad(self, images, masks, flat_meta_grad, weight=1.0, init_grad=True, new_segment=False, sync=True):
         """ADDS weight * task meta-gradient into flat_meta_grad ([lr state | init]); returns the meta loss.
-        weight / init_grad / new_segment: `multi_step_bptt_loss` and truncated BPTT (include/eosvos.h)."""
+        weight / init_grad / new_segment: `multi_step_bptt_loss` and truncated BPTT (include/eosvos.h).
+        sync=False: nothing waits for the GPU; returns a device tensor holding the meta loss (concurrent tasks)."""
         b = self._check_images(images)
         assert flat_meta_grad.numel() == self.n_lr_store + self.n_param and flat_meta_grad.is_cuda
-        l = ctypes.c_float()
         flags = (1 if init_grad else 0) | (2 if new_segment else 0)
+        if not sync:
+            _ffi.check(self.lib.eosvos_meta_grad_ex(self.h, _ptr(images), _ptr(masks), b, _ptr(flat_meta_grad), None,
+                                                    float(weight), flags))
+            out = torch.empty(1, device=self.device)
+            _ffi.check(self.lib.eosvos_last_loss(self.h, _ptr(out)))
+            return out
+        l = ctypes.c_float()
         _ffi.check(self.lib.eosvos_meta_grad_ex(self.h, _ptr(images), _ptr(masks), b, _ptr(flat_meta_grad),
                                                 ctypes.byref(l), float(weight), flags))
         return l.value

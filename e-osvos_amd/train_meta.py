@@ -155,7 +155,16 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
     sub = cfg['meta_batch_size'] // world
     oc = cfg['meta_optim_optim_cfg']
     eng = model._ensure_engine(height, width, max(cfg['data_cfg']['batch_sizes'].values()))
-    mt = MetaTrainer(eng, dist=dist, meta_batch_size=cfg['meta_batch_size'], model_init_lr=oc['model_init_lr'],
+    # several tasks per rank: up to 4 of them in flight together, one engine each on its own stream (a batch-1 task alone
+    # leaves CUs idle in its tails; measured 26.8 -> 34.2 tasks/s per GPU at 480x854)
+    extra_engines = []
+    if sub > 1 and dev.startswith('cuda'):
+        from .engine import Engine
+        for _ in range(min(sub, 4) - 1):
+            with torch.cuda.stream(torch.cuda.Stream()):
+                extra_engines.append(Engine(pm['encoder'], height, width, max(cfg['data_cfg']['batch_sizes'].values()), dev,
+                                            norm=model.norm))
+    mt = MetaTrainer(eng, dist=dist, extra_engines=extra_engines, meta_batch_size=cfg['meta_batch_size'], model_init_lr=oc['model_init_lr'],
                      log_init_lr_lr=oc['log_init_lr_lr'], model_init_weight_decay=oc['model_init_weight_decay'],
                      grad_clip=oc['grad_clip'], max_lr=cfg['meta_optim_cfg']['max_lr'],
                      lr_hierarchy_level=cfg['meta_optim_cfg']['lr_hierarchy_level'],

@@ -109,6 +109,9 @@ int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss
 #define EOSVOS_LOSS_BCE_DICE 2
 #define EOSVOS_LOSS_CLASS_BALANCED_BCE 3 /* `class_balanced_cross_entropy`, networks/loss_ce.py:15-60 */
 int eosvos_loss(eosvos_engine* e, int kind, const float* masks, int batch, float* loss_out);
+/* The value of the last loss evaluated by eosvos_loss* / eosvos_finetune_step / eosvos_meta_grad*, copied to a DEVICE
+ * float on the engine's stream without synchronising (several engines in flight on one GPU: concurrent meta tasks). */
+int eosvos_last_loss(eosvos_engine* e, float* loss_out);
 /* Loss used by the fused entry points eosvos_finetune_step / eosvos_meta_grad (`loss_func` of
  * the run config, cfgs/meta.yaml:68; default EOSVOS_LOSS_BCE = the north-star path). */
 int eosvos_set_loss(eosvos_engine* e, int kind);

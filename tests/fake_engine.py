@@ -152,7 +152,7 @@ class FakeEngine:
         self.gsum = torch.zeros(2)
         self.theta = self.init.clone()
 
-    def meta_grad(self, images, masks, flat_meta_grad, weight=1.0, init_grad=True, new_segment=False):
+    def meta_grad(self, images, masks, flat_meta_grad, weight=1.0, init_grad=True, new_segment=False, sync=True):
         self.forward(images, want_logits=False)
         l = self.loss(self.loss_name, masks)
         G = self._grads()
@@ -168,7 +168,7 @@ class FakeEngine:
             flat_meta_grad[-1] += weight * G[1]
         if new_segment:
             self.gsum = torch.zeros(2)
-        return float(l)
+        return float(l) if sync else l.detach().view(1)
 
     def radam_step(self, param, grad, exp_avg, exp_avg_sq, lr, weight_decay, step, grad_scale=1.0, grad_clip=0.0,
                    betas=(0.9, 0.999), eps=1e-8):

@@ -609,3 +609,35 @@ def test_groupnorm_full_size_forward_vs_oracle(weights):
     l1 = eng.finetune_step(x.to(DEV), y.to(DEV))
     assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0          # one step on the Winograd gradients lowers the loss
     eng.close()
+
+
+def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weights):
+    """MetaTrainer with extra engines (each on its own stream): three tasks in flight together give bit for bit the
+    meta-gradient, losses and updated state of the same three tasks run one after the other on one engine."""
+    from eosvos_amd.engine import Engine
+    from eosvos_amd.meta_run import MetaTrainer
+    tasks = []
+    for t in range(3):
+        x, y = synthetic.synthetic_frames(1, *SMALL, seed=2000 + t)
+        xg, yg = x.to(DEV), y.to(DEV)
+        tasks.append((xg, yg, torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()))
+    seq = MetaTrainer(small_engine, meta_batch_size=3)
+    seq.load_state(*weights)
+    l_seq = seq.meta_iteration(tasks, inner_steps=3)
+    extra = []
+    for _ in range(2):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            extra.append(Engine('resnet50', *SMALL, max_batch=1, device=DEV))
+    con = MetaTrainer(small_engine, meta_batch_size=3, extra_engines=extra)
+    con.load_state(*weights)
+    l_con = con.meta_iteration(tasks, inner_steps=3)
+    torch.cuda.synchronize()
+    assert l_con == l_seq
+    assert torch.equal(con.state, seq.state) and torch.equal(con.exp_avg, seq.exp_avg)
+    l2 = con.meta_iteration(tasks, inner_steps=3)          # the pushed state reached all three engines
+    seq._push_state()                                      # the shared first engine now holds con's second state
+    l2s = seq.meta_iteration(tasks, inner_steps=3)
+    assert l2 == l2s and torch.equal(con.state, seq.state)
+    for e in extra:
+        e.close()
+    small_engine.load_model_state(*weights)

@@ -62,7 +62,10 @@ def test_bench_control_flow_two_ranks(tmp_path, metric):
     assert open(f'{out}.1').read().strip() == ''                        # rank 0 prints the ONE line
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1 and line['scaling'] == 'weak'
     assert line['metric'] == ('meta_tasks_per_sec' if metric == 'meta' else 'finetune_iters_per_sec')
-    assert line['value'] > 0 and abs(line['value'] - 2 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+    per_step = 2 * (4 if metric == 'meta' else 1)                      # ranks x tasks per rank (meta: 4 tasks in flight per GPU)
+    assert line['value'] > 0 and abs(line['value'] - per_step * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+    if metric == 'meta':
+        assert line['config']['meta_batch_size'] == 8 and line['config']['tasks_per_rank'] == 4
     assert line['roofline']['kernel'] == 'stand_in_kernel' and line['cpu_baseline'] is None and line['vs_baseline'] is None
     if metric == 'finetune':
         assert line['extra']['meta_tasks_per_sec'] > 0
