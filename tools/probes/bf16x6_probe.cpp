@@ -436,6 +436,103 @@ __global__ __launch_bounds__(512, 1) void gemm_pipe_kernel(const float* __restri
   }
 }
 
+// 2-deep register prefetch on the adopted structure (256 threads, one LDS stage, 2 workgroups per CU): the loads of K step
+// ks + 2 are issued before the MFMAs of step ks, so a load has two MFMA phases to land.
+__global__ __launch_bounds__(256, 2) void gemm_pf2_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M, int N, int K) {
+  constexpr int BM = 128, BN = 128, BK = 32, NP = 3, ROWB = 80, OP_BYTES = NP * BM * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP_BYTES];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + OP_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int nt = N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int c4 = tid & 7, row = (wave << 3) + (((lane >> 3) & 1) << 2) + (lane >> 4);
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto load = [&](float4* qa, float4* qb, int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      qa[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      qb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + 32 * i) * K + ks * BK + c4 * 4);
+    }
+  };
+  auto put = [&](unsigned char* S, const float4* rv) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = rv[i];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        uint2 w;
+        w.x = pack_hi(v.x, v.y); w.y = pack_hi(v.z, v.w);
+        *reinterpret_cast<uint2*>(S + (p * BM + row + 32 * i) * ROWB + c4 * 8) = w;
+        if (p + 1 < NP) { v.x -= trunc_bf16(v.x); v.y -= trunc_bf16(v.y); v.z -= trunc_bf16(v.z); v.w -= trunc_bf16(v.w); }
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto mma = [&]() {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      bf16x8 fa[2][NP], fb[2][NP];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          fa[t][p] = *reinterpret_cast<const bf16x8*>(As + (p * BM + wm * 64 + t * 32 + r) * ROWB + g * 32 + h * 16);
+          fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * BM + wn * 64 + t * 32 + r) * ROWB + g * 32 + h * 16);
+        }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x16 c = acc[tm][tn];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][2], fb[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], fb[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], fb[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], fb[tn][0], c, 0, 0, 0);
+          acc[tm][tn] = c;
+        }
+    }
+  };
+  const int nk = K / BK;                      // even
+  load(ra0, rb0, 0);
+  put(As, ra0); put(Bs, rb0);
+  load(ra0, rb0, 1);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ks += 2) {
+    if (ks + 2 < nk) load(ra1, rb1, ks + 2);
+    mma();
+    __syncthreads();
+    put(As, ra0); put(Bs, rb0);               // step ks + 1
+    __syncthreads();
+    if (ks + 3 < nk) load(ra0, rb0, ks + 3);
+    mma();
+    __syncthreads();
+    if (ks + 2 < nk) { put(As, ra1); put(Bs, rb1); }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int n = n0 + wn * 64 + tn * 32 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e];
+      }
+}
+
 template <int MODE, int VAR>
 static void run(const char* name, const float* dA, const float* dB, float* dC, int M, int N, int K, const std::vector<float>& hA,
                 const std::vector<float>& hB) {
@@ -445,6 +542,7 @@ static void run(const char* name, const float* dA, const float* dB, float* dC, i
   CK(hipEventCreate(&e1));
   auto go = [&]() {
     if (VAR == 9) hipLaunchKernelGGL(gemm_ws_kernel, dim3(tiles < 256 ? tiles : 256), dim3(512), 0, 0, dA, dB, dC, M, N, K);
+    else if (VAR == 12) hipLaunchKernelGGL(gemm_pf2_kernel, dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K);
     else if (VAR == 10) hipLaunchKernelGGL((gemm_pipe_kernel<128>), dim3(tiles < 256 ? tiles : 256), dim3(512), 0, 0, dA, dB, dC, M, N, K);
     else if (VAR == 11) hipLaunchKernelGGL((gemm_pipe_kernel<256>), dim3(tiles / 2 < 256 ? tiles / 2 : 256), dim3(512), 0, 0, dA, dB, dC, M, N, K);
     else hipLaunchKernelGGL((gemm_kernel<MODE, VAR >= 9 ? 0 : VAR>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K);
@@ -498,6 +596,7 @@ int main() {
     run<3, 0>("bf16 x3", dA, dB, dC, M, N, K, hA, hB);
     run<6, 0>("bf16 x6 v0", dA, dB, dC, M, N, K, hA, hB);
     run<6, 9>("bf16 x6 ws", dA, dB, dC, M, N, K, hA, hB);
+    run<6, 12>("x6 prefetch-2", dA, dB, dC, M, N, K, hA, hB);
     run<6, 10>("x6 pipe 128x128", dA, dB, dC, M, N, K, hA, hB);
     run<6, 11>("x6 pipe 256x128", dA, dB, dC, M, N, K, hA, hB);
     {
