@@ -488,11 +488,21 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   }
 }
 
+static int env_int(const char* name, int dflt);
+// Tile width in N.  EOSVOS_TUNE_BN64_TILES=t (experiment): launches with fewer than t 128x128 tiles use 128x64 tiles,
+// halving the bytes of every parked partial tile at the price of more operand staging per MFMA.
+int conv_bn(const ConvArgs& a) {
+  if (a.N <= 64) return 64;
+  static const int thr = env_int("EOSVOS_TUNE_BN64_TILES", 0);
+  if (thr > 0 && conv_mfma_mode() == 1 && (long)((a.M + 127) / 128) * ((a.N + 127) / 128) < thr) return 64;
+  return 128;
+}
+
 // Host: per-tile compacted K-step prefix and valid-tap masks (dilated unit-stride gathers; stride-2 data
 // gradients in parity-major row order).
 // Returns the total number of valid K steps.  prefix has tiles+1 entries, mask tiles entries.
 long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vector<int>& mask) {
-  const int bn = (a.N > 64) ? 128 : 64;
+  const int bn = conv_bn(a);
   const int T = a.KH * a.KW;
   const int chunks = (a.Kc + EOSVOS_BK - 1) / EOSVOS_BK;
   const int nt = (a.N + bn - 1) / bn, mt = (a.M + 127) / 128;
@@ -1169,7 +1179,7 @@ int conv_prof_read(int max, const char** names, long* counts, double* ms, double
 // share of the nominal multiply-accumulates a launch executes (taps skipped by tap tables / pixel rectangles)
 double conv_exec_frac(const ConvArgs& a) {
   if (!a.tprefix || a.total_units <= 0) return 1.0;
-  const int bn = (a.N > 64) ? 128 : 64;
+  const int bn = conv_bn(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   return (double)a.total_units / (double)(tiles * (long)a.KH * a.KW * ((a.Kc + 31) / 32));
 }
@@ -1196,7 +1206,7 @@ int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG_DEEP * 2 * 128 * 128; }
 //                 the tiles%512 leftover tiles are streamed over all workgroups in equal K runs;
 //   tiles <  512: everything is streamed (K split across workgroups).
 int conv_plan(ConvArgs& a) {
-  const int bn = (a.N > 64) ? 128 : 64;
+  const int bn = conv_bn(a);
   const int T = a.KH * a.KW;
   long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
@@ -1244,7 +1254,7 @@ int conv_plan(ConvArgs& a) {
 }
 
 void launch_conv(ConvArgs& a, hipStream_t s) {
-  const int bn = (a.N > 64) ? 128 : 64;
+  const int bn = conv_bn(a);
   const int nwg = conv_plan(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   const dim3 grid(nwg), block(256);

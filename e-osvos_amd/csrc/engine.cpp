@@ -264,7 +264,7 @@ void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
   const bool s2_dgrad = c.k == 3 && kind == 1 && a.upshift == 1 && !a.dst_up;    // 2.25 of 9 taps per pixel on average
 #endif
   if (!dilated && !s2_dgrad) return;
-  const int bn = (a.N > 64) ? 128 : 64;
+  const int bn = conv_bn(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   if (tiles > 1024) return;                       // keep the partial-tile slab count bounded
   const long key = ((long)ci * 2 + kind) * 64 + B;

@@ -75,6 +75,7 @@ inline int conv_par_pixel(int B, int Ho, int Wo, int m) {
 }
 // fills a.per, launches the stream-K kernel (+ the fix-up kernel when tiles are shared)
 void launch_conv(ConvArgs& a, hipStream_t s);
+int conv_bn(const ConvArgs& a);      // tile width in N (64 or 128)
 int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
 void conv_set_mfma_mode(int mode);
 // per-launch HIP-event timing of the MFMA kernels (conv_kernels.hip)
