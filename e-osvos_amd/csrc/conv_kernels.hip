@@ -1198,6 +1198,18 @@ double wgrad_exec_frac(const WgradArgs& a) {
 }
 
 #define CONV_MAX_WG (256 * EOSVOS_OCC)
+// Workgroups a launch plans for.  An engine that shares the GPU with others (concurrent meta tasks) is better off
+// splitting K less: fewer parked partial tiles, and the other engines' launches fill the rest of the chip.
+int conv_clamp_wg_budget(int n) {
+  if (n <= 0) return 0;
+  n = (n + 63) / 64 * 64;
+  return n >= CONV_MAX_WG ? 0 : n;
+}
+static int conv_wg_budget(int requested) {
+  static const int env = conv_clamp_wg_budget(env_int("EOSVOS_TUNE_WG_BUDGET", 0));
+  const int b = requested > 0 ? conv_clamp_wg_budget(requested) : env;
+  return b > 0 ? b : CONV_MAX_WG;
+}
 #define CONV_MAX_WG_DEEP (256 * 3)
 int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG_DEEP * 2 * 128 * 128; }
 
@@ -1224,7 +1236,7 @@ int conv_plan(ConvArgs& a) {
   a.deep = 0;
 #endif
   if (a.deep == 2) ksteps = (long)T * ((a.Kc + EOSVOS_BK_DEEP - 1) / EOSVOS_BK_DEEP);
-  long nwg = a.deep ? CONV_MAX_WG_DEEP : CONV_MAX_WG, q = 0, per = 0;
+  long nwg = a.deep ? CONV_MAX_WG_DEEP : conv_wg_budget(a.wg_budget), q = 0, per = 0;
   if (tiles >= nwg && a.total_units <= 0) {
     q = tiles / nwg;
     const long rem = tiles - q * nwg;
@@ -1239,7 +1251,7 @@ int conv_plan(ConvArgs& a) {
 #endif
     // short K, or at least one tile per CU and a K so short that the fix-up pass (a second launch, >= 10 us)
     // costs more than the idle second slot of some CUs: one whole tile per workgroup
-    const bool dp_small = tiles >= CONV_MAX_WG / 2 && ksteps * EOSVOS_BK <= 256;
+    const bool dp_small = tiles >= conv_wg_budget(a.wg_budget) / 2 && ksteps * EOSVOS_BK <= 256;
     if ((ksteps <= EOSVOS_MINK + 1 || dp_small) && a.total_units <= 0) {
       per = ksteps; nwg = tiles;                       // no fix-up
     } else {
@@ -1475,13 +1487,13 @@ static bool wg_small(int P, int Cout, int Cin, int T) {
   const int t128 = ((Cout + wg_tile(Cout) - 1) / wg_tile(Cout)) * ((Cin + wg_tile(Cin) - 1) / wg_tile(Cin)) * T;
   return P < EOSVOS_WG_SMALLP && t128 < 256;
 }
-int wgrad_pick_splits(int P, int Cout, int Cin, int T) {
+int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget) {
   const bool small = wg_small(P, Cout, Cin, T);
   const int bm = small ? 64 : wg_tile(Cout), bn = small ? 64 : wg_tile(Cin);
   const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
   const int steps = (P + EOSVOS_WG_BKP - 1) / EOSVOS_WG_BKP;
   // pick the K split so that tiles*S fills whole rounds of the resident workgroups
-  constexpr int RES = 256 * EOSVOS_WG_OCC;
+  const int RES = conv_wg_budget(wg_budget) * EOSVOS_WG_OCC / EOSVOS_OCC;
   int best = 1;
   double best_eff = 0.0;
   static const int minsteps = env_int("EOSVOS_TUNE_WG_MINSTEPS", 128 / EOSVOS_WG_BKP);

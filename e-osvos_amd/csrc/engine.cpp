@@ -213,6 +213,7 @@ struct eosvos_engine {
   int lastB = 0;
   bool have_loss_grad = false;
   int force_algo = 0;                 // EOSVOS_ALGO_*: 0 = plan by work size; the op-level parity tests force one path
+  int wg_budget = 0;                  // eosvos_set_wg_budget: workgroups a launch plans for (0 = the whole chip)
 
   int64_t max_alloc_floats = 0;      // largest single allocation (every conv operand is one of them)
   float* falloc(int64_t n) {
@@ -362,6 +363,7 @@ ConvArgs wino_fwd_gemm(eosvos_engine* e, int ci, const WinoGeom& wg, float* ws) 
   const long prow = wg.prow;
   ConvArgs m;
   memset(&m, 0, sizeof(m));
+  m.wg_budget = e->wg_budget;
   m.x = e->wino_V[ci]; m.w = e->wino_U[ci]; m.y = e->wino_m; m.ws = ws; m.nplanes = wg.np;
   m.B = 1; m.Hi = 1; m.Wi = (int)(wg.np * prow); m.ldx = c.cin; m.Kc = c.cin;
   m.Ho = 1; m.Wo = m.Wi; m.N = c.cout; m.ldy = c.cout; m.KH = m.KW = 1; m.mul = 1;
@@ -375,6 +377,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.wg_budget = e->wg_budget;
   hipStream_t st = side ? e->s2 : e->s;
   a.x = x; a.w = e->W_(ci); a.y = y; a.ws = side ? e->ws_conv2 : e->ws_conv;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.ldx = ldx; a.Kc = c.cin;
@@ -431,6 +434,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.wg_budget = e->wg_budget;
   if (e->gn() && c.norm) { g = e->zbuf[ci]; ldg = c.cout; }   // gradient w.r.t. the raw conv output (conv_wgrad made it)
   a.x = g; a.w = e->W_(ci); a.y = gx; a.ws = e->ws_conv;
   a.B = B; a.Hi = conv_out(Hin, c.k, c.stride, c.dil, c.pad); a.Wi = conv_out(Win, c.k, c.stride, c.dil, c.pad);
@@ -458,6 +462,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     }
     ConvArgs m;
     memset(&m, 0, sizeof(m));
+    m.wg_budget = e->wg_budget;
     m.x = e->wino_dM[ci]; m.w = e->wino_Us[ci]; m.y = e->wino_dv; m.ws = e->ws_conv; m.nplanes = wg.np;
     m.B = 1; m.Hi = 1; m.Wi = (int)(wg.np * prow); m.ldx = c.cout; m.Kc = c.cout;
     m.Ho = 1; m.Wo = m.Wi; m.N = c.cin; m.ldy = c.cin; m.KH = m.KW = 1; m.mul = 1;
@@ -555,7 +560,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     a.B = 1; a.Ho = 1; a.Wo = (int)ntile; a.ldg = c.cout; a.Cout = c.cout; a.Hi = 1; a.Wi = (int)ntile; a.ldx = c.cin; a.Cin = c.cin;
     a.KH = a.KW = wg.tm + 2; a.stride = 1; a.pad = 0; a.dil = 0;  // the "taps" are the Winograd positions, no pixel shift
     a.g_tap_stride = prow * c.cout; a.x_tap_stride = prow * c.cin;
-    a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, wg.np);
+    a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, wg.np, e->wg_budget);
     trace("wgrad", ci, c.cout, (long)c.cin * wg.np, ntile, a.splits);
     const int cin = c.cin, cout = c.cout;
     go = [=](hipStream_t ws) {
@@ -573,7 +578,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     a.B = B; a.Ho = Ho; a.Wo = Wo;
     a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
     a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
-    a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T());
+    a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T(), e->wg_budget);
     trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits, wgrad_exec_frac(a));
     go = [=](hipStream_t ws) { launch_wgrad(a, ws); };
     nslabs = a.splits;
@@ -644,6 +649,13 @@ int eosvos_set_matrix_mode(int mode) {
   return 0;
 }
 int eosvos_get_matrix_mode(void) { return conv_mfma_mode(); }
+int eosvos_set_wg_budget(eosvos_engine* e, int workgroups) {
+  if (!e) { fail("null engine"); return -1; }
+  if (workgroups < 0) { fail("workgroup budget must be >= 0"); return -1; }
+  e->wg_budget = conv_clamp_wg_budget(workgroups);
+  for (auto& tab : e->upd_tab) tab = nullptr;      // the update tables carry the split counts of the old budget
+  return e->wg_budget;
+}
 
 int eosvos_num_convs(int arch) {
   Topo t;
@@ -735,7 +747,8 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     const int Mf = B * Ho * Wo, Md = B * Hin * Win;
     (void)Md;
     for (int b = 1; b <= B; ++b)
-      slabs[ci] = max64(slabs[ci], (int64_t)wgrad_pick_splits(b * Ho * Wo, c.cout, c.cin, c.T()) * c.wsize());
+      for (int wb = 0; wb <= 512; wb += 64)          // every budget eosvos_set_wg_budget accepts
+        slabs[ci] = max64(slabs[ci], (int64_t)wgrad_pick_splits(b * Ho * Wo, c.cout, c.cin, c.T(), wb) * c.wsize());
     bool reserve = false;
 #ifndef EOSVOS_NO_WINO
     reserve = wino_shape(c) && (ci == t.dec_a || ci == t.dec_b ||
@@ -744,7 +757,8 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     if (reserve) {                     // [final 9-tap slab][Winograd-domain slabs: splits x cout x 16 x cin]
       for (int b = 1; b <= B; ++b) {
         const WinoGeom gb = wino_geom(e, c, b, Ho, Wo);
-        slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits((int)gb.ntile, c.cout, c.cin, gb.np) * c.cout * gb.np * c.cin);
+        for (int wb = 0; wb <= 512; wb += 64)
+          slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits((int)gb.ntile, c.cout, c.cin, gb.np, wb) * c.cout * gb.np * c.cin);
       }
       const WinoGeom gm = wino_geom(e, c, B, Ho, Wo);
       const int64_t prow = gm.prow, np = gm.np;

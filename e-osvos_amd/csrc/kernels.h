@@ -51,6 +51,7 @@ struct ConvArgs {
   long total_units;     // sum of valid K steps when tprefix is set, else 0
   int deep;             // set by conv_plan: 1 / 2 = the 3-workgroups-per-CU kernel variants (K step 32 single stage / 16)
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
+  int wg_budget;        // workgroups the launch may plan for (0: two per CU); engines that run beside others split less
 };
 // Parity-major row order of a stride-2 data gradient: rows [0, M) walk the (even,even) output pixels of all
 // images, then (even,odd), (odd,even), (odd,odd).  A pixel of parity (py,px) only receives the filter taps with
@@ -105,7 +106,8 @@ struct WgradArgs {
   long g_tap_stride, x_tap_stride;   // != 0: tap t reads plane g + t*stride / x + t*stride (batched GEMMs, Winograd)
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
-int wgrad_pick_splits(int P, int Cout, int Cin, int T);
+int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget = 0);
+int conv_clamp_wg_budget(int n);     // the budgets the slab arenas are sized for: 0 (default) or a multiple of 64 in [64, 512]
 // Winograd F(2x2,3x3) weight gradient pieces (misc_kernels.hip): V = B^T d B, dM = A dY A^T, dW = G^T sum_z dU_z G
 // planes are [16][prow][C] with prow >= B*th*tw rows (padded to the GEMM tile so that a row tile never straddles planes)
 // dil: dilation of the 3x3 conv = dil*dil interleaved sub-grids; tiles are (image, sy, sx, ty, tx), th x tw per sub-grid

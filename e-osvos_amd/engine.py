@@ -273,6 +273,14 @@ class Engine:
     def synchronize(self):
         _ffi.check(self.lib.eosvos_synchronize(self.h))
 
+    def set_wg_budget(self, workgroups):
+        """Workgroups a launch plans for (`eosvos_set_wg_budget`): 0 = the whole chip (an engine alone on the GPU),
+        256 for engines that run beside each other.  Returns the budget in effect."""
+        r = self.lib.eosvos_set_wg_budget(self.h, int(workgroups))
+        if r < 0:
+            _ffi.check(1)
+        return r
+
     def time_hot_kernel(self, batch, reps=20):
         ms, fl = ctypes.c_float(), ctypes.c_double()
         _ffi.check(self.lib.eosvos_time_hot_kernel(self.h, batch, reps, ctypes.byref(ms), ctypes.byref(fl)))

@@ -13,10 +13,15 @@ The flat state vector is [log_init_lr_* | model_init_*] in `MetaOptimizer.named_
 order (`meta_optim.py:65-66,78`), the reference's OIHW layout.
 """
 import math
+import os
 
 import torch
 
 from .topology import neuron_lr_shape, trainable
+
+# engines in flight on one GPU -> workgroups each plans its launches for (0 = the whole chip); measured on MI355X,
+# 480x854 batch-1 tasks (profiles/r02_meta_wg_budget.txt); EOSVOS_META_WG_BUDGET overrides
+CONCURRENT_WG_BUDGET = {1: 0, 2: 256, 3: 256, 4: 256}
 
 
 class _on_stream:
@@ -44,6 +49,12 @@ class MetaTrainer:
         tails and small grids that a second and third task fill (measured: 3 engines 1.17x the task rate of 1)."""
         self.eng = engine
         self.engines = [engine] + list(extra_engines)
+        # engines that share the GPU plan each launch for part of the chip (`eosvos_set_wg_budget`): less K splitting,
+        # fewer parked partial tiles; the other tasks' launches fill the remaining CUs
+        budget = int(os.environ.get('EOSVOS_META_WG_BUDGET', CONCURRENT_WG_BUDGET.get(min(len(self.engines), 4), 0)))
+        for e in self.engines:
+            if hasattr(e, 'set_wg_budget'):
+                e.set_wg_budget(budget)
         self.level, self.use_log = lr_hierarchy_level, bool(use_log_init_lr)
         self.n_lr = engine.lr_store_count(lr_hierarchy_level)        # NotImplementedError for unknown levels
         engine.set_loss(loss_func)

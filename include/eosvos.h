@@ -53,6 +53,16 @@ const char* eosvos_last_error(void);
 int eosvos_set_matrix_mode(int mode);
 int eosvos_get_matrix_mode(void);
 
+/* Workgroups one launch of this engine plans for.  0 (default): two per CU, i.e. the whole chip -- right for an
+ * engine that has the GPU to itself.  Engines that run beside each other (concurrent meta tasks, one engine per task:
+ * meta_run.run_tasks_concurrent) do better with half of that: every launch then splits its reduction less (fewer parked
+ * partial tiles to write and re-read) and the other engines' launches fill the rest of the chip (4 tasks in flight:
+ * +8 % meta tasks/s at 256).  Rounded up to a multiple of 64; values >= 512 mean 0.  Changes the summation order of
+ * split reductions (results stay within the parity tolerances, not bit-identical across budgets).  Call between
+ * steps, not between a backward pass and its update.  Returns the budget in effect, < 0 on error.
+ * No reference counterpart (the reference runs one task per process and lets cuDNN choose). */
+int eosvos_set_wg_budget(eosvos_engine* e, int workgroups);
+
 /* Number of convolutions of DeepLabV3+ on `arch` (63 for ResNet-50); -1 on bad arch.
  * Replaces: module enumeration of networks/deeplabv3plus.py:104-155. */
 int eosvos_num_convs(int arch);

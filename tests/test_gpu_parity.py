@@ -611,11 +611,13 @@ def test_groupnorm_full_size_forward_vs_oracle(weights):
     eng.close()
 
 
-def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weights):
+def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weights, monkeypatch):
     """MetaTrainer with extra engines (each on its own stream): three tasks in flight together give bit for bit the
-    meta-gradient, losses and updated state of the same three tasks run one after the other on one engine."""
+    meta-gradient, losses and updated state of the same three tasks run one after the other on one engine (at the same
+    workgroup budget: the budget changes the order of split reductions)."""
     from eosvos_amd.engine import Engine
-    from eosvos_amd.meta_run import MetaTrainer
+    from eosvos_amd.meta_run import CONCURRENT_WG_BUDGET, MetaTrainer
+    monkeypatch.setenv('EOSVOS_META_WG_BUDGET', str(CONCURRENT_WG_BUDGET[3]))
     tasks = []
     for t in range(3):
         x, y = synthetic.synthetic_frames(1, *SMALL, seed=2000 + t)
@@ -640,4 +642,32 @@ def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weight
     assert l2 == l2s and torch.equal(con.state, seq.state)
     for e in extra:
         e.close()
+    small_engine.set_wg_budget(0)
     small_engine.load_model_state(*weights)
+
+
+@pytest.mark.gpu
+def test_wg_budget_changes_rounding_only(small_engine, weights):
+    """`eosvos_set_wg_budget`: an engine that plans its launches for half the chip (what engines sharing a GPU use)
+    gives the same fine-tune trajectory up to the order of the split reductions; the budget is clamped to the
+    multiples of 64 the slab arenas are sized for."""
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=77)
+    xg, yg = x.to(DEV), y.to(DEV)
+    assert small_engine.set_wg_budget(0) == 0 and small_engine.set_wg_budget(4096) == 0
+    assert small_engine.set_wg_budget(200) == 256 and small_engine.set_wg_budget(1) == 64
+    with pytest.raises(Exception):
+        small_engine.set_wg_budget(-5)
+    out = {}
+    for budget in (0, 256, 128):
+        small_engine.set_wg_budget(budget)
+        small_engine.load_model_state(*weights)
+        theta0 = small_engine.get_params().clone()
+        losses = [small_engine.finetune_step(xg, yg) for _ in range(4)]
+        out[budget] = (losses, small_engine.get_params().clone())
+    small_engine.set_wg_budget(0)
+    small_engine.load_model_state(*weights)
+    for budget in (256, 128):
+        for a, b in zip(out[budget][0], out[0][0]):
+            assert abs(a - b) <= LOSS_RTOL * 50 * abs(b), (budget, a, b)          # 4 steps of accumulated rounding
+        d = (out[budget][1] - out[0][1]).norm() / (out[0][1] - theta0).norm()
+        assert float(d) < 2e-3, (budget, float(d))                             # vs the size of the update itself

@@ -5,12 +5,14 @@ sys.path.insert(0, ".")
 from eosvos_amd import synthetic
 from eosvos_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-for n in (1, 2, 3):
+BUDGET = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # eosvos_set_wg_budget of every engine
+for n in (1, 2, 3, 4):
     engs = []
     for i in range(n):
         with torch.cuda.stream(torch.cuda.Stream()):
             e = Engine("resnet50", 480, 854, max_batch=B)
             e.load_model_state(synthetic.synthetic_state("resnet50"), synthetic.synthetic_lrs("resnet50"))
+            e.set_wg_budget(BUDGET)
         engs.append(e)
     def step(e):
         with torch.cuda.stream(e.stream):          # an engine is called on the stream it is bound to
@@ -26,5 +28,5 @@ for n in (1, 2, 3):
     t1 = time.perf_counter()
     for e in engs: e.synchronize()
     dt = time.perf_counter() - t0
-    print("B", B, "engines", n, "ms per step (aggregate) %.2f" % (dt * 100 / n), " enqueue ms/step %.2f" % ((t1 - t0) * 100 / n))
+    print("B", B, "budget", BUDGET, "engines", n, "ms per step (aggregate) %.2f" % (dt * 100 / n), " enqueue ms/step %.2f" % ((t1 - t0) * 100 / n))
     for e in engs: e.close()
