@@ -1485,7 +1485,8 @@ static int wg_tile(int c) {
 // few pixels AND few tiles (stride-16 layers at batch 1): 64x64 tiles give more tiles and fewer K splits
 static bool wg_small(int P, int Cout, int Cin, int T) {
   const int t128 = ((Cout + wg_tile(Cout) - 1) / wg_tile(Cout)) * ((Cin + wg_tile(Cin) - 1) / wg_tile(Cin)) * T;
-  return P < EOSVOS_WG_SMALLP && t128 < 256;
+  static const int smallp = env_int("EOSVOS_TUNE_WG_SMALLP", EOSVOS_WG_SMALLP), smallt = env_int("EOSVOS_TUNE_WG_SMALLT", 256);
+  return P < smallp && t128 < (P < EOSVOS_WG_SMALLP ? 256 : smallt);
 }
 int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget) {
   const bool small = wg_small(P, Cout, Cin, T);
