@@ -292,6 +292,31 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
     rows, prof_step_s = profiled_pass(eng, step, psteps)
     roofline = roofline_from(rows, psteps, mode, lib_version, BATCH, ms_per_step)
     roofline['profiled_pass_ms_per_step'] = 1e3 * prof_step_s
+    if not a.no_ab and world == 1 and torch.cuda.is_available() and engine_factory is None:
+        # `achieved` above times the kernel while the other stream's launches share the chip with it (weight-gradient
+        # launches run beside the data-gradient chain).  The same kernel with the chip to itself: an engine without the
+        # side stream, every launch in one queue.
+        os.environ['EOSVOS_NO_SIDE_STREAM'] = '1'
+        try:
+            e1 = Engine('resnet50', H, W, max_batch=BATCH, device=dev)
+        finally:
+            os.environ.pop('EOSVOS_NO_SIDE_STREAM', None)
+        e1.load_model_state(sd, lrs)
+        step1 = lambda: e1.finetune_step(xg, yg, sync_loss=False)
+        for _ in range(3):
+            step1()
+        rows1, s1 = profiled_pass(e1, step1, 10)
+        e1.close()
+        if roofline['kernel'] in rows1:
+            l1, ms1, fl1 = rows1[roofline['kernel']]
+            ach1 = fl1 / (ms1 * 1e-3) / 1e12
+            mf1 = {k: v for k, v in rows1.items() if 'fixup' not in k}
+            roofline['single_stream'] = {
+                'note': 'same kernel symbol, engine built without the side stream (one queue, no launch shares the chip '
+                        'with another): the quality of the kernel itself; the step is slower this way',
+                'achieved': ach1, 'frac': ach1 / roofline['peak'], 'frac_of_fp32_matrix_peak': ach1 / FP32_MATRIX_PEAK,
+                'avg_launch_us': 1e3 * ms1 / l1, 'ms_per_step': 1e3 * s1,
+                'all_matrix_kernels_tflops': sum(v[2] for v in mf1.values()) / (sum(v[1] for v in mf1.values()) * 1e-3) / 1e12}
 
     extra = {'last_loss': last_loss, 'matrix_mode': mode, 'lib_version': lib_version,
              'mfma_probe_fp32_tflops': eng.mfma_probe(),
