@@ -29,6 +29,7 @@ _SIGNATURES = {
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'eosvos_destroy': (ctypes.c_int, [_E]),
     'eosvos_synchronize': (ctypes.c_int, [_E]),
+    'eosvos_debug_check_guards': (ctypes.c_int, [_E]),
     'eosvos_set_init': (ctypes.c_int, [_E, c_float_p]),
     'eosvos_set_lr': (ctypes.c_int, [_E, c_float_p]),
     'eosvos_lr_store_count': (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),

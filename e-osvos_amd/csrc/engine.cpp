@@ -216,10 +216,24 @@ struct eosvos_engine {
   int wg_budget = 0;                  // eosvos_set_wg_budget: workgroups a launch plans for (0 = the whole chip)
 
   int64_t max_alloc_floats = 0;      // largest single allocation (every conv operand is one of them)
+  // EOSVOS_DEBUG_GUARD=1: every buffer sits between two 256 KB guard bands filled with a pattern;
+  // eosvos_debug_check_guards reports bands a kernel wrote into (out-of-bounds writes)
+  static constexpr int64_t GUARD = 65536;
+  std::vector<std::pair<unsigned*, int64_t>> guarded;
   float* falloc(int64_t n) {
     void* p = nullptr;
     if (n < 1) n = 1;
     if (n > max_alloc_floats) max_alloc_floats = n;
+    static const bool guard = getenv("EOSVOS_DEBUG_GUARD") != nullptr;
+    if (guard) {
+      const int64_t nn = (n + 63) / 64 * 64;
+      if (hipMalloc(&p, (size_t)(nn + 2 * GUARD) * sizeof(float)) != hipSuccess) return nullptr;
+      (void)hipMemsetD32((hipDeviceptr_t)p, 0xDEADBEEF, (size_t)(nn + 2 * GUARD));
+      (void)hipDeviceSynchronize();
+      allocs.push_back(p);
+      guarded.push_back({(unsigned*)p, n});
+      return (float*)p + GUARD;
+    }
     if (hipMalloc(&p, (size_t)n * sizeof(float)) != hipSuccess) return nullptr;
     allocs.push_back(p);
     return (float*)p;
@@ -869,6 +883,33 @@ int eosvos_destroy(eosvos_engine* e) {
   delete e;
   return 0;
 }
+// debug: returns the number of guard words that no longer hold the pattern and prints where (stderr)
+int eosvos_debug_check_guards(eosvos_engine* e) {
+  if (!e) return -1;
+  (void)hipDeviceSynchronize();
+  int bad = 0;
+  for (size_t i = 0; i < e->guarded.size(); ++i) {
+    unsigned* base = e->guarded[i].first;
+    const int64_t n = e->guarded[i].second, nn = (n + 63) / 64 * 64;
+    for (int side = 0; side < 2; ++side) {
+      // side 1 starts at the first float past the n requested ones (the rounding pad belongs to the band)
+      const unsigned* g = side == 0 ? base : base + eosvos_engine::GUARD + n;
+      const int64_t cnt = side == 0 ? eosvos_engine::GUARD : eosvos_engine::GUARD + (nn - n);
+      std::vector<unsigned> hh((size_t)cnt);
+      if (hipMemcpy(hh.data(), g, (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      int64_t first = -1, last = -1, c = 0;
+      for (int64_t k = 0; k < cnt; ++k)
+        if (hh[k] != 0xDEADBEEFu) { if (first < 0) first = k; last = k; ++c; }
+      if (c) {
+        fprintf(stderr, "[guard] allocation #%zu (%lld floats): %lld words overwritten %s it, offsets %lld..%lld (floats %s)\n", i,
+                (long long)n, (long long)c, side ? "after" : "before", (long long)first, (long long)last,
+                side ? "past the end" : "from the band start; the buffer begins at 65536");
+        bad += (int)c;
+      }
+    }
+  }
+  return bad;
+}
 int eosvos_synchronize(eosvos_engine* e) {
   if (!e) return fail("null engine");
   HIPOK(hipStreamSynchronize(e->s));
@@ -1329,7 +1370,7 @@ int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int fli
   if (interp != EOSVOS_INTER_NEAREST && interp != EOSVOS_INTER_CUBIC) return fail("unknown interpolation");
   const int H = e->H, W = e->W;
   if (!e->aug_tab) {
-    e->aug_tab = (int*)e->falloc(2 * W + 2 * H + 1);
+    e->aug_tab = (int*)e->falloc(4);            // the non-zero counter of label warps
     e->aug_ctab = e->falloc(128);
     if (!e->aug_tab || !e->aug_ctab) return fail("hipMalloc augmentation tables");
     float ct[128];
@@ -1357,22 +1398,15 @@ int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int fli
   M[2] = b1; M[5] = b2;
   const int AB_SCALE = 1 << 10;
   const int round_delta = interp == EOSVOS_INTER_NEAREST ? AB_SCALE / 2 : AB_SCALE / 32 / 2;
-  std::vector<int> tab(2 * W + 2 * H + 1);
-  for (int x = 0; x < W; ++x) {
-    tab[x] = (int)lrint(M[0] * x * AB_SCALE);
-    tab[W + x] = (int)lrint(M[3] * x * AB_SCALE);
-  }
-  for (int y = 0; y < H; ++y) {
-    tab[2 * W + y] = (int)lrint((M[1] * y + M[2]) * AB_SCALE) + round_delta;
-    tab[2 * W + H + y] = (int)lrint((M[4] * y + M[5]) * AB_SCALE) + round_delta;
-  }
-  tab[2 * W + 2 * H] = 0;
-  HIPOK(hipMemcpyAsync(e->aug_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, e->s));
-  launch_warp_affine(src, dst, channels, H, W, e->aug_tab, e->aug_ctab, interp == EOSVOS_INTER_CUBIC, flip != 0,
-                     nonzero_host ? e->aug_tab + 2 * W + 2 * H : nullptr, e->s);
+  // the fixed-point tables are evaluated in the kernel from M and round_delta (travelling by value): a queued launch
+  // owns everything it reads, so calls can follow each other without a host wait
+  int* counter = e->aug_tab;
+  if (nonzero_host) HIPOK(hipMemsetAsync(counter, 0, sizeof(int), e->s));
+  launch_warp_affine(src, dst, channels, H, W, M, round_delta, e->aug_ctab, interp == EOSVOS_INTER_CUBIC, flip != 0,
+                     nonzero_host ? counter : nullptr, e->s);
   HIPOK(hipGetLastError());
   if (nonzero_host) {
-    HIPOK(hipMemcpyAsync(nonzero_host, e->aug_tab + 2 * W + 2 * H, sizeof(int), hipMemcpyDeviceToHost, e->s));
+    HIPOK(hipMemcpyAsync(nonzero_host, counter, sizeof(int), hipMemcpyDeviceToHost, e->s));
     HIPOK(hipStreamSynchronize(e->s));
   }
   return 0;

@@ -200,8 +200,8 @@ void launch_dice(const float* logits, const float* gt, float* dlogits, float* lo
 void launch_sigmoid(const float* x, float* y, int64_t n, hipStream_t s);
 void launch_merge_labels(const float* probs, int n_obj, int64_t n_pix, uint8_t* labels, hipStream_t s);
 // cv2.warpAffine (+ optional horizontal flip of the source) of C planes; tables = adelta[W] bdelta[W] X0[H] Y0[H]
-void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const int* tables, const float* ctab,
-                        int cubic, int flip, int* nonzero, hipStream_t s);
+void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const double* inv_matrix, int round_delta,
+                        const float* ctab, int cubic, int flip, int* nonzero, hipStream_t s);
 
 // theta' = theta - lr[cout]*g, g = rowscale[cout] * sum_z ws[z][...]; optional gsum += g; g_out = g
 void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, const float* rowscale,

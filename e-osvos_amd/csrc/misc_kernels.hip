@@ -1177,20 +1177,28 @@ void launch_dice(const float* logits, const float* gt, float* dlogits, float* lo
 // RandomScaleNRotate warps the frame with cv2.INTER_CUBIC and the label with cv2.INTER_NEAREST, border 0,
 // canvas size unchanged; RandomHorizontalFlip mirrors the source first (cv2.flip, `:202-211`).  OpenCV's
 // warpAffine (imgproc/imgwarp.cpp, 4.1) computes the source coordinates in 10-bit fixed point from integer
-// tables adelta/bdelta (per column) and X0/Y0 (per row); the host builds those tables in double exactly as
-// OpenCV does, so the coordinates here are bit-identical to the restated algorithm; cubic taps use the
+// tables adelta/bdelta (per column) and X0/Y0 (per row), built in double; the kernel evaluates the same entries with the
+// same roundings, so the coordinates here are bit-identical to the restated algorithm; cubic taps use the
 // a = -0.75 kernel sampled at 1/32 pixel (INTER_BITS = 5), weights = cy[k1]*cx[k2] in float.
 namespace eosvos {
+// The fixed-point tables of cv::warpAffine, entry by entry in the kernel (the inverted matrix travels by value, so a
+// launch carries everything it reads: no table buffer a later call could overwrite while this one is still queued).
+// Same double expressions as the host form, (M0 * x) * 1024 and (M1 * y + M2) * 1024, each operation rounded on its own
+// (no fused multiply-add), then round-half-even to int like lrint.
+struct WarpMat { double m[6]; int round_delta; };
+__device__ __forceinline__ int warp_fix(double a, int i) { return __double2int_rn(__dmul_rn(__dmul_rn(a, (double)i), 1024.0)); }
+__device__ __forceinline__ int warp_fix(double a, int i, double b, int rd) {
+  return __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(a, (double)i), b), 1024.0)) + rd;
+}
 __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                           int C, int H, int W, const int* __restrict__ adelta,
-                                                           const int* __restrict__ bdelta, const int* __restrict__ X0,
-                                                           const int* __restrict__ Y0, const float* __restrict__ ctab,
+                                                           int C, int H, int W, const WarpMat wm, const float* __restrict__ ctab,
                                                            int cubic, int flip, int* __restrict__ nonzero) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   int cnt = 0;
   if (x < W) {
     const long hw = (long)H * W;
-    const int Xf = X0[y] + adelta[x], Yf = Y0[y] + bdelta[x];
+    const int Xf = warp_fix(wm.m[1], y, wm.m[2], wm.round_delta) + warp_fix(wm.m[0], x);
+    const int Yf = warp_fix(wm.m[4], y, wm.m[5], wm.round_delta) + warp_fix(wm.m[3], x);
     if (!cubic) {
       const int sx = Xf >> 10, sy = Yf >> 10;
       const bool in = (unsigned)sx < (unsigned)W && (unsigned)sy < (unsigned)H;
@@ -1212,6 +1220,12 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
         float sum = 0.f;
         if (interior) {
           // remapBicubic's interior order: one 4-term expression per row, rows accumulated
+          // Every product goes through an opaque register so that the compiler keeps the 16 taps in scalar fp32
+          // instructions.  Left alone it pairs the separately loaded taps into v_pk_mul_f32 / v_pk_fma_f32 operands, and
+          // on MI355X that form of this kernel lost the odd tap of a pair in lanes 48..63 of a wave whenever waves of the
+          // bf16x6 conv kernels (another engine's, on another stream) shared the SIMD -- 20-30 % of 96x160 warps had such
+          // a 16-pixel run, none in 300 runs with scalar instructions (tools/debug/concurrent_victims2.py,
+          // tests/test_augment.py::test_cubic_warp_is_stable_beside_another_engine).
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float* R = S + (long)(sy + i) * W;
@@ -1219,8 +1233,10 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int ux = flip ? W - 1 - (sx + j) : sx + j;
-              const float t = R[ux] * (cy[i] * cx[j]);
+              float t = R[ux] * (cy[i] * cx[j]);
+              asm volatile("" : "+v"(t));
               r = j == 0 ? t : r + t;
+              asm volatile("" : "+v"(r));
             }
             sum = i == 0 ? r : sum + r;
           }
@@ -1247,10 +1263,13 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nonzero, cnt);
   }
 }
-void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const int* tables /*adelta[W] bdelta[W] X0[H] Y0[H]*/,
+void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const double* inv_matrix /*6*/, int round_delta,
                         const float* ctab, int cubic, int flip, int* nonzero, hipStream_t s) {
-  hipLaunchKernelGGL(warp_affine_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, src, dst, C, H, W, tables, tables + W,
-                     tables + 2 * W, tables + 2 * W + H, ctab, cubic, flip, nonzero);
+  WarpMat wm;
+  for (int i = 0; i < 6; ++i) wm.m[i] = inv_matrix[i];
+  wm.round_delta = round_delta;
+  hipLaunchKernelGGL(warp_affine_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, src, dst, C, H, W, wm, ctab, cubic, flip,
+                     nonzero);
 }
 }  // namespace eosvos
 

@@ -65,6 +65,23 @@ def finetune_object(model, meta_optim, meta_optim_state_dict, frames, gt, cfg, a
     """One (sequence, object) work item of `evaluate.py:132-317`: fine-tune on the train frame, predict the following
     frames, with online adaptation re-fine-tune every `step` frames.  Returns (probs (N,H,W) with the train frame seeded
     as 2*GT (`:167-168`), train-loss history per round)."""
+    return _drain(finetune_object_steps(model, meta_optim, meta_optim_state_dict, frames, gt, cfg, augment, train_frame_id))
+
+
+def _drain(gen):
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
+def finetune_object_steps(model, meta_optim, meta_optim_state_dict, frames, gt, cfg, augment=None, train_frame_id=0):
+    """`finetune_object` as a generator: it yields each time a fine-tune iteration (or a few inference frames) has been
+    ENQUEUED on the model's engine and before the host waits for its loss, so that a caller holding several objects
+    (one model / engine / stream each, `run_objects_in_flight`) can queue the others' work in between.  Everything
+    random (`set_random_seeds` + the augmentation draws of an iteration) happens inside one resume, so the draws of an
+    object do not depend on what runs beside it.  The generator's return value is `finetune_object`'s."""
     if augment is None and cfg['data_cfg'].get('random_train_transform'):
         augment = device_augment(model)
     augment = augment or _repeat_batch
@@ -105,12 +122,13 @@ def finetune_object(model, meta_optim, meta_optim_state_dict, frames, gt, cfg, a
                         gts = torch.cat([gts, pg])
                 inputs, gts = inputs.contiguous(), gts.contiguous()
             outputs = model(inputs)
-            train_loss = compute_loss(loss_func, outputs[-1], gts)
-            round_hist.append(train_loss.item())
+            train_loss = compute_loss(loss_func, outputs[-1], gts)     # a device scalar: no host wait yet
             model.zero_grad()
             meta_optim.set_train_loss(train_loss)
             meta_optim.step(train_loss)
             meta_optim.meta_model.detach_param_groups()
+            yield
+            round_hist.append(train_loss.item())                       # the loss before the step (evaluate.py:262-264)
             if early_stopping(round_hist, **es):
                 break
         hist.append(round_hist)
@@ -119,7 +137,75 @@ def finetune_object(model, meta_optim, meta_optim_state_dict, frames, gt, cfg, a
         model.eval()
         for f in range(rd['eval_min'], rd['eval_max']):
             masks[f] = model.engine.infer(frames[f:f + 1].contiguous())[0]
+            if (f - rd['eval_min']) % 4 == 3:
+                yield
     return masks[:, 0], hist
+
+
+class ObjectWorker:
+    """A (model, meta_optim) pair bound to one torch stream: one fine-tune in flight."""
+
+    def __init__(self, model, meta_optim, stream=None):
+        self.model, self.meta_optim, self.stream = model, meta_optim, stream
+
+    def on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else _NullCtx()
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def object_workers(model, meta_optim, meta_optim_cfg, n, wg_budget=256):
+    """`n` workers for `run_objects_in_flight`: the given pair (on the current stream) plus n - 1 spawned ones, each on
+    its own stream with its own engine.  The objects of a multi-object sequence are independent fine-tunes
+    (`evaluate.py:132`); three of them in flight fill the tails and small grids one leaves idle (+8 % iterations/s at
+    batch 3, 480x854, `bench.py` extra).  Engines that share the GPU plan for `wg_budget` workgroups per launch."""
+    from .meta_optim import MetaOptimizer
+    ws = [ObjectWorker(model, meta_optim, torch.cuda.current_stream(model.device) if model.device.type == 'cuda' else None)]
+    for _ in range(n - 1):
+        m = model.spawn()
+        ws.append(ObjectWorker(m, MetaOptimizer(m, **meta_optim_cfg),
+                               torch.cuda.Stream(model.device) if model.device.type == 'cuda' else None))
+    for w in ws:
+        w.wg_budget = wg_budget
+    return ws
+
+
+def run_objects_in_flight(workers, meta_optim_state_dict, frames, gts, cfg, augment=None, train_frame_id=0):
+    """[(probs, hist)] for the objects `gts` of one sequence, up to len(workers) of them in flight together; results are
+    those of `finetune_object` one after the other (same engine arithmetic at the same workgroup budget)."""
+    out = [None] * len(gts)
+    if frames.is_cuda:
+        torch.cuda.current_stream(frames.device).synchronize()      # frames / masks were produced on this stream
+    pending = list(range(len(gts)))
+    active = {}                                                     # worker index -> (object index, generator)
+    budget = workers[0].wg_budget if min(len(gts), len(workers)) > 1 else 0   # alone on the GPU: plan for the whole chip
+    for w in workers:
+        if hasattr(w.model, 'set_wg_budget'):
+            w.model.set_wg_budget(budget)
+    while pending or active:
+        for wi, w in enumerate(workers):
+            if wi not in active and pending:
+                oi = pending.pop(0)
+                active[wi] = (oi, finetune_object_steps(w.model, w.meta_optim, meta_optim_state_dict, frames, gts[oi], cfg,
+                                                        augment, train_frame_id))
+        for wi in sorted(active):
+            oi, gen = active[wi]
+            w = workers[wi]
+            with w.on_stream():
+                try:
+                    next(gen)
+                except StopIteration as stop:
+                    if w.model.engine is not None:
+                        w.model.engine.synchronize()
+                    out[oi] = stop.value
+                    del active[wi]
+    return out
 
 
 def merge_objects(engine, probs_all):
@@ -156,7 +242,7 @@ def save_label_png(path, labels_hw):
 
 def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dataset_key, save_dir=None,
                      meta_iter=None, meta_epoch=None, best_mean_J=0.0, dist=None, device=None, vis_win_names=None,
-                     log=None):
+                     log=None, objects_in_flight=None):
     """The evaluation worker of `src/util/evaluate.py:111-382` for the DeepLab path: every sequence of `dataset`
     (an `eosvos_amd.data` reader), every object, fine-tune / online adaptation / inference / merge; prediction PNGs
     under `{save_dir}/best_eval_preds/{name}/{split}/{seq}/{frame}.png`, J per sequence, and the
@@ -166,6 +252,8 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     ranks (they are independent fine-tunes); the only exchange is one all-reduce(sum) per sequence of the
     zero-initialised per-object probability stack (every slot is written by exactly one rank, so the sum is exact),
     after which every rank merges the same label maps and rank 0 writes files.
+    `objects_in_flight` (default: EOSVOS_OBJECTS_IN_FLIGHT, else 3 on a GPU): how many of a sequence's objects this
+    rank fine-tunes side by side, one engine and stream each (`run_objects_in_flight`); 1 = one after the other.
     Returns dict(J_seq, mean_J, best_mean_J, time_per_frame, labels={seq: (N,H,W) uint8})."""
     from .checkpoint import save_meta_checkpoint
     from .data import sequence_J
@@ -179,16 +267,33 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
             for seq in dataset.seqs_names:
                 os.makedirs(os.path.join(preds_dir, seq), exist_ok=True)
     set_random_seeds(cfg.get('seed', 1))                                        # evaluate.py:42
+    if objects_in_flight is None:
+        objects_in_flight = int(os.environ.get('EOSVOS_OBJECTS_IN_FLIGHT', 3 if torch.device(device or model.device).type == 'cuda' else 1))
+    workers = None
+    if objects_in_flight > 1:
+        workers = getattr(model, '_object_workers', None)
+        if workers is None or len(workers) != objects_in_flight or workers[0].meta_optim is not meta_optim:
+            workers = model._object_workers = object_workers(model, meta_optim, cfg['meta_optim_cfg'], objects_in_flight)
     J_seq, labels_out, item, eval_time, num_frames = [], {}, 0, 0.0, 0
     for seq in dataset.seqs_names:
         frames, gts = dataset.sequence_tensors(seq, device or model.device)
         n = frames.shape[0]
         probs = torch.zeros(len(gts), n, *frames.shape[-2:], device=frames.device)
         t0 = time.perf_counter()
-        for obj_id, gt in enumerate(gts):
+        mine = []
+        for obj_id in range(len(gts)):
             if item % world == rank:
-                probs[obj_id], _ = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gt, cfg)
+                mine.append(obj_id)
             item += 1
+        if workers is not None and len(mine) > 1:
+            res = run_objects_in_flight(workers, meta_optim_state_dict, frames, [gts[o] for o in mine], cfg)
+            for o, (p, _) in zip(mine, res):
+                probs[o] = p
+        else:
+            if workers is not None:
+                model.set_wg_budget(0)                                          # alone on the GPU
+            for o in mine:
+                probs[o], _ = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gts[o], cfg)
         if world > 1:
             dist.all_reduce(probs)
         eval_time += time.perf_counter() - t0

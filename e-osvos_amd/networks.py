@@ -52,6 +52,8 @@ class DeepLabV3Plus:
         if batch_norm is not None and (batch_norm.get('accum_stats') or batch_norm.get('learn_weight')
                                        or batch_norm.get('learn_bias')):
             raise NotImplementedError('only frozen BatchNorm (accum_stats/learn_* False) is implemented')
+        self._ctor = dict(backbone=backbone, num_classes=num_classes, batch_norm=batch_norm, train_encoder=train_encoder,
+                          replace_batch_with_group_norms=replace_batch_with_group_norms)
         self.encoder = backbone
         self.norm = 'gn' if replace_batch_with_group_norms else 'bn'
         self.device = torch.device(device)
@@ -143,6 +145,21 @@ class DeepLabV3Plus:
                 self._norm[k] = sd[k].detach().clone().cpu()
         self._dirty = True
 
+    def spawn(self):
+        """A second model with the same construction and learned state and its own (lazily built) engine -- for work
+        that runs beside this one on the same GPU (the objects of a sequence, `evaluate.object_workers`)."""
+        m = type(self)(max_batch=self.max_batch, device=str(self.device), **self._ctor)
+        m._flat.copy_(self._flat)
+        m._norm = OrderedDict((k, v.clone()) for k, v in self._norm.items())
+        m.training, m._dropout_off = self.training, self._dropout_off
+        return m
+
+    def set_wg_budget(self, workgroups):
+        """`eosvos_set_wg_budget` of this model's engine, now and whenever the engine is rebuilt."""
+        self.wg_budget = int(workgroups)
+        if self.engine is not None and hasattr(self.engine, 'set_wg_budget'):      # (CPU stand-ins of the tests have none)
+            self.engine.set_wg_budget(self.wg_budget)
+
     # ---- engine plumbing --------------------------------------------------------------------
     def _ensure_engine(self, height, width, batch):
         e = self.engine
@@ -162,6 +179,8 @@ class DeepLabV3Plus:
                     carry = e.get_params()
                 e.close()
             self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm)
+            if getattr(self, 'wg_budget', 0) and hasattr(self.engine, 'set_wg_budget'):
+                self.engine.set_wg_budget(self.wg_budget)
             self.max_batch = max(batch, self.max_batch)
             self._dirty = True
             if carry is not None:

@@ -85,6 +85,11 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
 int eosvos_destroy(eosvos_engine* e);
 int eosvos_synchronize(eosvos_engine* e);
 
+/* Debug aid.  With EOSVOS_DEBUG_GUARD=1 in the environment every device buffer of an engine is allocated between two
+ * 256 KB guard bands holding a pattern; this call waits for the device, reports on stderr every band a kernel wrote into
+ * (an out-of-bounds write) and returns the number of overwritten words (0 without the environment variable). */
+int eosvos_debug_check_guards(eosvos_engine* e);
+
 /* ---- state ------------------------------------------------------------------------ */
 /* Learned model initialisation (`model_init_*`, meta_optim.py:71-78): flat OIHW. */
 int eosvos_set_init(eosvos_engine* e, const float* flat_params);

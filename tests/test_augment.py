@@ -190,3 +190,39 @@ def test_meta_taskset_materialises_tasks_on_the_device(tmp_path):
     img, lab = ds.make_img_label_pair(it0['train_frame'])
     assert torch.equal(x0[0].cpu(), torch.from_numpy(img.transpose(2, 0, 1))) and torch.equal(y0[0, 0].cpu(), torch.from_numpy(lab))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_cubic_warp_is_stable_beside_another_engine():
+    """Regression: with its taps paired into packed-fp32 instructions the bicubic warp lost one tap in lanes 48..63 of
+    a wave whenever another engine's bf16x6 conv kernels shared the SIMD (20-30 % of 96x160 warps; first seen as
+    run-to-run differences of objects fine-tuned side by side).  The warp of one engine must be bit-stable while a
+    second engine, on its own stream, runs forward passes."""
+    from eosvos_amd import synthetic
+    from eosvos_amd.custom_transforms import INTER_CUBIC, warp_affine
+    from eosvos_amd.engine import Engine
+    H, W = SMALL
+    sd, lrs = synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50')
+    x, _ = synthetic.synthetic_frames(3, H, W, seed=5)
+    xg = x.to(DEV)
+    e0 = Engine('resnet50', H, W, max_batch=3, device=DEV)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        e1 = Engine('resnet50', H, W, max_batch=1, device=DEV)
+    e0.load_model_state(sd, lrs)
+    src = xg[0].clone()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(e1.stream):
+        ref = warp_affine(e1, src, 0, 17.0, 1.1, INTER_CUBIC)[0].clone()
+    torch.cuda.synchronize()
+    ref_np = augment.rot_and_sc(src.permute(1, 2, 0).cpu().numpy(), 17.0, 1.1, False)
+    assert np.abs(ref.permute(1, 2, 0).cpu().numpy() - ref_np).max() <= 2e-6
+    wrong = 0
+    for _ in range(150):
+        e0.forward(xg, want_logits=False)                      # enqueued on e0's stream, not waited for
+        with torch.cuda.stream(e1.stream):
+            got = warp_affine(e1, src, 0, 17.0, 1.1, INTER_CUBIC)[0].clone()
+        torch.cuda.synchronize()
+        wrong += int(not torch.equal(got, ref))
+    assert wrong == 0, f'{wrong} of 150 warps differ'
+    e0.close()
+    e1.close()

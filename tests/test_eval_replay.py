@@ -97,7 +97,7 @@ class ScenarioDataset:
         return lab
 
 
-def run_product(sc, tmp_path, monkeypatch):
+def run_product(sc, tmp_path, monkeypatch, objects_in_flight=None):
     cfg = config_mod.parse_cli([])
     cfg['seed'] = sc['seed']
     cfg['num_epochs']['eval'] = sc['eval_epochs']
@@ -140,7 +140,9 @@ def run_product(sc, tmp_path, monkeypatch):
         return prob_map(ds.current, obj, f, HW).view(1, 1, *HW)
 
     res = product_eval.evaluate_dataset(model, meta_optim, msd, ds, cfg, 'val', save_dir=str(tmp_path), meta_iter=3,
-                                        meta_epoch=1, best_mean_J=0.0)
+                                        meta_epoch=1, best_mean_J=0.0, objects_in_flight=objects_in_flight)
+    if objects_in_flight:
+        return events, res
     # events -> the same structure as parse_reference
     out = {}
     it = iter(events)
@@ -203,6 +205,29 @@ def test_evaluation_worker_replays_reference_event_log(sc, tmp_path, monkeypatch
         ck = torch.load(os.path.join(str(tmp_path), rel), map_location='cpu', weights_only=False)
         assert sorted(ck.keys()) == keys and ck['meta_iter'] == meta_iter
     assert {s[0] for s in saves} == {'last_val_meta_iter.model', 'best_val_meta_iter.model'}
+
+
+def test_objects_in_flight_replay_the_same_work(tmp_path, monkeypatch):
+    """`evaluate_dataset(objects_in_flight=2)`: the two objects of a sequence are fine-tuned side by side (one model /
+    engine each, steps interleaved at the points where the host would wait for a loss).  Per object the events -- seeds,
+    batches, pseudo-labels, restores, inference frames -- are those of the one-after-the-other run, and the merged
+    label maps, J and checkpoints are identical."""
+    sc = SCENARIOS[0]                                   # 'bear' has two objects, 'cows' one (falls back to sequential)
+    with monkeypatch.context() as m:
+        ev_seq, res_seq = run_product(sc, tmp_path / 'seq', m, objects_in_flight=1)
+    with monkeypatch.context() as m:
+        ev_con, res_con = run_product(sc, tmp_path / 'con', m, objects_in_flight=2)
+    assert res_con['J_seq'] == res_seq['J_seq'] and res_con['mean_J'] == res_seq['mean_J']
+    for seq in sc['seqs']:
+        assert torch.equal(res_con['labels'][seq], res_seq['labels'][seq])
+    # same multiset of events; the in-flight run interleaves the two objects of 'bear' (its forward batches alternate)
+    key = lambda e: json.dumps(e)
+    assert sorted(map(key, ev_con)) == sorted(map(key, ev_seq))
+    assert [e for e in ev_con if e[0] != 'seed'] != [e for e in ev_seq if e[0] != 'seed']
+    inf = [e[1] for e in ev_con if e[0] == 'infer'][:8]
+    assert inf[:8] == [1, 2, 3, 4, 1, 2, 3, 4]                           # 4 frames of object 0, then 4 of object 1, ...
+    for sub in ('seq', 'con'):
+        assert os.path.exists(tmp_path / sub / 'best_val_meta_iter.model')
 
 
 def test_schedule_function_matches_reference_rounds():

@@ -178,6 +178,37 @@ def test_online_adaptation_sequence(model_and_optim):
     assert set(labels.unique().tolist()) <= {0, 1, 2}
 
 
+def test_objects_in_flight_equal_one_after_the_other(model_and_optim):
+    """`evaluate.run_objects_in_flight`: the two objects of a sequence fine-tuned side by side (one spawned model /
+    engine / stream each, both planning for half the chip) give bit for bit what the same objects give one after the
+    other on one engine at that workgroup budget -- online adaptation, augmentation draws and snapshots included --
+    and the whole-chip run differs from it by summation order only."""
+    from eosvos_amd import config
+    from eosvos_amd.evaluate import finetune_object, object_workers, run_objects_in_flight
+    model, mo, msd = model_and_optim
+    cfg = config.parse_cli(['with', 'DAVIS-2017', 'e-OSVOS-OnA', 'num_epochs.eval=3', 'eval_online_adapt.num_epochs=2',
+                            'eval_online_adapt.step=3'])
+    H, W, N = SMALL[0], SMALL[1], 6
+    frames, gt = synthetic.synthetic_frames(1, H, W, seed=3, second_object=True)
+    seq = torch.cat([torch.roll(frames, shifts=4 * i, dims=3) for i in range(N)]).to(DEV)
+    rows = torch.arange(H).view(-1, 1)
+    objs = [(gt[0] * (rows < H // 2)).float(), (gt[0] * (rows >= H // 2)).float()]
+    workers = object_workers(model, mo, MO_CFG, 2)
+    assert workers[0].model is model and workers[1].model is not model and workers[1].stream != workers[0].stream
+    res = run_objects_in_flight(workers, msd, seq, objs, cfg)
+    assert model.engine.set_wg_budget(256) == 256 and workers[1].model.engine is not model.engine
+    torch.cuda.synchronize()
+    one = [finetune_object(model, mo, msd, seq, g, cfg) for g in objs]              # same budget, one engine
+    for (p2, h2), (p1, h1) in zip(res, one):
+        assert h2 == h1 and torch.equal(p2, p1)
+    model.set_wg_budget(0)
+    whole = [finetune_object(model, mo, msd, seq, g, cfg) for g in objs]
+    for (p2, _), (p0, _) in zip(res, whole):
+        assert float((p2 - p0).abs().max()) < 1e-3
+    for w in workers[1:]:
+        w.model.engine.close()
+
+
 def test_train_meta_entry_points(tmp_path):
     from eosvos_amd import train_meta
     from eosvos_amd.checkpoint import load_meta_checkpoint

@@ -647,6 +647,47 @@ def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weight
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('budget', [0, 256])
+def test_trajectory_is_bit_stable_beside_another_engine(weights, budget):
+    """Two engines on two streams of one GPU, batch-3 fine-tune iterations + inference enqueued alternately with no host
+    wait in between: each engine's parameters and probabilities equal, bit for bit, what it produces alone."""
+    from eosvos_amd.engine import Engine
+    x, y = synthetic.synthetic_frames(3, *SMALL, seed=21)
+    xg, yg = x.to(DEV), y.to(DEV)
+    engs = []
+    for i in range(2):
+        with torch.cuda.stream(torch.cuda.Stream() if i else torch.cuda.current_stream()):
+            e = Engine('resnet50', *SMALL, max_batch=3, device=DEV)
+            e.set_wg_budget(budget)
+        engs.append(e)
+
+    def run(which):
+        for e in which:
+            with torch.cuda.stream(e.stream):
+                e.load_model_state(*weights)
+        torch.cuda.synchronize()
+        probs = {id(e): [] for e in which}
+        for _ in range(3):
+            for e in which:
+                with torch.cuda.stream(e.stream):
+                    e.finetune_step(xg, yg, sync_loss=False)
+                    probs[id(e)].append(e.infer(xg[1:2].contiguous()))
+        out = []
+        for e in which:
+            e.synchronize()
+            out.append((e.get_params().clone(), torch.stack(probs[id(e)]).clone()))
+        torch.cuda.synchronize()
+        return out
+    solo = [run([e])[0] for e in engs]
+    both = run(engs)
+    for (p1, q1), (p2, q2) in zip(solo, both):
+        assert torch.equal(p1, p2) and torch.equal(q1, q2)
+    assert torch.equal(solo[0][0], solo[1][0])
+    for e in engs:
+        e.close()
+
+
+@pytest.mark.gpu
 def test_wg_budget_changes_rounding_only(small_engine, weights):
     """`eosvos_set_wg_budget`: an engine that plans its launches for half the chip (what engines sharing a GPU use)
     gives the same fine-tune trajectory up to the order of the split reductions; the budget is clamped to the
