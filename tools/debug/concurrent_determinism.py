@@ -15,7 +15,7 @@ for i in range(2):
         e.load_model_state(sd, lrs)
     engs.append(e)
 torch.cuda.synchronize()
-def run(which, steps=4):
+def run(which, steps=int(sys.argv[4]) if len(sys.argv) > 4 else 4):
     for e in which:
         with torch.cuda.stream(e.stream):
             e.load_model_state(sd, lrs)
