@@ -654,7 +654,7 @@ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 
 extern "C" {
 
-const char* eosvos_version(void) { return "eosvos-mi355x 0.2 (gfx950, fp32 implicit GEMM on the bf16 matrix cores: exact 3-way split, 6 partial products)"; }
+const char* eosvos_version(void) { return "eosvos-mi355x 0.3 (gfx950, fp32 implicit GEMM on the bf16 matrix cores: exact 3-way split, 6 partial products)"; }
 const char* eosvos_last_error(void) { return g_err.c_str(); }
 
 int eosvos_set_matrix_mode(int mode) {
