@@ -666,7 +666,9 @@ int eosvos_get_matrix_mode(void) { return conv_mfma_mode(); }
 int eosvos_set_wg_budget(eosvos_engine* e, int workgroups) {
   if (!e) { fail("null engine"); return -1; }
   if (workgroups < 0) { fail("workgroup budget must be >= 0"); return -1; }
-  e->wg_budget = conv_clamp_wg_budget(workgroups);
+  const int b = conv_clamp_wg_budget(workgroups);
+  if (b == e->wg_budget) return b;
+  e->wg_budget = b;
   for (auto& tab : e->upd_tab) tab = nullptr;      // the update tables carry the split counts of the old budget
   return e->wg_budget;
 }

@@ -51,10 +51,8 @@ class MetaTrainer:
         self.engines = [engine] + list(extra_engines)
         # engines that share the GPU plan each launch for part of the chip (`eosvos_set_wg_budget`): less K splitting,
         # fewer parked partial tiles; the other tasks' launches fill the remaining CUs
-        budget = int(os.environ.get('EOSVOS_META_WG_BUDGET', CONCURRENT_WG_BUDGET.get(min(len(self.engines), 4), 0)))
-        for e in self.engines:
-            if hasattr(e, 'set_wg_budget'):
-                e.set_wg_budget(budget)
+        self.wg_budget = int(os.environ.get('EOSVOS_META_WG_BUDGET', CONCURRENT_WG_BUDGET.get(min(len(self.engines), 4), 0)))
+        self._apply_wg_budget()
         self.level, self.use_log = lr_hierarchy_level, bool(use_log_init_lr)
         self.n_lr = engine.lr_store_count(lr_hierarchy_level)        # NotImplementedError for unknown levels
         engine.set_loss(loss_func)
@@ -177,11 +175,18 @@ class MetaTrainer:
         return meta_loss
 
     # ---- one meta-iteration --------------------------------------------------------------
+    def _apply_wg_budget(self):
+        """(Re)apply the budget: the first engine is the model's and an evaluation in between may have changed it."""
+        for e in self.engines:
+            if hasattr(e, 'set_wg_budget'):
+                e.set_wg_budget(self.wg_budget)
+
     def run_tasks_concurrent(self, tasks, inner_steps):
         """The default schedule (one meta frame after `inner_steps` steps) for several tasks at once, task i on engine
         i % n: every call is enqueued without waiting, one synchronisation at the end.  NaN tasks are skipped as in
         run_task.  Returns the meta losses."""
         n = len(self.engines)
+        self._apply_wg_budget()
         if not hasattr(self, '_task_grads'):
             self._task_grads = [torch.zeros_like(self.grad) for _ in range(n)]
         losses = []
