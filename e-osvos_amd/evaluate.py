@@ -135,10 +135,13 @@ def finetune_object_steps(model, meta_optim, meta_optim_state_dict, frames, gt, 
         if r == 0:
             model.engine.snapshot()             # model_state_dict_first_step (evaluate.py:283-287)
         model.eval()
-        for f in range(rd['eval_min'], rd['eval_max']):
-            masks[f] = model.engine.infer(frames[f:f + 1].contiguous())[0]
-            if (f - rd['eval_min']) % 4 == 3:
-                yield
+        # the reference predicts frame by frame (`test` batch size 1, evaluate.py:293-314); frozen normalisation makes
+        # the frames of a batch independent, and a batch of 3 costs 1.40 ms per frame instead of 2.30 at 480x854
+        nb = max(1, int(getattr(model.engine, 'max_batch', 1)))
+        for f in range(rd['eval_min'], rd['eval_max'], nb):
+            g = min(f + nb, rd['eval_max'])
+            masks[f:g] = model.engine.infer(frames[f:g].contiguous())
+            yield
     return masks[:, 0], hist
 
 
