@@ -23,6 +23,11 @@ import torch
 from .helper_func import compute_loss, early_stopping, set_random_seeds
 
 
+# frames predicted per inference launch (`evaluate_dataset` sizes its engines for it; engines sized elsewhere use what
+# they have)
+INFER_BATCH = int(os.environ.get('EOSVOS_INFER_BATCH', 8))
+
+
 def online_adapt_schedule(num_frames, train_frame_id, step, train_batch_size):
     """Frame ranges and propagated frames per round (`evaluate.py:140-193,231-240`)."""
     rounds = []
@@ -136,8 +141,8 @@ def finetune_object_steps(model, meta_optim, meta_optim_state_dict, frames, gt, 
             model.engine.snapshot()             # model_state_dict_first_step (evaluate.py:283-287)
         model.eval()
         # the reference predicts frame by frame (`test` batch size 1, evaluate.py:293-314); frozen normalisation makes
-        # the frames of a batch independent, and a batch of 3 costs 1.40 ms per frame instead of 2.30 at 480x854
-        nb = max(1, int(getattr(model.engine, 'max_batch', 1)))
+        # the frames of a batch independent, and at 480x854 a batch of 3 costs 1.40 ms per frame, one of 8 1.16, one 2.30
+        nb = max(1, min(int(getattr(model.engine, 'max_batch', 1)), INFER_BATCH))
         for f in range(rd['eval_min'], rd['eval_max'], nb):
             g = min(f + nb, rd['eval_max'])
             masks[f:g] = model.engine.infer(frames[f:g].contiguous())
@@ -272,6 +277,15 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     set_random_seeds(cfg.get('seed', 1))                                        # evaluate.py:42
     if objects_in_flight is None:
         objects_in_flight = int(os.environ.get('EOSVOS_OBJECTS_IN_FLIGHT', 3 if torch.device(device or model.device).type == 'cuda' else 1))
+    if torch.device(device or model.device).type == 'cuda' and model.max_batch < INFER_BATCH:
+        # size the engine(s) for the inference batch before any object starts (a fine-tune never needs the old engine's
+        # weights: every object begins with load_state_dict + reset)
+        model.max_batch = INFER_BATCH
+        if model.engine is not None and model.engine.max_batch < INFER_BATCH:
+            model.engine.close()
+            model.engine = None
+            model._dirty = True
+        model._object_workers = None
     workers = None
     if objects_in_flight > 1:
         workers = getattr(model, '_object_workers', None)
