@@ -60,10 +60,17 @@ class FirstFrameAugmenter:
         self.engine, self.rng = engine, rng
         self.flip, self.snr = RandomHorizontalFlip(), RandomScaleNRotate(rots, scales)
 
-    def sample(self, frame, label, out_image=None, out_label=None):
+    @staticmethod
+    def has_object(label):
+        """num_labels > 1 for a binary mask: both object and background pixels."""
+        nz = int((label != 0).sum())
+        return 0 < nz < label.numel()
+
+    def sample(self, frame, label, out_image=None, out_label=None, has_object=None):
         """frame (3,H,W), label (1,H,W) device tensors -> (image, label, params)."""
         flip = self.flip.draw(self.rng)
-        has_object = bool((label != 0).any()) and bool((label == 0).any())     # num_labels > 1 for a binary mask
+        if has_object is None:
+            has_object = self.has_object(label)
         total = label.numel()
         tries = 0
         while True:
@@ -81,5 +88,6 @@ class FirstFrameAugmenter:
         dev = frame.device
         images = torch.empty(batch_size, *frame.shape, device=dev)
         labels = torch.empty(batch_size, *label.shape, device=dev)
-        params = [self.sample(frame, label, images[b], labels[b])[2] for b in range(batch_size)]
+        has_object = self.has_object(label)                   # one host read for the batch, not two per sample
+        params = [self.sample(frame, label, images[b], labels[b], has_object)[2] for b in range(batch_size)]
         return images, labels, params

@@ -114,18 +114,22 @@ def finetune_object_steps(model, meta_optim, meta_optim_state_dict, frames, gt, 
         num_epochs = cfg['num_epochs']['eval'] if r == 0 else ona['num_epochs']
         model.train_without_dropout()
         round_hist = []
+        if r > 0:
+            # the adaptation batch of this round: train frame + the propagated frames whose thresholded prediction is
+            # not empty (evaluate.py:231-240).  The reference rebuilds it every epoch from the same masks; once is enough.
+            round_inputs, round_gts = frames[train_frame_id:train_frame_id + 1], gt
+            for f in rd['propagate_frames']:
+                pg = masks[f:f + 1].ge(ona['min_prop']).float()
+                if pg.sum().item() != 0:                            # evaluate.py:239
+                    round_inputs = torch.cat([round_inputs, frames[f:f + 1]])
+                    round_gts = torch.cat([round_gts, pg])
+            round_inputs, round_gts = round_inputs.contiguous(), round_gts.contiguous()
         for epoch in range(1, num_epochs + 1):
             set_random_seeds(cfg.get('seed', 1) + epoch + r)
             if r == 0:
                 inputs, gts = augment(frames[train_frame_id:train_frame_id + 1], gt, bsz, cfg.get('seed', 1) + epoch)
             else:
-                inputs, gts = frames[train_frame_id:train_frame_id + 1], gt
-                for f in rd['propagate_frames']:
-                    pg = masks[f:f + 1].ge(ona['min_prop']).float()
-                    if pg.sum().item() != 0:                        # evaluate.py:239
-                        inputs = torch.cat([inputs, frames[f:f + 1]])
-                        gts = torch.cat([gts, pg])
-                inputs, gts = inputs.contiguous(), gts.contiguous()
+                inputs, gts = round_inputs, round_gts
             outputs = model(inputs)
             train_loss = compute_loss(loss_func, outputs[-1], gts)     # a device scalar: no host wait yet
             model.zero_grad()
