@@ -50,7 +50,11 @@ class MetaOptimizer:
         if lr_hierarchy_level not in ('SINGLE', 'TENSOR', 'NEURON', 'PARAM'):
             raise NotImplementedError                   # meta_optim.py:68-69
         if second_order_gradients:
-            raise NotImplementedError('second_order_gradients=True needs double backward')
+            # the reference cannot run this on the DeepLab path either: step() calls
+            # model.named_parameters_without_second_order_derivate() (meta_optim.py:195), which only the Mask R-CNN
+            # model defines (mask_rcnn.py:536-543) -- DeepLabV3Plus raises AttributeError there
+            raise NotImplementedError('second_order_gradients=True needs a double backward through every kernel (and is '
+                                      'not reachable for DeepLabV3Plus in the reference: meta_optim.py:195)')
         self._max_lr = max_lr
         self._learn_model_init = bool(learn_model_init)
         self._lr_hierarchy_level = lr_hierarchy_level
