@@ -357,17 +357,23 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         for e2 in others:
             e2.close()
     if not a.no_meta:
-        # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4]), tasks in flight together
+        # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4]), tasks in flight together.
+        # An extra of this line: a failure here (every rank raises alike: the only rank-dependent step is the all-reduce)
+        # is recorded, not allowed to take the headline with it.
         tpr = a.tasks_per_rank
-        mt, mstep, _, extra_eng = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory or Engine)
-        mstep()                                                             # warm-up
-        n_it = 4
-        dtm = timed(mstep, n_it, barrier, dist, dev)
-        extra['meta_tasks_per_sec'] = world * tpr * n_it / dtm
-        extra['meta_config'] = (f'meta_batch_size={world * tpr} ({tpr} tasks per GPU in flight on one engine each), 5 inner steps + '
-                                f'1 meta frame, batch 1, {H}x{W}')
-        for e in extra_eng:
-            e.close()
+        try:
+            mt, mstep, _, extra_eng = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory or Engine)
+            mstep()                                                             # warm-up
+            n_it = 4
+            dtm = timed(mstep, n_it, barrier, dist, dev)
+            extra['meta_tasks_per_sec'] = world * tpr * n_it / dtm
+            extra['meta_config'] = (f'meta_batch_size={world * tpr} ({tpr} tasks per GPU in flight on one engine each), 5 inner steps + '
+                                    f'1 meta frame, batch 1, {H}x{W}')
+            for e in extra_eng:
+                e.close()
+        except Exception as exc:                                                # noqa: BLE001
+            extra['meta_tasks_per_sec'] = None
+            extra['meta_error'] = f'{type(exc).__name__}: {exc}'
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
