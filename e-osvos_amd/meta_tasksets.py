@@ -16,6 +16,7 @@ parameters from `random` (`custom_transforms.py:26-33,193-194`); the colour jitt
 Mask R-CNN-only options (`random_box_coord_perm`, `random_object_id_sub_group`, `single_obj_seq_mode` AUGMENT_*)
 raise NotImplementedError.
 """
+import copy
 import random
 
 import numpy as np
@@ -115,14 +116,36 @@ class MetaTaskset:
         return item
 
     # ---- materialisation ------------------------------------------------------------------------------
-    def _frame(self, item, frame_id, engine, device):
-        ds = self.dataset
+    def load_frames(self, item):
+        """The host half of `task_tensors`: decode every frame of the task and apply its colour jitter.  No random draw
+        and no device work happen here, and the dataset is used through a private shallow copy, so this can run on a
+        worker thread while the GPU is busy with the previous meta-iteration (`train_meta` prefetches one iteration
+        ahead).  -> {frame_id: (image HxWx3 float32, label HxW float32)}."""
+        ds = copy.copy(self.dataset)
         ds.set_seq(item['seq_name'])
         ds.multi_object_id = item['obj_id']
-        img, label = ds.make_img_label_pair(frame_id)
+        ds._label_id = None
+        out = {}
+        for frame_id in [item['train_frame']] + list(item['meta_frames']):
+            if frame_id in out:
+                continue
+            img, label = ds.make_img_label_pair(frame_id)
+            if item['transform'] is not None:
+                img = item['transform']['color'](img)
+            out[frame_id] = (img, label)
+        return out
+
+    def _frame(self, item, frame_id, engine, device, host=None):
         tr = item['transform']
-        if tr is not None:
-            img = tr['color'](img)
+        if host is not None and frame_id in host:
+            img, label = host[frame_id]
+        else:
+            ds = self.dataset
+            ds.set_seq(item['seq_name'])
+            ds.multi_object_id = item['obj_id']
+            img, label = ds.make_img_label_pair(frame_id)
+            if tr is not None:
+                img = tr['color'](img)
         x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))).to(device)
         y = torch.from_numpy(label[None].copy()).to(device)
         if item['flip_label']:
@@ -145,12 +168,13 @@ class MetaTaskset:
             y = lab
         return x, y
 
-    def task_tensors(self, item, engine, device):
+    def task_tensors(self, item, engine, device, host=None):
         """-> (x_train (B,3,H,W), y_train (B,1,H,W), x_meta (Bm,3,H,W), y_meta (Bm,1,H,W)) on `device`: the train frame
-        repeated `batch_sizes.train` times (EpochSampler, `helper_func.py:521-545`) and the meta frames."""
+        repeated `batch_sizes.train` times (EpochSampler, `helper_func.py:521-545`) and the meta frames.  `host`: the
+        result of `load_frames(item)` when it was prepared ahead of time."""
         bt = self.data_cfg['batch_sizes']['train']
-        xt, yt = self._frame(item, item['train_frame'], engine, device)
-        xs, ys = zip(*[self._frame(item, f, engine, device) for f in item['meta_frames']])
+        xt, yt = self._frame(item, item['train_frame'], engine, device, host)
+        xs, ys = zip(*[self._frame(item, f, engine, device, host) for f in item['meta_frames']])
         return (xt.unsqueeze(0).expand(bt, -1, -1, -1).contiguous(), yt.unsqueeze(0).expand(bt, -1, -1, -1).contiguous(),
                 torch.stack(xs).contiguous(), torch.stack(ys).contiguous())
 

@@ -177,15 +177,32 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
     set_random_seeds(cfg['seed'] + rank)                                    # meta_run.py:30
     tasksets = _train_tasksets(cfg, data_root)
     order, epoch = [], 0
-    for it in range(num_meta_iters):
-        tasks = []
-        if tasksets is not None:
+    pool = prefetched = None
+    if tasksets is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=2)
+
+        def draw_and_prefetch():
+            """The next sub-batch of this rank: the items (every random draw, on this thread, in order) and the decoding
+            + colour jitter of their frames, started on the pool so that they run beside the GPU's current iteration."""
+            nonlocal order, epoch
             if not order:                                                   # one worker's shuffled DataLoader, meta_run.py:76-85
                 order = task_order(len(tasksets), sub, cfg['seed'] + rank, epoch)
                 epoch += 1
+            out = []
             for idx in order.pop(0):
                 ts, i = tasksets.locate(idx)
-                tasks.append(ts.task_tensors(ts[i], eng, dev))
+                item = ts[i]
+                out.append((ts, item, pool.submit(ts.load_frames, item)))
+            return out
+        prefetched = draw_and_prefetch()
+    for it in range(num_meta_iters):
+        tasks = []
+        if tasksets is not None:
+            current = prefetched
+            tasks = [ts.task_tensors(item, eng, dev, host=fut.result()) for ts, item, fut in current]
+            if it + 1 < num_meta_iters:
+                prefetched = draw_and_prefetch()
         else:
             for t in range(rank, cfg['meta_batch_size'], world):           # synthetic: task t of the meta-batch
                 x, y = synthetic.synthetic_frames(1, height, width, seed=1000 + t + cfg['meta_batch_size'] * (meta_iter + it))
@@ -203,6 +220,8 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
                     tmp = os.path.join(run_dir, 'eval_snapshot.tmp')
                     save_meta_checkpoint(tmp, mt.state_dict(), done, 0)
                     os.replace(tmp, os.path.join(run_dir, 'eval_snapshot.model'))
+    if pool is not None:
+        pool.shutdown(wait=True)
     if eval_proc is not None:
         open(os.path.join(run_dir, 'eval_stop'), 'w').close()
         eval_proc.wait()

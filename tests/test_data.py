@@ -128,6 +128,26 @@ def test_youtube_reader_and_meta_taskset(youtube_root):
     assert out.shape == img.shape and 0.0 <= out.min() and out.max() <= 1.0 and np.abs(out - img).max() < 0.5
     for name, f in cj.ops:
         assert (-0.1 <= f <= 0.1) if name == 'hue' else (0.8 <= f <= 1.2)
+    # the host half of a task (decode + colour jitter), as train_meta prefetches it on a worker thread: same pixels as the
+    # direct path, the shared dataset object is left alone, and without a per-task transform the whole task materialises
+    # from it (no engine needed)
+    from concurrent.futures import ThreadPoolExecutor
+    item = ts[2]
+    ds.set_seq('a00')
+    ds.multi_object_id = 0
+    with ThreadPoolExecutor(1) as pool:
+        host = pool.submit(ts.load_frames, item).result()
+    assert ds.seq_key == 'a00' and ds.multi_object_id == 0
+    assert sorted(host) == sorted({item['train_frame'], *item['meta_frames']})
+    ds.set_seq('b01')
+    ds.multi_object_id = 1
+    for f, (img_h, lab_h) in host.items():
+        img_d, lab_d = ds.make_img_label_pair(f)
+        assert np.array_equal(img_h, item['transform']['color'](img_d)) and np.array_equal(lab_h, lab_d)
+    it0 = ts_eps[1]
+    got = ts_eps.task_tensors(it0, None, 'cpu', host=ts_eps.load_frames(it0))
+    ref = ts_eps.task_tensors(it0, None, 'cpu')
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)) and got[0].shape[0] == cfg['data_cfg']['batch_sizes']['train']
     # a worker's shuffled sub-batches cover every task once per pass
     both = ConcatTaskset([ts, ts_eps])
     assert len(both) == 6 and both.locate(4) == (ts_eps, 1)

@@ -230,6 +230,38 @@ def test_train_meta_entry_points(tmp_path):
     assert mt.step == 1
 
 
+def test_train_meta_on_dataset_files(tmp_path, capsys):
+    """`train_meta.main` in meta-train mode on a DAVIS-2017 tree on disk: `MetaTaskset` sampling, the one-iteration-ahead
+    prefetch of decoding + colour jitter on a worker thread, device-side flip / scale-rotate, three meta-iterations of two
+    tasks in flight."""
+    import json
+    from PIL import Image
+    from eosvos_amd import train_meta
+    root = tmp_path / 'data' / 'DAVIS-2017'
+    rng = np.random.default_rng(0)
+    for seq in ('bear', 'camel'):
+        (root / 'JPEGImages' / '480p' / seq).mkdir(parents=True)
+        (root / 'Annotations' / '480p' / seq).mkdir(parents=True)
+        for f in range(5):
+            Image.fromarray(rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)).save(root / 'JPEGImages' / '480p' / seq / f'{f:05d}.jpg')
+            lab = np.zeros((96, 160), np.uint8)
+            lab[30:60, 50 + 3 * f:100 + 3 * f] = 1
+            if seq == 'camel':
+                lab[70:90, 20:60] = 2
+            Image.fromarray(lab, mode='L').save(root / 'Annotations' / '480p' / seq / f'{f:05d}.png')
+    (root / 'train_seqs.txt').write_text('bear\ncamel\n')
+    capsys.readouterr()
+    mt = train_meta.main(['with', 'DAVIS-2017', 'meta_batch_size=2', 'num_epochs.train=2', 'datasets.train.eval=False',
+                          f'save_dir={tmp_path}', 'env_suffix=files'], height=96, width=160, num_meta_iters=3,
+                         data_root=str(tmp_path / 'data'), eval_cmd=False)
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith('{')]
+    assert [l['meta_iter'] for l in lines] == [1, 2, 3] and all(l['data'] == 'files' for l in lines)
+    # 3 tasks (bear, camel x 2 objects) in sub-batches of 2: a pass is [2, 1], then the next pass starts
+    assert [len(l['meta_losses']) for l in lines] == [2, 1, 2], lines
+    assert all(np.isfinite(v) for l in lines for v in l['meta_losses'])
+    assert mt.step == 3 and mt.skipped_tasks == 0 and len(mt.engines) == 2
+
+
 @pytest.mark.parametrize('level,use_log', [('TENSOR', True), ('SINGLE', False)])
 def test_reference_style_meta_task_other_levels(golden_dir, level, use_log):
     """The meta_run.py:121-214 call sequence with `lr_hierarchy_level` TENSOR / SINGLE and
