@@ -84,14 +84,18 @@ class DAVIS:
 
     def make_img_label_pair(self, idx):                          # vos_dataset.py:224-322
         img = np.array(Image.open(self.imgs[idx]).convert('RGB'), dtype=np.float32)
+        if self.normalize:
+            img = img - np.array(self.mean_val, dtype=np.float32)
+        img = img / 255.0
+        return img, self.make_label(idx)
+
+    def make_label(self, idx):
+        """The label half of `make_img_label_pair` (the frame-selection loop only needs this one: no JPEG decode)."""
         if self._label_id is not None:                           # vos_dataset.py:235-242
             label = Image.open(self.labels[self._label_id])
         else:
             label = Image.open(self.labels[0] if self.test_mode else self.labels[idx])
         label = np.array(np.atleast_3d(label)[..., 0], dtype=np.float32)
-        if self.normalize:
-            img = img - np.array(self.mean_val, dtype=np.float32)
-        img = img / 255.0
         if self.multi_object and self.num_objects > 1:
             if self.multi_object != 'single_id':
                 raise NotImplementedError("multi_object='all' (object groups) is a Mask R-CNN path")
@@ -104,7 +108,7 @@ class DAVIS:
                 label = (label == oid).astype(np.float32) if oid in unique_labels else np.zeros_like(label)
         else:
             label = np.where(label != 0.0, 1.0, 0.0).astype(np.float32)
-        return img, label
+        return label
 
     def __len__(self):
         return 1 if self.frame_id is not None else len(self.imgs)
@@ -153,7 +157,7 @@ class DAVIS:
         return torch.randint(n, (1,)).item()
 
     def has_frame_object(self, frame_id):                        # vos_dataset.py:118-122
-        _, label = self.make_img_label_pair(frame_id)
+        label = self.make_label(frame_id)
         return len([l for l in np.unique(label) if l != 0.0]) == self.num_objects_in_group
 
     def get_random_frame_id_with_label(self):                    # vos_dataset.py:124-142: redraw until the object is visible

@@ -180,7 +180,8 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
     pool = prefetched = None
     if tasksets is not None:
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=2)
+        # EOSVOS_META_PREFETCH=0: decode on the main thread at the start of every iteration (for A/B timing)
+        pool = ThreadPoolExecutor(max_workers=2) if os.environ.get('EOSVOS_META_PREFETCH', '1') != '0' else None
 
         def draw_and_prefetch():
             """The next sub-batch of this rank: the items (every random draw, on this thread, in order) and the decoding
@@ -193,14 +194,14 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
             for idx in order.pop(0):
                 ts, i = tasksets.locate(idx)
                 item = ts[i]
-                out.append((ts, item, pool.submit(ts.load_frames, item)))
+                out.append((ts, item, pool.submit(ts.load_frames, item) if pool else None))
             return out
         prefetched = draw_and_prefetch()
     for it in range(num_meta_iters):
         tasks = []
         if tasksets is not None:
             current = prefetched
-            tasks = [ts.task_tensors(item, eng, dev, host=fut.result()) for ts, item, fut in current]
+            tasks = [ts.task_tensors(item, eng, dev, host=fut.result() if fut else None) for ts, item, fut in current]
             if it + 1 < num_meta_iters:
                 prefetched = draw_and_prefetch()
         else:

@@ -10,12 +10,13 @@ from eosvos_amd.helper_func import init_parent_model
 from eosvos_amd.meta_optim import MetaOptimizer
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 70
+NSEQ = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 H, W = 480, 854
 for name, extra in (('e-OSVOS-50', ['num_epochs.eval=50']),
                     ('e-OSVOS-100-OnA', ['e-OSVOS-OnA', 'num_epochs.eval=100', 'eval_online_adapt.num_epochs=10', 'eval_online_adapt.step=5'])):
     cfg = config.parse_cli(['with', 'DAVIS-2017', 'e-OSVOS'] + extra)
     cfg['datasets']['val'] = dict(cfg['datasets'].get('val', {}), name='synthetic', split='val', eval=True)
-    ds = data.SyntheticSequences(1, N, H, W, seed=3)
+    ds = data.SyntheticSequences(NSEQ, N, H, W, seed=3)
     for in_flight, infer_batch in ((1, 1), (1, 8), (3, 8)):
         ev.INFER_BATCH = infer_batch
         model, _ = init_parent_model(**dict(cfg['parent_model']))
@@ -30,7 +31,7 @@ for name, extra in (('e-OSVOS-50', ['num_epochs.eval=50']),
         res = ev.evaluate_dataset(model, mo, msd, ds, cfg, 'val', objects_in_flight=in_flight)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(json.dumps({'config': name, 'frames': N, 'objects': 2, 'objects_in_flight': in_flight, 'inference_batch': infer_batch,
-                          'seconds_per_sequence': round(dt, 3), 'seconds_per_object': round(dt / 2, 3),
+                          'sequences': NSEQ, 'seconds_per_sequence': round(dt / NSEQ, 3), 'seconds_per_object': round(dt / NSEQ / 2, 3),
                           'ms_per_object_frame': round(1e3 * res['time_per_frame'], 2), 'mean_J': round(res['mean_J'], 4)}), flush=True)
         for w in getattr(model, '_object_workers', None) or []:
             if w.model.engine is not None:
