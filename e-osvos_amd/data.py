@@ -67,6 +67,10 @@ class DAVIS:
     def seqs_names(self):
         return list(self.seqs.keys())
 
+    # all per-sequence state lives in plain attributes: a shallow copy is an independent cursor over the same file lists,
+    # which is how `evaluate_dataset` / `MetaTaskset.load_frames` read ahead on worker threads
+    prefetchable = True
+
     def set_seq(self, seq_name):                                 # vos_dataset.py:170-175
         self.imgs, self.labels = self.seqs[seq_name]['imgs'], self.seqs[seq_name]['labels']
         self.seq_key, self._num_objects = seq_name, None
@@ -83,11 +87,13 @@ class DAVIS:
         return self._num_objects
 
     def make_img_label_pair(self, idx):                          # vos_dataset.py:224-322
+        return self.make_image(idx), self.make_label(idx)
+
+    def make_image(self, idx):
         img = np.array(Image.open(self.imgs[idx]).convert('RGB'), dtype=np.float32)
         if self.normalize:
             img = img - np.array(self.mean_val, dtype=np.float32)
-        img = img / 255.0
-        return img, self.make_label(idx)
+        return img / 255.0
 
     def make_label(self, idx):
         """The label half of `make_img_label_pair` (the frame-selection loop only needs this one: no JPEG decode)."""
@@ -127,7 +133,7 @@ class DAVIS:
         """(frames (N,3,H,W), [first-frame mask (1,H,W) per object]) of one sequence, ready for
         `evaluate.evaluate_sequence`."""
         self.set_seq(seq_name)
-        frames = torch.stack([torch.from_numpy(self.make_img_label_pair(i)[0].transpose(2, 0, 1)) for i in range(len(self.imgs))])
+        frames = torch.stack([torch.from_numpy(self.make_image(i).transpose(2, 0, 1)) for i in range(len(self.imgs))])
         gts = []
         for o in range(self.num_objects):
             self.multi_object_id = o

@@ -296,8 +296,35 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         if workers is None or len(workers) != objects_in_flight or workers[0].meta_optim is not meta_optim:
             workers = model._object_workers = object_workers(model, meta_optim, cfg['meta_optim_cfg'], objects_in_flight)
     J_seq, labels_out, item, eval_time, num_frames = [], {}, 0, 0.0, 0
-    for seq in dataset.seqs_names:
-        frames, gts = dataset.sequence_tensors(seq, device or model.device)
+    # File readers (`prefetchable`) are used through shallow copies on two worker threads: sequence k + 1 is decoded while
+    # sequence k is fine-tuned, and the PNGs / J of sequence k are written while k + 1 runs (PIL releases the GIL).
+    # EOSVOS_EVAL_PREFETCH=0 keeps everything on the calling thread.
+    import copy
+    from concurrent.futures import ThreadPoolExecutor
+    seqs = list(dataset.seqs_names)
+    pool = None
+    if getattr(dataset, 'prefetchable', False) and seqs and os.environ.get('EOSVOS_EVAL_PREFETCH', '1') != '0':
+        pool = ThreadPoolExecutor(max_workers=2)
+    load = lambda sq: copy.copy(dataset).sequence_tensors(sq, 'cpu')
+    ahead = pool.submit(load, seqs[0]) if pool else None
+    finishing = []
+
+    def finish(ds, sq, labels, n_obj):
+        """PNG files + J of one finished sequence (host only)."""
+        if rank == 0 and preds_dir is not None:
+            names = ds.frame_names(sq)
+            for f in range(labels.shape[0]):
+                save_label_png(os.path.join(preds_dir, sq, names[f] + '.png'), labels[f].numpy())
+        return 0.0 if ds.test_mode else sequence_J(labels.numpy(), ds.label_maps(sq), n_obj)     # evaluate.py:344-346
+
+    for k, seq in enumerate(seqs):
+        if pool:
+            frames, gts = ahead.result()
+            frames, gts = frames.to(device or model.device), [g.to(device or model.device) for g in gts]
+            if k + 1 < len(seqs):
+                ahead = pool.submit(load, seqs[k + 1])
+        else:
+            frames, gts = dataset.sequence_tensors(seq, device or model.device)
         n = frames.shape[0]
         probs = torch.zeros(len(gts), n, *frames.shape[-2:], device=frames.device)
         t0 = time.perf_counter()
@@ -323,16 +350,16 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
             model._ensure_engine(frames.shape[2], frames.shape[3], 1)
         labels = merge_objects(model.engine, [probs[o] for o in range(len(gts))]).cpu()
         labels_out[seq] = labels
-        if rank == 0 and preds_dir is not None:
-            names = dataset.frame_names(seq)
-            for f in range(n):
-                save_label_png(os.path.join(preds_dir, seq, names[f] + '.png'), labels[f].numpy())
-        if dataset.test_mode:
-            J_seq.append(0.0)                                                   # evaluate.py:344-346
+        if pool:
+            finishing.append(pool.submit(finish, copy.copy(dataset), seq, labels, len(gts)))
         else:
-            J_seq.append(sequence_J(labels.numpy(), dataset.label_maps(seq), len(gts)))
+            finishing.append(finish(dataset, seq, labels, len(gts)))
+    for seq, j in zip(seqs, finishing):
+        J_seq.append(j.result() if pool else j)
         if log is not None and rank == 0:
             log(f"{dataset_key}: {seq} [{J_seq[-1]}]")
+    if pool:
+        pool.shutdown(wait=True)
     mean_J = float(np.mean(J_seq)) if J_seq else 0.0
     out_best = best_mean_J
     if rank == 0 and save_dir is not None and not dataset.test_mode:
