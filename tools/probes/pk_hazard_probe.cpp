@@ -1,0 +1,148 @@
+// Stand-alone reproducer for DESIGN.md 5c: a kernel whose packed-fp32 (v_pk_mul_f32) operands are register pairs filled by
+// two separate global_load_dword, run on one stream while a bf16 MFMA 32x32x16 kernel with 256 VGPRs per wave (the bf16x6
+// conv loop, tools/probes/x6_phases_probe.cpp) runs on another.  Counts victim outputs that differ from the host result,
+// by 16-lane group of the wave, for the packed form and for the scalar control.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/probes/pk_hazard_probe.cpp -o tools/probes/bin/pk_hazard
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// ---- aggressor: LDS-fed bf16 MFMA loop with staging, 256 threads, 2 workgroups per CU ------------------------------
+__global__ __launch_bounds__(256, 2) void mfma_kernel(const float* __restrict__ A, float* __restrict__ C, int K, int nk) {
+  constexpr int BM = 128, ROWB = 80, OP = 3 * BM * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5, c4 = tid & 7;
+  const int row = (wave << 3) + (((lane >> 3) & 1) << 2) + (lane >> 4);
+  for (int i = tid; i < 2 * OP / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u ^ ((i * 2654435761u) & 0x80ff80ffu);
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const size_t base = (size_t)(blockIdx.x % 64) * BM * K;
+  float4 ra[8];
+  for (int ks = 0; ks < nk; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const float4*>(A + base + (size_t)(row + 32 * (i & 3)) * K + (ks % (K / 32)) * 32 + c4 * 4);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[t][p] = *reinterpret_cast<const bf16x8*>(smem + (p * BM + wm * 64 + t * 32 + r) * ROWB + g * 32 + h * 16);
+          fb[t][p] = *reinterpret_cast<const bf16x8*>(smem + OP + (p * BM + wn * 64 + t * 32 + r) * ROWB + g * 32 + h * 16);
+        }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 3 - pa; ++pb)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][pa], fb[tn][pb], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float4 v = ra[i];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        uint2 w;
+        w.x = __builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u);
+        w.y = __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u);
+        *reinterpret_cast<uint2*>(smem + (i >> 2) * OP + (p * BM + row + 32 * (i & 3)) * ROWB + c4 * 8) = w;
+        v.x -= __uint_as_float(__float_as_uint(v.x) & 0xffff0000u); v.y -= __uint_as_float(__float_as_uint(v.y) & 0xffff0000u);
+        v.z -= __uint_as_float(__float_as_uint(v.z) & 0xffff0000u); v.w -= __uint_as_float(__float_as_uint(v.w) & 0xffff0000u);
+      }
+    }
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  C[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+// ---- victim: 8 gathered dwords per lane, multiplied pairwise ----------------------------------------------------------
+// PACKED: the pairs are v_pk_mul_f32 operands (two separately loaded registers form one 64-bit operand).
+template <bool PACKED>
+__global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = src[idx[i] + 37 * j];            // eight separate global_load_dword
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    if (PACKED) {
+      float2v in = {t[j], t[j + 1]}, w = {0.5f + j, 0.25f + j}, pr;
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(in), "v"(w));
+      sum += pr.x;
+      sum += pr.y;
+    } else {
+      float a = t[j] * (0.5f + j), b = t[j + 1] * (0.25f + j);
+      asm volatile("" : "+v"(a), "+v"(b));
+      sum += a;
+      sum += b;
+    }
+  }
+  out[i] = sum;
+}
+
+int main() {
+  const int n = 96 * 160 * 3, NSRC = 1 << 20, K = 1024;
+  std::vector<float> hs(NSRC);
+  std::vector<int> hi(n);
+  srand(3);
+  for (auto& v : hs) v = (float)rand() / RAND_MAX;
+  for (auto& v : hi) v = rand() % (NSRC - 400);
+  std::vector<float> ref(n);
+  for (int i = 0; i < n; ++i) {
+    float sum = 0.f;
+    for (int j = 0; j < 8; j += 2) { sum += hs[hi[i] + 37 * j] * (0.5f + j); sum += hs[hi[i] + 37 * (j + 1)] * (0.25f + j); }
+    ref[i] = sum;
+  }
+  float *dsrc, *dout, *dA, *dC;
+  int* didx;
+  CK(hipMalloc(&dsrc, NSRC * 4)); CK(hipMalloc(&dout, n * 4)); CK(hipMalloc(&didx, n * 4));
+  CK(hipMalloc(&dA, (size_t)8192 * K * 4)); CK(hipMalloc(&dC, 1024 * 256 * 4));
+  CK(hipMemcpy(dsrc, hs.data(), NSRC * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(didx, hi.data(), n * 4, hipMemcpyHostToDevice));
+  std::vector<float> hA((size_t)8192 * K);
+  for (auto& v : hA) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  hipStream_t s1, s2;
+  CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  std::vector<float> got(n);
+  for (int busy = 0; busy < 3; ++busy)
+    for (int packed = 1; packed >= 0; --packed) {
+      long wrong = 0, runs_wrong = 0, by_group[4] = {0, 0, 0, 0};
+      const int reps = 300;
+      for (int rep = 0; rep < reps; ++rep) {
+        // a train of MFMA launches that leaves one of the two workgroup slots of many CUs free: the victim's waves then
+        // share SIMDs with MFMA waves for its whole run
+        if (busy) for (int q = 0; q < 12; ++q) hipLaunchKernelGGL(mfma_kernel, dim3(busy == 1 ? 384 : 512), dim3(256), 0, s2, dA, dC, K, 6);
+        CK(hipMemsetAsync(dout, 0, n * 4, s1));
+        if (packed) hipLaunchKernelGGL((victim_kernel<true>), dim3((n + 255) / 256), dim3(256), 0, s1, dsrc, didx, dout, n);
+        else hipLaunchKernelGGL((victim_kernel<false>), dim3((n + 255) / 256), dim3(256), 0, s1, dsrc, didx, dout, n);
+        CK(hipMemcpyAsync(got.data(), dout, n * 4, hipMemcpyDeviceToHost, s1));
+        CK(hipStreamSynchronize(s1));
+        long w = 0;
+        for (int i = 0; i < n; ++i)
+          if (got[i] != ref[i]) { ++w; ++by_group[(i & 63) >> 4]; }
+        wrong += w; runs_wrong += w != 0;
+      }
+      CK(hipDeviceSynchronize());
+      printf("neighbour %-18s victim %-8s: %ld of %d runs with wrong outputs, %ld wrong values, by 16-lane group [%ld %ld %ld %ld]\n",
+             busy == 0 ? "none" : busy == 1 ? "MFMA x12 (384 WG)" : "MFMA x12 (512 WG)", packed ? "v_pk_mul" : "scalar", runs_wrong, reps, wrong, by_group[0], by_group[1],
+             by_group[2], by_group[3]);
+    }
+  return 0;
+}
