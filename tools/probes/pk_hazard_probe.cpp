@@ -2,6 +2,8 @@
 // two separate global_load_dword, run on one stream while a bf16 MFMA 32x32x16 kernel with 256 VGPRs per wave (the bf16x6
 // conv loop, tools/probes/x6_phases_probe.cpp) runs on another.  Counts victim outputs that differ from the host result,
 // by 16-lane group of the wave, for the packed form and for the scalar control.
+// RESULT (profiles/r02_pk_hazard_probe.txt): no wrong value with these generic neighbours (142 / 238 VGPRs) -- the effect
+// seen in the engine (tools/debug/concurrent_victims2.py on the pre-fix warp kernel) needs the engine's own kernels.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/probes/pk_hazard_probe.cpp -o tools/probes/bin/pk_hazard
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,6 +15,7 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 // ---- aggressor: LDS-fed bf16 MFMA loop with staging, 256 threads, 2 workgroups per CU ------------------------------
+template <int PAD>
 __global__ __launch_bounds__(256, 2) void mfma_kernel(const float* __restrict__ A, float* __restrict__ C, int K, int nk) {
   constexpr int BM = 128, ROWB = 80, OP = 3 * BM * ROWB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP];
@@ -25,7 +28,12 @@ __global__ __launch_bounds__(256, 2) void mfma_kernel(const float* __restrict__ 
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const size_t base = (size_t)(blockIdx.x % 64) * BM * K;
   float4 ra[8];
+  float pad[PAD > 0 ? PAD : 1];                       // extra live registers: the engine's kernels hold 232-242 VGPRs
+#pragma unroll
+  for (int i = 0; i < PAD; ++i) pad[i] = A[base + tid + 256 * i];
   for (int ks = 0; ks < nk; ++ks) {
+#pragma unroll
+    for (int i = 0; i < PAD; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(pad[i]));
 #pragma unroll
     for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const float4*>(A + base + (size_t)(row + 32 * (i & 3)) * K + (ks % (K / 32)) * 32 + c4 * 4);
 #pragma unroll
@@ -66,15 +74,21 @@ __global__ __launch_bounds__(256, 2) void mfma_kernel(const float* __restrict__ 
   }
   float s = 0.f;
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  for (int i = 0; i < PAD; ++i) s += pad[i];
   C[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
 // ---- victim: 8 gathered dwords per lane, multiplied pairwise ----------------------------------------------------------
 // PACKED: the pairs are v_pk_mul_f32 operands (two separately loaded registers form one 64-bit operand).
-template <bool PACKED>
+template <bool PACKED, int VPAD>
 __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  float vpad[VPAD > 0 ? VPAD : 1];                     // live registers below the loaded pairs (the warp kernel holds 114)
+#pragma unroll
+  for (int j = 0; j < VPAD; ++j) vpad[j] = src[(i + 64 * j) & 0xffff];
+#pragma unroll
+  for (int j = 0; j < VPAD; ++j) asm volatile("v_add_f32 %0, 0, %0" : "+v"(vpad[j]));
   float t[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) t[j] = src[idx[i] + 37 * j];            // eight separate global_load_dword
@@ -93,7 +107,10 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ s
       sum += b;
     }
   }
-  out[i] = sum;
+  float ps = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPAD; ++j) ps += vpad[j];
+  out[i] = ps == 12345.678f ? ps : sum;               // keeps the padding alive without changing the result
 }
 
 int main() {
@@ -121,17 +138,19 @@ int main() {
   hipStream_t s1, s2;
   CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   std::vector<float> got(n);
-  for (int busy = 0; busy < 3; ++busy)
+  for (int busy = 0; busy < 4; ++busy)
     for (int packed = 1; packed >= 0; --packed) {
       long wrong = 0, runs_wrong = 0, by_group[4] = {0, 0, 0, 0};
       const int reps = 300;
       for (int rep = 0; rep < reps; ++rep) {
         // a train of MFMA launches that leaves one of the two workgroup slots of many CUs free: the victim's waves then
         // share SIMDs with MFMA waves for its whole run
-        if (busy) for (int q = 0; q < 12; ++q) hipLaunchKernelGGL(mfma_kernel, dim3(busy == 1 ? 384 : 512), dim3(256), 0, s2, dA, dC, K, 6);
+        if (busy == 1) for (int q = 0; q < 12; ++q) hipLaunchKernelGGL((mfma_kernel<0>), dim3(384), dim3(256), 0, s2, dA, dC, K, 6);
+        if (busy == 2) for (int q = 0; q < 12; ++q) hipLaunchKernelGGL((mfma_kernel<96>), dim3(384), dim3(256), 0, s2, dA, dC, K, 6);
+        if (busy == 3) for (int q = 0; q < 12; ++q) hipLaunchKernelGGL((mfma_kernel<96>), dim3(512), dim3(256), 0, s2, dA, dC, K, 6);
         CK(hipMemsetAsync(dout, 0, n * 4, s1));
-        if (packed) hipLaunchKernelGGL((victim_kernel<true>), dim3((n + 255) / 256), dim3(256), 0, s1, dsrc, didx, dout, n);
-        else hipLaunchKernelGGL((victim_kernel<false>), dim3((n + 255) / 256), dim3(256), 0, s1, dsrc, didx, dout, n);
+        if (packed) hipLaunchKernelGGL((victim_kernel<true, 96>), dim3((n + 255) / 256), dim3(256), 0, s1, dsrc, didx, dout, n);
+        else hipLaunchKernelGGL((victim_kernel<false, 96>), dim3((n + 255) / 256), dim3(256), 0, s1, dsrc, didx, dout, n);
         CK(hipMemcpyAsync(got.data(), dout, n * 4, hipMemcpyDeviceToHost, s1));
         CK(hipStreamSynchronize(s1));
         long w = 0;
@@ -140,8 +159,8 @@ int main() {
         wrong += w; runs_wrong += w != 0;
       }
       CK(hipDeviceSynchronize());
-      printf("neighbour %-18s victim %-8s: %ld of %d runs with wrong outputs, %ld wrong values, by 16-lane group [%ld %ld %ld %ld]\n",
-             busy == 0 ? "none" : busy == 1 ? "MFMA x12 (384 WG)" : "MFMA x12 (512 WG)", packed ? "v_pk_mul" : "scalar", runs_wrong, reps, wrong, by_group[0], by_group[1],
+      printf("neighbour %-24s victim %-8s: %ld of %d runs with wrong outputs, %ld wrong values, by 16-lane group [%ld %ld %ld %ld]\n",
+             busy == 0 ? "none" : busy == 1 ? "MFMA 142 VGPR, 384 WG" : busy == 2 ? "MFMA ~240 VGPR, 384 WG" : "MFMA ~240 VGPR, 512 WG", packed ? "v_pk_mul" : "scalar", runs_wrong, reps, wrong, by_group[0], by_group[1],
              by_group[2], by_group[3]);
     }
   return 0;
