@@ -218,13 +218,14 @@ static int run(const char* name, Args p, int tiles, std::vector<float>* out, con
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int wg_budget = argc > 1 ? atoi(argv[1]) : 512;      // workgroups the plan deals the units to
   const int shapes[][3] = {{4864, 256, 2304}, {4864, 256, 1024}, {1664, 256, 2304}, {4864, 1024, 512}, {19328, 128, 1152}};
   for (auto& s : shapes) {
     const int M = s[0], N = s[1], K = s[2];
     const int tiles = (M / 128) * (N / 128), ksteps = K / 32;
     const long U = (long)tiles * ksteps;
-    int nwg = 512;
+    int nwg = wg_budget;
     if (U / nwg < 3) nwg = (int)(U / 3);
     const int per = (int)((U + nwg - 1) / nwg);
     nwg = (int)((U + per - 1) / per);
