@@ -129,17 +129,31 @@ class DAVIS:
         return {'image': torch.from_numpy(img.transpose(2, 0, 1)), 'gt': torch.from_numpy(label[None]),     # ToTensor
                 'file_name': sample['file_name']}
 
-    def sequence_tensors(self, seq_name, device='cpu'):
-        """(frames (N,3,H,W), [first-frame mask (1,H,W) per object]) of one sequence, ready for
-        `evaluate.evaluate_sequence`."""
+    def sequence_tensors(self, seq_name, device='cpu', with_frame_ids=False):
+        """(frames (N,3,H,W), [train-frame mask (1,H,W) per object]) of one sequence, ready for
+        `evaluate.evaluate_sequence`; with `with_frame_ids` also the frame each object is first annotated in -- the frame
+        it is fine-tuned on (`train_loader.dataset.set_gt_frame_id()` per object, `evaluate.py:132-137`): 0 for DAVIS,
+        possibly later for YouTube-VOS objects (`youtube.py:131-143`)."""
         self.set_seq(seq_name)
         frames = torch.stack([torch.from_numpy(self.make_image(i).transpose(2, 0, 1)) for i in range(len(self.imgs))])
-        gts = []
+        keep = (self.frame_id, self._label_id)
+        gts, fids = [], []
         for o in range(self.num_objects):
             self.multi_object_id = o
-            gts.append(torch.from_numpy(self.make_img_label_pair(0)[1][None]))
+            self.set_gt_frame_id()
+            fids.append(int(self.frame_id))
+            gts.append(torch.from_numpy(self.make_label(self.frame_id)[None]))
         self.multi_object_id = None
+        self.frame_id, self._label_id = keep
+        if with_frame_ids:
+            return frames.to(device), [g.to(device) for g in gts], fids
         return frames.to(device), [g.to(device) for g in gts]
+
+    all_frames = False
+
+    def has_label_file(self, seq_name, frame_name):
+        """all-frames splits: is this frame one of the annotated ones (`evaluate.py:334-335`: the others get no PNG)."""
+        return any(frame_name in l for l in self.seqs[seq_name]['labels'])
 
 
     # ---- frame selection of the meta-train tasks (vos_dataset.py:73-146) ------------------------------
@@ -279,9 +293,13 @@ class SyntheticSequences:
         top = (torch.arange(self.h).view(-1, 1) < self.h // 2)
         return frames, [(gt[0] * top).float(), (gt[0] * ~top).float()]
 
-    def sequence_tensors(self, seq, device='cpu'):
+    all_frames = False
+
+    def sequence_tensors(self, seq, device='cpu', with_frame_ids=False):
         frames, gts = self._objects(seq)
         seq_frames = torch.cat([torch.roll(frames, shifts=4 * i, dims=3) for i in range(self.n)])
+        if with_frame_ids:
+            return seq_frames.to(device), [g.to(device) for g in gts], [0] * len(gts)
         return seq_frames.to(device), [g.to(device) for g in gts]
 
     def frame_names(self, seq):

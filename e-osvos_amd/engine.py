@@ -128,7 +128,8 @@ class Engine:
 
     def reset(self):
         _ffi.check(self.lib.eosvos_reset(self.h))
-        self.steps_since_reset, self.in_meta_task = 0, False
+        # theta <- init starts a new object / task: the first-step snapshot of the previous one is dead
+        self.steps_since_reset, self.in_meta_task, self.has_snapshot = 0, False, False
 
     def get_params(self):
         out = torch.empty(self.n_param, device=self.device)
@@ -241,7 +242,7 @@ class Engine:
     # ---- meta-training ----------------------------------------------------------------
     def meta_task_begin(self):
         _ffi.check(self.lib.eosvos_meta_task_begin(self.h))
-        self.steps_since_reset, self.in_meta_task = 0, True
+        self.steps_since_reset, self.in_meta_task, self.has_snapshot = 0, True, False
 
     def meta_grad(self, images, masks, flat_meta_grad, weight=1.0, init_grad=True, new_segment=False, sync=True):
         """ADDS weight * task meta-gradient into flat_meta_grad ([lr state | init]); returns the meta loss.

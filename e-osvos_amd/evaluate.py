@@ -190,8 +190,10 @@ def object_workers(model, meta_optim, meta_optim_cfg, n, wg_budget=256):
 
 def run_objects_in_flight(workers, meta_optim_state_dict, frames, gts, cfg, augment=None, train_frame_id=0):
     """[(probs, hist)] for the objects `gts` of one sequence, up to len(workers) of them in flight together; results are
-    those of `finetune_object` one after the other (same engine arithmetic at the same workgroup budget)."""
+    those of `finetune_object` one after the other (same engine arithmetic at the same workgroup budget).
+    `train_frame_id`: one frame for all objects, or one per object (YouTube-VOS objects that appear later)."""
     out = [None] * len(gts)
+    tfid = list(train_frame_id) if isinstance(train_frame_id, (list, tuple)) else [train_frame_id] * len(gts)
     if frames.is_cuda:
         torch.cuda.current_stream(frames.device).synchronize()      # frames / masks were produced on this stream
     pending = list(range(len(gts)))
@@ -205,7 +207,7 @@ def run_objects_in_flight(workers, meta_optim_state_dict, frames, gts, cfg, augm
             if wi not in active and pending:
                 oi = pending.pop(0)
                 active[wi] = (oi, finetune_object_steps(w.model, w.meta_optim, meta_optim_state_dict, frames, gts[oi], cfg,
-                                                        augment, train_frame_id))
+                                                        augment, tfid[oi]))
         for wi in sorted(active):
             oi, gen = active[wi]
             w = workers[wi]
@@ -266,6 +268,10 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     after which every rank merges the same label maps and rank 0 writes files.
     `objects_in_flight` (default: EOSVOS_OBJECTS_IN_FLIGHT, else 3 on a GPU): how many of a sequence's objects this
     rank fine-tunes side by side, one engine and stream each (`run_objects_in_flight`); 1 = one after the other.
+    Engines that run side by side plan every launch for half the chip (`eosvos_set_wg_budget` 256), an object alone on
+    the GPU for all of it: the budget changes the split-K partition, i.e. the order of fp32 partial sums, so the last
+    bits of a result (not its parity margins, `profiles/*parity_margins*`) depend on how many objects of the sequence
+    landed on this rank.  EOSVOS_OBJECTS_IN_FLIGHT=1 gives one schedule-independent order.
     Returns dict(J_seq, mean_J, best_mean_J, time_per_frame, labels={seq: (N,H,W) uint8})."""
     from .checkpoint import save_meta_checkpoint
     from .data import sequence_J
@@ -305,7 +311,8 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     pool = None
     if getattr(dataset, 'prefetchable', False) and seqs and os.environ.get('EOSVOS_EVAL_PREFETCH', '1') != '0':
         pool = ThreadPoolExecutor(max_workers=2)
-    load = lambda sq: copy.copy(dataset).sequence_tensors(sq, 'cpu')
+    load = lambda sq: copy.copy(dataset).sequence_tensors(sq, 'cpu', with_frame_ids=True)
+    budget_before = getattr(model, 'wg_budget', 0)
     ahead = pool.submit(load, seqs[0]) if pool else None
     finishing = []
 
@@ -314,17 +321,19 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         if rank == 0 and preds_dir is not None:
             names = ds.frame_names(sq)
             for f in range(labels.shape[0]):
+                if getattr(ds, 'all_frames', False) and not ds.has_label_file(sq, names[f]):
+                    continue                                                    # evaluate.py:334-335
                 save_label_png(os.path.join(preds_dir, sq, names[f] + '.png'), labels[f].numpy())
         return 0.0 if ds.test_mode else sequence_J(labels.numpy(), ds.label_maps(sq), n_obj)     # evaluate.py:344-346
 
     for k, seq in enumerate(seqs):
         if pool:
-            frames, gts = ahead.result()
+            frames, gts, fids = ahead.result()
             frames, gts = frames.to(device or model.device), [g.to(device or model.device) for g in gts]
             if k + 1 < len(seqs):
                 ahead = pool.submit(load, seqs[k + 1])
         else:
-            frames, gts = dataset.sequence_tensors(seq, device or model.device)
+            frames, gts, fids = dataset.sequence_tensors(seq, device or model.device, with_frame_ids=True)
         n = frames.shape[0]
         probs = torch.zeros(len(gts), n, *frames.shape[-2:], device=frames.device)
         t0 = time.perf_counter()
@@ -334,14 +343,16 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
                 mine.append(obj_id)
             item += 1
         if workers is not None and len(mine) > 1:
-            res = run_objects_in_flight(workers, meta_optim_state_dict, frames, [gts[o] for o in mine], cfg)
+            res = run_objects_in_flight(workers, meta_optim_state_dict, frames, [gts[o] for o in mine], cfg,
+                                        train_frame_id=[fids[o] for o in mine])
             for o, (p, _) in zip(mine, res):
                 probs[o] = p
         else:
             if workers is not None:
                 model.set_wg_budget(0)                                          # alone on the GPU
             for o in mine:
-                probs[o], _ = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gts[o], cfg)
+                probs[o], _ = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gts[o], cfg,
+                                              train_frame_id=fids[o])
         if world > 1:
             dist.all_reduce(probs)
         eval_time += time.perf_counter() - t0
@@ -360,6 +371,8 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
             log(f"{dataset_key}: {seq} [{J_seq[-1]}]")
     if pool:
         pool.shutdown(wait=True)
+    if workers is not None and hasattr(model, 'set_wg_budget'):
+        model.set_wg_budget(budget_before)              # worker 0 is the caller's model: leave it as it was handed in
     mean_J = float(np.mean(J_seq)) if J_seq else 0.0
     out_best = best_mean_J
     if rank == 0 and save_dir is not None and not dataset.test_mode:
