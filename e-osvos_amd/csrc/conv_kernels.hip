@@ -551,15 +551,20 @@ long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vect
 //
 // Tile: 128 x {128,64} x 32 per 256-thread workgroup (2x2 waves, 64 x {64,32} per wave), 2 workgroups per CU.
 // Operands are gathered global -> registers (fp32, prefetched behind the MFMAs) -> split -> one LDS stage of
-// [piece][row][32 k] bf16 rows (80-byte pitch: conflict-free ds_read_b128 fragment reads).  K-major operands
-// (the weights of the data gradient, both operands of the weight gradient) are transposed in registers while
-// staging: a thread loads RPT consecutive k rows of 4 channels and writes one k-run per channel; their LDS rows are
-// de-interleaved (row j*W/4 + c <-> channel 4c + j) so that those writes spread over the banks -- the epilogue maps
-// the MFMA tile coordinates back.
+// [piece][row][32 k] bf16 rows.  The products run on v_mfma_f32_16x16x32_bf16 (one ds_read_b128 = the 8 k of a lane's
+// k slot; a fragment = 16 rows x all 32 k of the stage): on random data the chip holds a higher clock under this shape
+// than under 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7; measured on this loop:
+// +7-11 %, tools/probes/x6_shape_probe.cpp, profiles/r03_x6_shape_probe.txt), and s_setprio 1 around the MFMA block
+// keeps the co-resident workgroup's split / LDS-store phase from delaying it (+4-6 % more).  Row pitch 96 bytes:
+// conflict-free ds_read_b128 for the 16-row fragments (lane l reads row l % 16, 16-byte slot l / 16).
+// K-major operands (the weights of the data gradient, both operands of the weight gradient) are transposed in
+// registers while staging: a thread loads RPT consecutive k rows of 4 channels and writes one k-run per channel; their
+// LDS rows are de-interleaved (row j*W/4 + c <-> channel 4c + j) -- the epilogue maps the MFMA tile coordinates back.
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-#define X6_ROWB 80
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define X6_ROWB 96
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // Two fp32 values -> bf16 pieces, packed (e1 << 16 | e0).  Default: the truncated top 16 bits (one v_perm_b32; the
@@ -595,33 +600,60 @@ __device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v
 // LDS row of a K-major operand tile of width W <-> channel inside the tile
 __device__ __forceinline__ int x6_row_chan(int R, int W) { return 4 * (R % (W / 4)) + R / (W / 4); }
 
-// one 16-deep k group of a wave's 64 x (32*TN) tile: 6*(2+TN) fragment reads, 12*TN MFMAs
-template <int TM, int TN>
-__device__ __forceinline__ void x6_mma_group(const unsigned char* As, const unsigned char* Bs, int a_rows, int b_rows, int a_row0,
-                                             int b_row0, int g, int r, int h, f32x16 (&acc)[TM][TN]) {
-  bf16x8 fa[TM][3], fb[TN][3];
+// Staging maps.  Row-major operands: a thread stores 8 bytes (4 k) of one row per pass of 32 rows; the two rows of a
+// 16-lane ds_write_b64 group lie 2 rows apart (192 B = 16 banks: disjoint bank halves at the 96-byte pitch).
+__device__ __forceinline__ int x6_stage_row(int tid) {
+  const int j = (tid >> 3) & 7;
+  return ((tid >> 6) << 3) + ((j & 1) << 1) + ((j >> 1) & 1) + (j & 4);
+}
+// K-major operands, 128 channels wide (a thread owns 4 k x 4 channels): a 16-lane ds_write_b64 group = 4 consecutive
+// LDS rows x 4 k runs (32 distinct banks); a wave's global load covers 256 contiguous bytes of each of 4 k rows.
+__device__ __forceinline__ int x6_kmaj_c4_128(int tid) { return (tid & 3) | (((tid >> 4) & 3) << 2) | (((tid >> 6) & 1) << 4); }
+__device__ __forceinline__ int x6_kmaj_kq_128(int tid) { return ((tid >> 2) & 3) | (((tid >> 7) & 1) << 2); }
+// 64 channels wide (2 k x 4 channels, ds_write_b32): a 32-lane group = 4 consecutive rows x 8 k pairs
+__device__ __forceinline__ int x6_kmaj_c4_64(int tid) { return (tid & 3) | (((tid >> 5) & 1) << 2) | (((tid >> 6) & 1) << 3); }
+__device__ __forceinline__ int x6_kmaj_kq_64(int tid) { return ((tid >> 2) & 7) | (((tid >> 7) & 1) << 3); }
+
+// one 32-deep K step of a wave's (16*TM) x (16*TN) tile: 6*TM*TN MFMAs.  Fragments are taken MB x 2 at a time:
+// MB = TM reads every fragment once (3*(TM + TN) ds_read_b128); MB = 2 re-reads the B fragments per A pair
+// (3*(TM + TN*TM/2) reads) and keeps only 12 fragments live -- for the conv kernels, whose gather state needs the registers.
+template <int TM, int TN, int MB = TM>
+__device__ __forceinline__ void x6_mma_step(const unsigned char* As, const unsigned char* Bs, int a_rows, int b_rows, int a_row0,
+                                            int b_row0, int r16, int q, f32x4 (&acc)[TM][TN]) {
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+  for (int hm = 0; hm < TM; hm += MB) {
+    bf16x8 fa[MB][3];
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
-      fa[t][p] = *reinterpret_cast<const bf16x8*>(As + (p * a_rows + a_row0 + t * 32 + r) * X6_ROWB + g * 32 + h * 16);
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
-      fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * b_rows + b_row0 + t * 32 + r) * X6_ROWB + g * 32 + h * 16);
-  }
+      for (int t = 0; t < MB; ++t)
+        fa[t][p] = *reinterpret_cast<const bf16x8*>(As + (p * a_rows + a_row0 + (hm + t) * 16 + r16) * X6_ROWB + q * 16);
+    // the re-read of the B fragments must stay a re-read (a merged load would keep all of them live): opaque base
+    unsigned boff = (unsigned)((b_row0 + r16) * X6_ROWB + q * 16);
+    if (MB != TM) asm volatile("" : "+v"(boff));
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+    for (int hn = 0; hn < TN; hn += 2) {
+      bf16x8 fb[2][3];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      f32x16 c = acc[tm][tn];
-      c = MFMA_BF16(fa[tm][2], fb[tn][0], c);            // smallest terms first
-      c = MFMA_BF16(fa[tm][0], fb[tn][2], c);
-      c = MFMA_BF16(fa[tm][1], fb[tn][1], c);
-      c = MFMA_BF16(fa[tm][1], fb[tn][0], c);
-      c = MFMA_BF16(fa[tm][0], fb[tn][1], c);
-      c = MFMA_BF16(fa[tm][0], fb[tn][0], c);
-      acc[tm][tn] = c;
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + boff + (p * b_rows + (hn + t) * 16) * X6_ROWB);
+#pragma unroll
+      for (int tm = 0; tm < MB; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x4 c = acc[hm + tm][hn + tn];
+          c = MFMA_BF16(fa[tm][2], fb[tn][0], c);            // smallest terms first
+          c = MFMA_BF16(fa[tm][0], fb[tn][2], c);
+          c = MFMA_BF16(fa[tm][1], fb[tn][1], c);
+          c = MFMA_BF16(fa[tm][1], fb[tn][0], c);
+          c = MFMA_BF16(fa[tm][0], fb[tn][1], c);
+          c = MFMA_BF16(fa[tm][0], fb[tn][0], c);
+          acc[hm + tm][hn + tn] = c;
+        }
     }
+  }
 }
 
 template <int BN, bool KMAJOR>
@@ -629,16 +661,14 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   constexpr int BM = 128, BK = 32;
   constexpr int A_BYTES = 3 * BM * X6_ROWB, B_BYTES = 3 * BN * X6_ROWB, SMEM = A_BYTES + B_BYTES;
   constexpr int LDC = BN + 4;
-  constexpr int EPASS = (BM * LDC * 4 <= SMEM) ? 1 : 2;      // C-tile staging passes
-  constexpr int EROWS = BM / EPASS;
-  static_assert(EROWS * LDC * 4 <= SMEM, "epilogue staging must fit the operand buffers");
+  static_assert(BM * LDC * 4 <= SMEM, "the C tile is staged through the operand buffers");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   unsigned char* const As = smem;
   unsigned char* const Bs = smem + A_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
+  const int fr = lane & 15, fq = lane >> 4;              // fragment row / 16-byte k slot of this lane
 
   const int T = p.KH * p.KW;
   const int chunks = (p.Kc + BK - 1) / BK;
@@ -654,18 +684,16 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   int dp_i = 0;
 
   constexpr int APASS = BM / 32;                         // 8 float4 per 32-k row, 32 rows per pass
-  // row of a staging pass: the two rows of a 16-lane ds_write_b64 group are 4 rows (320 B) apart -> disjoint banks
-  const int a_c4 = tid & 7, a_r = (wave << 3) + (((lane >> 3) & 1) << 2) + (lane >> 4);
+  const int a_c4 = tid & 7, a_r = x6_stage_row(tid);
   // B operand: rows of k (n-major weights, forward) staged like A; k-major weights (data gradient): a thread owns
   // RPT consecutive k rows x 4 columns
   constexpr int NQ = BN / 4, RPT = BN / 32;              // K-major: threads per k row, k rows per thread
   constexpr int BPASS = BN / 32;                         // = RPT: float4 loads per thread in both layouts
   const int b_c4 = a_c4, b_r = a_r;
-  // K-major: a 16-lane write group = 8 columns x 2 k runs (bank-conflict free at the 80-byte pitch)
-  const int b_n4 = RPT == 4 ? ((tid & 7) | (((tid >> 4) & 3) << 3)) : tid % NQ;
-  const int b_kq = RPT == 4 ? (((tid >> 3) & 1) | ((tid >> 6) << 1)) : tid / NQ;
+  const int b_n4 = RPT == 4 ? x6_kmaj_c4_128(tid) : x6_kmaj_c4_64(tid);
+  const int b_kq = RPT == 4 ? x6_kmaj_kq_128(tid) : x6_kmaj_kq_64(tid);
   const int up = 1 << p.upshift;
-  constexpr int TN = BN / 64;
+  constexpr int TN = BN / 32;                            // 16-column fragments per wave
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (p.plane_rows ? (long)p.nplanes : 1L) * p.wN * T * p.wK * 4);
 
@@ -815,13 +843,14 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
       }
     };
 
-    f32x16 acc[2][TN];
+    constexpr int TM = 4;                                // 16-row fragments of a wave's 64 x (BN/2) tile
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
     load_tiles(ks_begin);
     __syncthreads();            // previous segment's epilogue reads of smem are done
@@ -831,8 +860,9 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       const bool more = (ks + 1) < ks_end;
       if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
-#pragma unroll
-      for (int g = 0; g < BK / 16; ++g) x6_mma_group<2, TN>(As, Bs, BM, BN, wm * 64, wn * (BN / 2), g, r, h, acc);
+      __builtin_amdgcn_s_setprio(1);
+      x6_mma_step<TM, TN, (BN == 128 ? 2 : TM)>(As, Bs, BM, BN, wm * 64, wn * (BN / 2), fr, fq, acc);
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();                       // every wave is done reading the stage
       if (more) store_tiles();
       __syncthreads();
@@ -850,26 +880,21 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
       if (p.bias) bi = ldg4(p.bias + n);
     }
     const bool use_mask = p.mask && n >= p.mask_c0;
+    {
+      // D of 16x16x32: lane (fr = column, fq) holds rows 4*fq .. 4*fq+3 of the fragment
 #pragma unroll
-    for (int ep = 0; ep < EPASS; ++ep) {
-      if (ep) __syncthreads();
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        if (EPASS == 2 && tm != ep) continue;
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          const int Rb = wn * (BN / 2) + tn * 32 + r;
+          const int Rb = wn * (BN / 2) + tn * 16 + fr;
           const int ncol = KMAJOR ? x6_row_chan(Rb, BN) : Rb;
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            Cs[((EPASS == 1 ? wm * 64 + tm * 32 : wm * 32) + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + ncol] = acc[tm][tn][e];
+          for (int e = 0; e < 4; ++e) Cs[(wm * 64 + tm * 16 + 4 * fq + e) * LDC + ncol] = acc[tm][tn][e];
         }
-      }
       __syncthreads();
-      auto trow = [&](int lr) { return EPASS == 1 ? lr : ((lr >> 5) << 6) + (ep << 5) + (lr & 31); };
       if (full) {
         if (n < p.N) {
-          constexpr int NIT = EROWS / CROWS, EB = EOSVOS_EB;
+          constexpr int NIT = BM / CROWS, EB = EOSVOS_EB;
 #pragma unroll
           for (int it0 = 0; it0 < NIT; it0 += EB) {
             size_t md[EB];
@@ -877,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
             float4 rs[EB], ac[EB], mk[EB];
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
-              const int m = m0 + trow(c_r + (it0 + j) * CROWS);
+              const int m = m0 + c_r + (it0 + j) * CROWS;
               ok[j] = m < p.M;
               md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
             }
@@ -912,9 +937,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
       } else {
         float* slab = p.ws + ((size_t)bid * 2 + (u == u_begin ? 0 : 1)) * (BM * BN);
 #pragma unroll 4
-        for (int lr = c_r; lr < EROWS; lr += CROWS)
-          *reinterpret_cast<float4*>(slab + trow(lr) * BN + c_c4 * 4) =
-              *reinterpret_cast<const float4*>(Cs + lr * LDC + c_c4 * 4);
+        for (int lr = c_r; lr < BM; lr += CROWS)
+          *reinterpret_cast<float4*>(slab + lr * BN + c_c4 * 4) = *reinterpret_cast<const float4*>(Cs + lr * LDC + c_c4 * 4);
       }
     }
     if (!dp) u += ks_end - ks_begin;
@@ -923,25 +947,21 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
 
 // Weight gradient on the bf16 matrix cores: same split, both operands K-major (a pixel's channels are contiguous).
 template <int BMO, int BNI>
-__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid, unsigned char* smem) {
   constexpr int BKP = 32;
   constexpr int A_BYTES = 3 * BMO * X6_ROWB, B_BYTES = 3 * BNI * X6_ROWB, SMEM = A_BYTES + B_BYTES;
   constexpr int LDC = BNI + 4;
-  constexpr int EPASS = (BMO * LDC * 4 <= SMEM) ? 1 : 2;
-  constexpr int EROWS = BMO / EPASS;
-  static_assert(EROWS * LDC * 4 <= SMEM, "epilogue staging must fit the operand buffers");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  static_assert(BMO * LDC * 4 <= SMEM, "the C tile is staged through the operand buffers");
   unsigned char* const As = smem;
   unsigned char* const Bs = smem + A_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
+  const int fr = lane & 15, fq = lane >> 4;              // fragment row / 16-byte k slot of this lane
 
   const int T = p.KH * p.KW;
   const int ct = (p.Cout + BMO - 1) / BMO, it = (p.Cin + BNI - 1) / BNI;
   const int tiles = ct * it * T;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int z = bid / tiles;
   int tile = bid - z * tiles;
   const int tap = tile % T; tile /= T;
@@ -966,9 +986,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
 
   // a thread owns RPT consecutive pixels x 4 channels of each operand
   constexpr int ANQ = BMO / 4, ARPT = BMO / 32, BNQ = BNI / 4, BRPT = BNI / 32;
-  const int c4_128 = (tid & 7) | (((tid >> 4) & 3) << 3), kq_128 = ((tid >> 3) & 1) | ((tid >> 6) << 1);   // see conv_x6_kernel
-  const int a_c4 = ARPT == 4 ? c4_128 : tid % ANQ, a_kq = ARPT == 4 ? kq_128 : tid / ANQ;
-  const int b_c4 = BRPT == 4 ? c4_128 : tid % BNQ, b_kq = BRPT == 4 ? kq_128 : tid / BNQ;
+  const int a_c4 = ARPT == 4 ? x6_kmaj_c4_128(tid) : x6_kmaj_c4_64(tid), a_kq = ARPT == 4 ? x6_kmaj_kq_128(tid) : x6_kmaj_kq_64(tid);
+  const int b_c4 = BRPT == 4 ? x6_kmaj_c4_128(tid) : x6_kmaj_c4_64(tid), b_kq = BRPT == 4 ? x6_kmaj_kq_128(tid) : x6_kmaj_kq_64(tid);
   const bool a_cok = (co0 + a_c4 * 4) < p.Cout;
   const bool b_cok = (ci0 + b_c4 * 4) < p.Cin;
   float4 ra[ARPT], rb[BRPT];
@@ -1043,14 +1062,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
     }
   };
 
-  constexpr int TM = BMO / 64, TN = BNI / 64;
-  f32x16 acc[TM][TN];
+  constexpr int TM = BMO / 32, TN = BNI / 32;            // 16 x 16 fragments of a wave's (BMO/2) x (BNI/2) tile
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
   if (st_begin < st_end) {
     load_tiles(st_begin);
@@ -1061,8 +1080,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
   for (int st = st_begin; st < st_end; ++st) {
     const bool more = (st + 1) < st_end;
     if (more) load_tiles(st + 1);
-#pragma unroll
-    for (int g = 0; g < BKP / 16; ++g) x6_mma_group<TM, TN>(As, Bs, BMO, BNI, wm * (BMO / 2), wn * (BNI / 2), g, r, h, acc);
+    __builtin_amdgcn_s_setprio(1);
+    x6_mma_step<TM, TN>(As, Bs, BMO, BNI, wm * (BMO / 2), wn * (BNI / 2), fr, fq, acc);
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (more) {
       store_op(As, ra, BMO, ANQ, ARPT, a_c4, a_kq);
@@ -1076,33 +1096,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
   float* out = p.ws + (size_t)z * p.Cout * T * p.Cin;
   constexpr int CF4 = BNI / 4, CROWS = 256 / CF4;
   const int c_c4 = tid % CF4, c_r = tid / CF4;
-  // tile row (cout) of accumulator element e of sub-tile tm: Ra = wm*(BMO/2) + tm*32 + (e&3) + 8*(e>>2) + 4h,
-  // channel = 4*(Ra % (BMO/4)) + Ra / (BMO/4).  A staging pass ep holds the channels [ep*EROWS, (ep+1)*EROWS).
+  // tile row (cout) of accumulator element e of fragment tm: Ra = wm*(BMO/2) + tm*16 + 4*fq + e,
+  // channel = 4*(Ra % (BMO/4)) + Ra / (BMO/4); tile column likewise from Rb = wn*(BNI/2) + tn*16 + fr.
 #pragma unroll
-  for (int ep = 0; ep < EPASS; ++ep) {
-    if (ep) __syncthreads();
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tn = 0; tn < TN; ++tn) {
+      const int ncol = x6_row_chan(wn * (BNI / 2) + tn * 16 + fr, BNI);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int ncol = x6_row_chan(wn * (BNI / 2) + tn * 32 + r, BNI);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int ch = x6_row_chan(wm * (BMO / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, BMO);
-          if (EPASS == 1 || (ch / EROWS) == ep) Cs[(ch - ep * EROWS) * LDC + ncol] = acc[tm][tn][e];
-        }
-      }
-    __syncthreads();
-    const int ci = ci0 + c_c4 * 4;
-    if (ci < p.Cin) {
-#pragma unroll 4
-      for (int lr = c_r; lr < EROWS; lr += CROWS) {
-        const int co = co0 + ep * EROWS + lr;
-        if (co < p.Cout)
-          *reinterpret_cast<float4*>(out + ((size_t)co * T + tap) * p.Cin + ci) = *reinterpret_cast<const float4*>(Cs + lr * LDC + c_c4 * 4);
+      for (int e = 0; e < 4; ++e) {
+        const int ch = x6_row_chan(wm * (BMO / 2) + tm * 16 + 4 * fq + e, BMO);
+        Cs[ch * LDC + ncol] = acc[tm][tn][e];
       }
     }
+  __syncthreads();
+  const int ci = ci0 + c_c4 * 4;
+  if (ci < p.Cin) {
+#pragma unroll 4
+    for (int lr = c_r; lr < BMO; lr += CROWS) {
+      const int co = co0 + lr;
+      if (co < p.Cout)
+        *reinterpret_cast<float4*>(out + ((size_t)co * T + tap) * p.Cin + ci) = *reinterpret_cast<const float4*>(Cs + lr * LDC + c_c4 * 4);
+    }
   }
+}
+
+template <int BMO, int BNI>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (BMO + BNI) * X6_ROWB];
+  wgrad_x6_body<BMO, BNI>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+// Several weight gradients in one launch (the independent GEMMs of a ResNet stage): workgroup w works on entry
+// map[w].x of the table as its workgroup map[w].y.  Grouped, the small layers fill the chip with a few K splits each
+// instead of 30-240 (fewer parked slabs, no per-launch tails).
+template <int BMO, int BNI>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_group_kernel(const WgradArgs* __restrict__ tab, const int2* __restrict__ map) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (BMO + BNI) * X6_ROWB];
+  const int2 m = map[xcd_remap(blockIdx.x, gridDim.x)];
+  const int ent = __builtin_amdgcn_readfirstlane(m.x), bid = __builtin_amdgcn_readfirstlane(m.y);
+  const WgradArgs p = tab[ent];
+  wgrad_x6_body<BMO, BNI>(p, bid, smem);
 }
 
 // EOSVOS_MFMA=f32 selects the fp32-MFMA kernels (A/B and fallback); default: bf16x6
@@ -1135,7 +1168,8 @@ const char* const kProfNames[] = {
     "wgrad_x6_kernel<128, 128>", "wgrad_x6_kernel<128, 64>", "wgrad_x6_kernel<64, 128>", "wgrad_x6_kernel<64, 64>",
     "conv_igemm_kernel<128, false, *>", "conv_igemm_kernel<128, true, *>", "conv_igemm_kernel<64, false, 0>", "conv_igemm_kernel<64, true, 0>",
     "wgrad_kernel<128, 128>", "wgrad_kernel<128, 64>", "wgrad_kernel<64, 128>", "wgrad_kernel<64, 64>",
-    "conv_fixup_kernel"};
+    "conv_fixup_kernel",
+    "wgrad_x6_group_kernel<128, 128>", "wgrad_x6_group_kernel<128, 64>", "wgrad_x6_group_kernel<64, 128>", "wgrad_x6_group_kernel<64, 64>"};
 constexpr int kProfKernels = sizeof(kProfNames) / sizeof(kProfNames[0]);
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -1210,6 +1244,7 @@ static int conv_wg_budget(int requested) {
   const int b = requested > 0 ? conv_clamp_wg_budget(requested) : env;
   return b > 0 ? b : CONV_MAX_WG;
 }
+int conv_wg_budget_of(int requested) { return conv_wg_budget(requested); }
 #define CONV_MAX_WG_DEEP (256 * 3)
 int64_t conv_ws_floats() { return (int64_t)CONV_MAX_WG_DEEP * 2 * 128 * 128; }
 
@@ -1506,6 +1541,18 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget) {
     if (eff >= 0.93) { best = s; break; }
   }
   return best;
+}
+
+int wgrad_group_tile(int channels) { return wg_tile(channels); }
+// One launch for several weight gradients that share the tile shape bm x bn (engine.cpp plan_wgrad_group)
+void launch_wgrad_group(const WgradArgs* dev_tab, const int* dev_map, int nwg, int bm, int bn, double flops, hipStream_t s) {
+  const dim3 grid(nwg), block(256);
+  const int2* map = reinterpret_cast<const int2*>(dev_map);
+  ProfScope ps(17 + (bm == 128 ? 0 : 2) + (bn == 128 ? 0 : 1), flops, s);
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_x6_group_kernel<128, 128>), grid, block, 0, s, dev_tab, map);
+  else if (bm == 128) hipLaunchKernelGGL((wgrad_x6_group_kernel<128, 64>), grid, block, 0, s, dev_tab, map);
+  else if (bn == 128) hipLaunchKernelGGL((wgrad_x6_group_kernel<64, 128>), grid, block, 0, s, dev_tab, map);
+  else hipLaunchKernelGGL((wgrad_x6_group_kernel<64, 64>), grid, block, 0, s, dev_tab, map);
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {

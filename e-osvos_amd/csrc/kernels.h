@@ -107,6 +107,11 @@ struct WgradArgs {
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget = 0);
+// grouped launch (bf16x6 mode): entries of one tile shape bm x bn = wgrad_group_tile(Cout) x wgrad_group_tile(Cin);
+// dev_map holds (entry, workgroup-of-entry) pairs, workgroup-of-entry = split * tiles + tile as in launch_wgrad
+int wgrad_group_tile(int channels);
+void launch_wgrad_group(const WgradArgs* dev_tab, const int* dev_map, int nwg, int bm, int bn, double flops, hipStream_t s);
+int conv_wg_budget_of(int requested);   // workgroups a launch plans for under eosvos_set_wg_budget(requested)
 int conv_clamp_wg_budget(int n);     // the budgets the slab arenas are sized for: 0 (default) or a multiple of 64 in [64, 512]
 // Winograd F(2x2,3x3) weight gradient pieces (misc_kernels.hip): V = B^T d B, dM = A dY A^T, dW = G^T sum_z dU_z G
 // planes are [16][prow][C] with prow >= B*th*tw rows (padded to the GEMM tile so that a row tile never straddles planes)
