@@ -64,6 +64,7 @@ struct Block {
 struct Topo {
   std::vector<ConvL> convs;
   std::vector<Block> blocks;
+  std::vector<int> stage;  // per conv: ResNet layer 0..3 of a bottleneck conv, -1 otherwise
   int layer1_last_block;  // index of the block whose output is the low-level feature
   int aspp[4], pool, project, dec1, dec_a, dec_b, last;
   int64_t nparam, nlr, nnorm;
@@ -98,6 +99,8 @@ bool build_topo(int arch, Topo& t) {
       b.c3 = add(w, 4 * w, 1, 1, 1, 0, true, false);
       b.ds = first ? add(inpl, 4 * w, 1, s1 * s2, 1, 0, true, false) : -1;
       t.blocks.push_back(b);
+      t.stage.resize(t.convs.size(), -1);
+      for (int ci : {b.c1, b.c2, b.c3, b.ds}) if (ci >= 0) t.stage[ci] = li;
       inpl = 4 * w;
     }
     if (li == 0) t.layer1_last_block = (int)t.blocks.size() - 1;
@@ -111,6 +114,7 @@ bool build_topo(int arch, Topo& t) {
   t.dec_a = add(304, 256, 3, 1, 1, 1, true, false);
   t.dec_b = add(256, 256, 3, 1, 1, 1, true, false);
   t.last = add(256, 1, 1, 1, 1, 0, false, true);
+  t.stage.resize(t.convs.size(), -1);
   int64_t po = 0, lo = 0, no = 0;
   for (auto& c : t.convs) {
     c.poff = po; c.lroff = lo; c.noff = no;
@@ -204,6 +208,14 @@ struct eosvos_engine {
   float *gn_sums = nullptr, *gn_partial = nullptr;
   struct TapTab { int* prefix; int* mask; long total; };
   std::map<long, TapTab> tap_tabs;    // (conv, fwd/dgrad, batch) -> compacted K-step table of a dilated conv
+  // Grouped weight gradients: the convs of ResNet layer1..3 only queue their WgradArgs; when the stage's data-gradient
+  // chain is queued, one launch per tile shape computes all of them (plan_wgrad_group)
+  struct WgGroupLaunch { WgradArgs* dtab; int* dmap; int nwg, bm, bn; double flops; int first_ci; };
+  struct WgGroupPlan { std::vector<WgGroupLaunch> launches; std::vector<int> splits; };
+  std::vector<std::pair<int, WgradArgs>> wg_pending;
+  std::map<long, WgGroupPlan> wg_plans;           // (stage, batch, budget) -> device tables
+  bool wg_group_on = true;
+  std::vector<int> conv_hin, conv_win;            // per conv: input map size (grouped-plan slab sizing)
   std::vector<int64_t> ws_off;       // per conv: offset of its weight-gradient slabs in ws_wg
   std::vector<int> upd_splits;       // per conv: slabs written by the current backward pass
   std::vector<UpdEntry*> upd_tab;    // per batch size: device copy of the update table
@@ -543,7 +555,124 @@ void side_flush(eosvos_engine* e) {
   e->side_q.clear();
   e->side_used = true;
 }
-// slabs of dW into ws_wg; returns the number of slabs
+// ---- grouped weight gradients ------------------------------------------------------------------------
+// K splits of the weight gradients of one group: every launch (one per tile shape) should fill the chip with
+// workgroups of about equal K length.  tau = (sum of tiles x K steps of the shape class) / workgroups the launch plans
+// for; a conv with `steps` K steps of 32 pixels is cut into ceil(steps / tau) splits (>= 4 steps each).
+struct WgGroupItem { int ci, P, cout, cin, T; };
+std::vector<int> plan_wgrad_splits(const std::vector<WgGroupItem>& items, int wg_budget) {
+  const int RES = conv_wg_budget_of(wg_budget);
+  std::vector<int> splits(items.size(), 1);
+  for (int bm : {128, 64})
+    for (int bn : {128, 64}) {
+      long work = 0;
+      for (const auto& it : items) {
+        if (wgrad_group_tile(it.cout) != bm || wgrad_group_tile(it.cin) != bn) continue;
+        const long tiles = (long)((it.cout + bm - 1) / bm) * ((it.cin + bn - 1) / bn) * it.T;
+        work += tiles * ((it.P + 31) / 32);
+      }
+      if (!work) continue;
+      // smallest tau whose workgroups all fit one resident round (a launch a little over one round would run its
+      // last workgroups alone: measured 556 workgroups at 113 TFLOP/s against 864 = 1.7 rounds at 163)
+      long tau = std::max<long>(4, (work + RES - 1) / RES);
+      auto count = [&](long t) {
+        long n = 0;
+        for (const auto& it : items) {
+          if (wgrad_group_tile(it.cout) != bm || wgrad_group_tile(it.cin) != bn) continue;
+          const long tiles = (long)((it.cout + bm - 1) / bm) * ((it.cin + bn - 1) / bn) * it.T;
+          const long steps = (it.P + 31) / 32;
+          long sp = (steps + t - 1) / t;
+          if (sp > steps / 4) sp = std::max<long>(1, steps / 4);
+          n += tiles * sp;
+        }
+        return n;
+      };
+      static const int rounds = getenv("EOSVOS_TUNE_WGRAD_GROUP_ROUNDS") ? atoi(getenv("EOSVOS_TUNE_WGRAD_GROUP_ROUNDS")) : 1;
+      if (rounds > 1) tau = std::max<long>(4, tau / rounds);
+      while (count(tau) > (long)RES * rounds && tau < (1L << 20)) tau += std::max<long>(1, tau / 32);
+      for (size_t k = 0; k < items.size(); ++k) {
+        const auto& it = items[k];
+        if (wgrad_group_tile(it.cout) != bm || wgrad_group_tile(it.cin) != bn) continue;
+        const long steps = (it.P + 31) / 32;
+        long sp = (steps + tau - 1) / tau;
+        if (sp > steps / 4) sp = std::max<long>(1, steps / 4);
+        splits[k] = (int)std::min<long>(sp, 512);
+      }
+    }
+  return splits;
+}
+bool wgrad_groupable(const eosvos_engine* e, int ci) {
+  static const bool off = getenv("EOSVOS_NO_WGRAD_GROUP") != nullptr;
+  // Measured at batch 3 (profiles/r03_ab_wgrad_group.txt): grouping layer3 (30 / 14 splits per conv -> 2, 578 -> 57 MB of
+  // slabs) leaves the two-stream step time unchanged; grouping layer2 / layer1 as well makes it 1 % LONGER although the
+  // summed kernel time drops by 0.3 ms -- their grouped launches start only after the stage's data-gradient chain and
+  // the last one runs with nothing beside it.  Default: layer3 only.
+  static const int min_stage = getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE") ? atoi(getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE")) : 2;
+  return !off && e->wg_group_on && conv_mfma_mode() == 1 && e->force_algo == 0 && ci < (int)e->t.stage.size() &&
+         e->t.stage[ci] >= min_stage && e->t.stage[ci] <= 2 && !e->conv_hin.empty();
+}
+// Launch the queued weight gradients (all of one stage) -- on the side stream when there is one.
+int flush_wgrad_group(eosvos_engine* e, int stage, int B) {
+  if (e->wg_pending.empty()) return 0;
+  const long key = ((long)stage * 64 + B) * 1024 + e->wg_budget;
+  auto it = e->wg_plans.find(key);
+  if (it == e->wg_plans.end()) {
+    std::vector<WgGroupItem> items;
+    for (auto& pa : e->wg_pending) {
+      const WgradArgs& a = pa.second;
+      items.push_back({pa.first, a.B * a.Ho * a.Wo, a.Cout, a.Cin, a.KH * a.KW});
+    }
+    eosvos_engine::WgGroupPlan plan;
+    plan.splits = plan_wgrad_splits(items, e->wg_budget);
+    for (int bm : {128, 64})
+      for (int bn : {128, 64}) {
+        std::vector<WgradArgs> tab;
+        std::vector<int> map;
+        double flops = 0;
+        int first = -1;
+        for (size_t k = 0; k < items.size(); ++k) {
+          const auto& im = items[k];
+          if (wgrad_group_tile(im.cout) != bm || wgrad_group_tile(im.cin) != bn) continue;
+          WgradArgs a = e->wg_pending[k].second;
+          a.splits = plan.splits[k];
+          a.ws = e->ws_wg + e->ws_off[im.ci];
+          const int tiles = ((im.cout + bm - 1) / bm) * ((im.cin + bn - 1) / bn) * im.T;
+          // workgroups of an entry in launch_wgrad's order: split-major, the taps of a (cout, cin) tile pair adjacent
+          for (int w = 0; w < tiles * a.splits; ++w) { map.push_back((int)tab.size()); map.push_back(w); }
+          flops += 2.0 * im.cout * im.cin * im.T * (double)im.P * wgrad_exec_frac(a);
+          if (first < 0) first = im.ci;
+          tab.push_back(a);
+        }
+        if (tab.empty()) continue;
+        eosvos_engine::WgGroupLaunch L;
+        L.dtab = (WgradArgs*)e->falloc((int64_t)(tab.size() * sizeof(WgradArgs) + 3) / 4);
+        L.dmap = (int*)e->falloc((int64_t)map.size());
+        if (!L.dtab || !L.dmap) return fail("hipMalloc grouped weight-gradient tables");
+        HIPOK(hipMemcpy(L.dtab, tab.data(), tab.size() * sizeof(WgradArgs), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(L.dmap, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+        L.nwg = (int)(map.size() / 2); L.bm = bm; L.bn = bn; L.flops = flops; L.first_ci = first;
+        plan.launches.push_back(L);
+      }
+    it = e->wg_plans.emplace(key, plan).first;
+  }
+  const eosvos_engine::WgGroupPlan& plan = it->second;
+  if (plan.splits.size() != e->wg_pending.size()) return fail("internal: grouped weight-gradient plan does not match the queue");
+  for (size_t k = 0; k < e->wg_pending.size(); ++k) e->upd_splits[e->wg_pending[k].first] = plan.splits[k];
+  e->wg_pending.clear();
+  for (const auto& L : plan.launches) {
+    if (trace_on()) fprintf(stderr, "EOSVOS_TRACE wgrad conv=%d M=%d N=%d K=%d splits=%d flops=%.0f\n", L.first_ci, L.bm, L.bn, 0, L.nwg, L.flops);
+    const eosvos_engine::WgGroupLaunch LL = L;
+    if (e->s2) {
+      hipStream_t s2 = e->s2;
+      e->side_q.push_back([LL, s2]() { launch_wgrad_group(LL.dtab, LL.dmap, LL.nwg, LL.bm, LL.bn, LL.flops, s2); });
+    } else {
+      launch_wgrad_group(LL.dtab, LL.dmap, LL.nwg, LL.bm, LL.bn, LL.flops, e->s);
+    }
+  }
+  if (e->s2) side_flush(e);
+  return 0;
+}
+// slabs of dW into ws_wg; returns the number of slabs (-1: queued for the stage's grouped launch, flush_wgrad_group)
 int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x, int ldx, int Hin, int Win, int B) {
   const ConvL& c = e->t.convs[ci];
   if (e->gn() && c.norm) {        // dz = GroupNorm backward of G_u, written over the stored raw output
@@ -592,6 +721,10 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     a.B = B; a.Ho = Ho; a.Wo = Wo;
     a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
     a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
+    if (wgrad_groupable(e, ci)) {
+      e->wg_pending.push_back({ci, a});
+      return -1;
+    }
     a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T(), e->wg_budget);
     trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits, wgrad_exec_frac(a));
     go = [=](hipStream_t ws) { launch_wgrad(a, ws); };
@@ -608,7 +741,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
 }
 // reduce slabs, scale by the frozen-norm a[cout], (optionally) theta <- theta - lr*g
 void apply_update(eosvos_engine* e, int ci, int splits, bool /*update*/, bool /*accumulate*/) {
-  e->upd_splits[ci] = splits;     // the slabs stay parked; flush_updates() consumes them
+  if (splits >= 0) e->upd_splits[ci] = splits;     // the slabs stay parked; flush_updates() consumes them
 }
 // one launch: sum every layer's slabs, norm scale, theta <- theta - lr*g, optional gsum/gout
 // part 0: convs [split, nconv) = layer4 + ASPP + decoder (90 % of the parameters), whose backward
@@ -757,8 +890,11 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   e->upd_tab.assign(2 * B + 2, nullptr);
   e->upd_blocks.assign(2 * B + 2, 0);
   std::vector<int64_t> slabs(t.convs.size(), 0);   // floats of slab space per conv (max over batch sizes)
+  e->conv_hin.assign(t.convs.size(), 0);
+  e->conv_win.assign(t.convs.size(), 0);
   auto track = [&](int ci, int Hin, int Win) {
     const ConvL& c = t.convs[ci];
+    e->conv_hin[ci] = Hin; e->conv_win[ci] = Win;
     const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
     const int Mf = B * Ho * Wo, Md = B * Hin * Win;
     (void)Md;
@@ -834,6 +970,21 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     slabs[t.last] = max64(slabs[t.last], (int64_t)last_bwd_chunks((int64_t)b * e->h4 * e->w4) * 257);
   }
   slabs[t.pool] = (int64_t)256 * 2048;
+  // grouped weight gradients of layer1..3 (flush_wgrad_group): their split counts come from the stage plan
+  for (int st = 0; st <= 2; ++st)
+    for (int b = 1; b <= B; ++b)
+      for (int wb = 0; wb <= 512; wb += 64) {
+        std::vector<WgGroupItem> items;
+        for (size_t ci = 0; ci < t.convs.size(); ++ci) {
+          if (t.stage[ci] != st) continue;
+          const ConvL& c = t.convs[ci];
+          const int Ho = conv_out(e->conv_hin[ci], c.k, c.stride, c.dil, c.pad), Wo = conv_out(e->conv_win[ci], c.k, c.stride, c.dil, c.pad);
+          items.push_back({(int)ci, b * Ho * Wo, c.cout, c.cin, c.T()});
+        }
+        const std::vector<int> sp = plan_wgrad_splits(items, wb);
+        for (size_t k = 0; k < items.size(); ++k)
+          slabs[items[k].ci] = max64(slabs[items[k].ci], (int64_t)sp[k] * t.convs[items[k].ci].wsize());
+      }
   for (size_t ci = 0; ci < t.convs.size(); ++ci) {
     e->ws_off[ci] = wsw;
     wsw += (slabs[ci] + 3) / 4 * 4;
@@ -1132,6 +1283,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
 // ---- backward + fused update ----------------------------------------------------------------------
 static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   e->side_q.clear();              // nothing may be left over from a call that failed half way
+  e->wg_pending.clear();
   const Topo& t = e->t;
   hipStream_t s = e->s;
   const int B = e->lastB;
@@ -1235,6 +1387,9 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
       conv_dgrad(e, b.c1, f.g_t1, cmid, f.Hi, f.Wi, f.g_xin, f.Cin, B, false, inmask, f.Cin, 0, f.g_out, cout);
       apply_update(e, b.c1, sp, update, accumulate);
     }
+    // first block of a ResNet layer: its data-gradient chain is queued, every operand of the stage's weight gradients
+    // is final -> one grouped launch per tile shape
+    if (b.ds >= 0 && flush_wgrad_group(e, t.stage[b.c1], B)) return 1;
   }
   // stem
   launch_maxpool_bwd(e->g_p1, e->p1idx, e->c1, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s);
@@ -1605,12 +1760,15 @@ int eosvos_bench_conv(eosvos_engine* e, int ci, int kind, int batch, int reps, f
   HIPOK(hipEventCreate(&b));
   hipStream_t side = e->s2;
   e->s2 = nullptr;                 // time everything on the main stream
+  const bool group_was = e->wg_group_on;
+  e->wg_group_on = false;          // one layer at a time: its own launch
   run();
   HIPOK(hipEventRecord(a, e->s));
   for (int i = 0; i < reps; ++i) run();
   HIPOK(hipEventRecord(b, e->s));
   HIPOK(hipEventSynchronize(b));
   e->s2 = side;
+  e->wg_group_on = group_was;
   float ms = 0.f;
   HIPOK(hipEventElapsedTime(&ms, a, b));
   *ms_host = ms / reps;
@@ -1643,6 +1801,8 @@ int eosvos_debug_tensor(eosvos_engine* e, const char* name, float** ptr, int64_t
   const int B = e->lastB > 0 ? e->lastB : 1;
   const std::string n(name);
   auto set = [&](float* p, int h, int w, int c) { *ptr = p; dims4[0] = B; dims4[1] = h; dims4[2] = w; dims4[3] = c; return 0; };
+  // folded frozen-norm scale / shift (a = gamma / sqrt(var + eps), b = beta - mean * a), all norm layers concatenated
+  if (n == "norm_a" || n == "norm_b") { *ptr = n == "norm_a" ? e->na : e->nb; dims4[0] = dims4[1] = dims4[2] = 1; dims4[3] = e->t.nnorm; return 0; }
   if (n == "c1") return set(e->c1, e->h2, e->w2, 64);
   if (n == "p1") return set(e->p1, e->h4, e->w4, 64);
   if (n == "g_c1") return set(e->g_c1, e->h2, e->w2, 64);

@@ -41,20 +41,21 @@ def _datasets(cfg, data_root, height, width, num_frames):
 
 
 def run(cfg, run_dir, device, data_root='data', height=480, width=854, num_frames=12, poll=0.25, once=False,
-        init_parent_model=None, MetaOptimizer=None, log=print):
-    from . import synthetic
+        init_parent_model=None, MetaOptimizer=None, log=print, parent_pid=None):
     from .checkpoint import load_meta_checkpoint
     from .evaluate import evaluate_dataset
+    from .train_meta import load_parent_state
     if init_parent_model is None:
         from .helper_func import init_parent_model
     if MetaOptimizer is None:
         from .meta_optim import MetaOptimizer
     snap = os.path.join(run_dir, 'eval_snapshot.model')
     stop = os.path.join(run_dir, 'eval_stop')
-    model, _ = init_parent_model(**cfg['parent_model'])
+    model, parent_states = init_parent_model(**cfg['parent_model'])
     model.to(device)
     model.max_batch = max(model.max_batch, cfg['data_cfg']['batch_sizes']['train'])
-    model.load_state_dict(synthetic.synthetic_state(cfg['parent_model']['encoder']))     # frozen norm statistics
+    enc = cfg['parent_model']['encoder']
+    load_parent_state(model, parent_states, None, enc)                # shapes for MetaOptimizer; per-dataset state below
     meta_optim = MetaOptimizer(model, **cfg['meta_optim_cfg'])
     readers = _datasets(cfg, data_root, height, width, num_frames)
     best = {k: 0.0 for k in readers}
@@ -65,6 +66,9 @@ def run(cfg, run_dir, device, data_root='data', height=480, width=854, num_frame
             seen = mtime
             sd, info = load_meta_checkpoint(snap)
             for key, ds in readers.items():
+                # the parent checkpoint of THIS dataset key (weights the learned init replaces + the frozen norm
+                # statistics it does not), evaluate.py:46-50
+                load_parent_state(model, parent_states, key, enc, log)
                 res = evaluate_dataset(model, meta_optim, sd, ds, cfg, key, save_dir=run_dir, meta_iter=info['meta_iter'],
                                        meta_epoch=info['meta_epoch'], best_mean_J=best[key], device=device,
                                        vis_win_names=info.get('vis_win_names'))
@@ -80,6 +84,9 @@ def run(cfg, run_dir, device, data_root='data', height=480, width=854, num_frame
             continue
         if os.path.exists(stop):
             return done
+        if parent_pid is not None and os.getppid() != parent_pid:     # the trainer died without writing eval_stop
+            log(json.dumps({'mode': 'concurrent_eval', 'exit': 'parent process is gone'}))
+            return done
         time.sleep(poll)
 
 
@@ -93,11 +100,13 @@ def main(argv=None, **hooks):
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--num-frames', type=int, default=12)
     ap.add_argument('--once', action='store_true')
+    ap.add_argument('--parent-pid', type=int, default=None, help='exit when this is no longer the parent process')
     a = ap.parse_args(argv)
     cfg = json.load(open(a.config))
     if a.device.startswith('cuda'):
         torch.cuda.set_device(torch.device(a.device))
-    return run(cfg, a.run_dir, a.device, a.data_root, a.height, a.width, a.num_frames, once=a.once, **hooks)
+    return run(cfg, a.run_dir, a.device, a.data_root, a.height, a.width, a.num_frames, once=a.once,
+               parent_pid=a.parent_pid, **hooks)
 
 
 if __name__ == '__main__':

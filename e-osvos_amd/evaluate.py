@@ -311,7 +311,14 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     pool = None
     if getattr(dataset, 'prefetchable', False) and seqs and os.environ.get('EOSVOS_EVAL_PREFETCH', '1') != '0':
         pool = ThreadPoolExecutor(max_workers=2)
-    load = lambda sq: copy.copy(dataset).sequence_tensors(sq, 'cpu', with_frame_ids=True)
+    def read(ds, sq, dev):
+        """(frames, train-frame masks, train frame per object); readers without late objects report frame 0."""
+        import inspect
+        if 'with_frame_ids' in inspect.signature(ds.sequence_tensors).parameters:
+            return ds.sequence_tensors(sq, dev, with_frame_ids=True)
+        fr, gs = ds.sequence_tensors(sq, dev)
+        return fr, gs, [0] * len(gs)
+    load = lambda sq: read(copy.copy(dataset), sq, 'cpu')
     budget_before = getattr(model, 'wg_budget', 0)
     ahead = pool.submit(load, seqs[0]) if pool else None
     finishing = []
@@ -333,7 +340,7 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
             if k + 1 < len(seqs):
                 ahead = pool.submit(load, seqs[k + 1])
         else:
-            frames, gts, fids = dataset.sequence_tensors(seq, device or model.device, with_frame_ids=True)
+            frames, gts, fids = read(dataset, seq, device or model.device)
         n = frames.shape[0]
         probs = torch.zeros(len(gts), n, *frames.shape[-2:], device=frames.device)
         t0 = time.perf_counter()

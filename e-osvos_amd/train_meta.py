@@ -21,6 +21,7 @@ no dataset is reachable from the build or bench boxes.
 import json
 import os
 import random
+import signal
 import subprocess
 import sys
 import time
@@ -70,6 +71,33 @@ def _train_tasksets(cfg, data_root):
     return ConcatTaskset(sets)
 
 
+def load_parent_state(model, parent_states, key, encoder, log=None):
+    """`model.load_state_dict(parent_states[key]['states'][0])` when `parent_model.<key>.paths` names a parent
+    checkpoint (`train_meta.py:91-96`, `evaluate.py:46-50`); only without one the seeded synthetic weights / norm
+    statistics (no pretrained file is reachable offline).  Returns 'file' or 'synthetic'."""
+    states = (parent_states.get(key) or {}).get('states') or []
+    if states:
+        if len(states) > 1:
+            raise NotImplementedError('more than one parent state per dataset (train_meta.py:92-93)')
+        model.load_state_dict(states[0])
+        src = 'file'
+    else:
+        model.load_state_dict(synthetic.synthetic_state(encoder))
+        src = 'synthetic'
+    if log is not None:
+        log(json.dumps({'parent_state': src, 'dataset_key': key}))
+    return src
+
+
+def resume_checkpoint_name(mode):
+    """`resume_meta_run_epoch_mode` -> file name (`train_meta.py:70-77`)."""
+    if mode == 'LAST':
+        return 'last_meta_iter.model'
+    if mode and 'BEST' in mode:
+        return f"best_{mode.split('_')[1].lower()}_meta_iter.model"
+    raise NotImplementedError(mode)
+
+
 def _start_eval_process(cfg, run_dir, device, data_root, height, width, num_frames, eval_cmd):
     """Child process for the datasets with `eval: True` (train_meta.py:175-186).  Must run before this process
     initialises the GPU."""
@@ -81,13 +109,32 @@ def _start_eval_process(cfg, run_dir, device, data_root, height, width, num_fram
     json.dump(cfg, open(cfg_path, 'w'))
     cmd = list(eval_cmd) if eval_cmd else [sys.executable, '-m', 'eosvos_amd.eval_worker']
     cmd += ['--run-dir', run_dir, '--config', cfg_path, '--device', device, '--data-root', data_root,
-            '--height', str(height), '--width', str(width), '--num-frames', str(num_frames)]
+            '--height', str(height), '--width', str(width), '--num-frames', str(num_frames), '--parent-pid', str(os.getpid())]
     return subprocess.Popen(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data_root='data', eval_cmd=None,
+def _stop_eval_process(eval_proc, run_dir, timeout=600):
+    """Ask the validation child to finish (it exits after the snapshot it is working on); kill it if it does not."""
+    if eval_proc is None:
+        return
+    try:
+        open(os.path.join(run_dir, 'eval_stop'), 'w').close()
+        eval_proc.wait(timeout=timeout)
+    except Exception:
+        eval_proc.terminate()
+        try:
+            eval_proc.wait(timeout=30)
+        except Exception:
+            eval_proc.kill()
+
+
+def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=None, data_root='data', eval_cmd=None,
          device=None):
+    """`num_meta_iters`: None = run until SIGINT / SIGTERM like the reference's `while True` (`train_meta.py:207`; the
+    iteration in flight is finished and checkpointed), or EOSVOS_NUM_META_ITERS; a number for tests and benchmarks."""
     cfg = config_mod.parse_cli(sys.argv[1:] if argv is None else argv)
+    if num_meta_iters is None and os.environ.get('EOSVOS_NUM_META_ITERS'):
+        num_meta_iters = int(os.environ['EOSVOS_NUM_META_ITERS'])
     run = cfg['env_suffix'] or 'run'
     run_dir = os.path.join(cfg['save_dir'], run)
     meta_mode = cfg['num_meta_processes_per_gpu'] != 0
@@ -101,23 +148,34 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
         eval_dev = device or (f'cuda:{cfg["num_eval_gpus"] - 1}' if cfg['num_eval_gpus'] else f'cuda:{max(n_local - 1, 0)}')
         eval_proc = _start_eval_process(cfg, run_dir, eval_dev, data_root, height, width, num_frames, eval_cmd)
 
+    try:
+        return _run(cfg, run, run_dir, meta_mode, eval_proc, height, width, num_frames, num_meta_iters, data_root, device)
+    finally:
+        # whatever ended the run (normal exit, data error, NaN assert, dist failure, KeyboardInterrupt): the validation
+        # child must not keep polling for snapshots on a GPU it shares with a meta rank
+        _stop_eval_process(eval_proc, run_dir)
+
+
+def _run(cfg, run, run_dir, meta_mode, eval_proc, height, width, num_frames, num_meta_iters, data_root, device):
     dist, rank, world, local = _dist()
     dev = device or f'cuda:{local}'
     ck_last = checkpoint_names(cfg['save_dir'], run)['last']
+    log = (lambda line: print(line, flush=True)) if rank == 0 else None
 
     pm = dict(cfg['parent_model'])
-    model, _ = init_parent_model(**pm)
+    model, parent_states = init_parent_model(**pm)
     model.to(dev)
     model.max_batch = max(model.max_batch, *cfg['data_cfg']['batch_sizes'].values())
-    model.load_state_dict(synthetic.synthetic_state(pm['encoder']))       # no pretrained weights offline
+    load_parent_state(model, parent_states, 'train', pm['encoder'], log)      # train_meta.py:91-96
     set_random_seeds(cfg['seed'])      # every rank draws the SAME initial lrs (the reference builds them once, in main)
     meta_optim = MetaOptimizer(model, **cfg['meta_optim_cfg'])
     meta_iter = 0
     if cfg['meta_optim_model_file']:
         sd, _ = load_meta_checkpoint(cfg['meta_optim_model_file'])
         meta_optim.load_state_dict(sd)
-    if cfg['resume_meta_run_epoch_mode'] == 'LAST' and os.path.exists(ck_last):
-        sd, info = load_meta_checkpoint(ck_last)
+    if cfg['resume_meta_run_epoch_mode'] is not None:                          # train_meta.py:70-77,103-104
+        ck_resume = os.path.join(run_dir, resume_checkpoint_name(cfg['resume_meta_run_epoch_mode']))
+        sd, info = load_meta_checkpoint(ck_resume)                             # a missing file is an error, as in the reference
         meta_optim.load_state_dict(sd)
         meta_iter = info['meta_iter'] or 0
 
@@ -136,6 +194,7 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
             cfg['datasets']['val'] = dict(cfg['datasets'].get('val', {}), name='synthetic', split='val', eval=True)
             readers['val'] = data_mod.SyntheticSequences(1, num_frames, height, width, seed=cfg['seed'])
         for key, reader in readers.items():
+            load_parent_state(model, parent_states, key, pm['encoder'], log)   # evaluate.py:46-50
             results[key] = evaluate_dataset(model, meta_optim, meta_optim.state_dict(), reader, cfg, key, save_dir=run_dir,
                                             meta_iter=meta_iter, meta_epoch=0, dist=dist if world > 1 else None, device=dev)
         if dev.startswith('cuda'):
@@ -197,12 +256,24 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
                 out.append((ts, item, pool.submit(ts.load_frames, item) if pool else None))
             return out
         prefetched = draw_and_prefetch()
-    for it in range(num_meta_iters):
+    # `while True` of train_meta.py:207: runs until stopped.  SIGINT / SIGTERM finish the iteration in flight, write
+    # last_meta_iter.model and leave; every rank agrees on the stop through the flag summed into the all-reduce below.
+    stop = {'flag': False}
+    handlers = {}
+    if num_meta_iters is None:
+        for sig in (signal.SIGINT, signal.SIGTERM):
+            try:
+                handlers[sig] = signal.signal(sig, lambda *_: stop.__setitem__('flag', True))
+            except ValueError:                                  # not the main thread (tests)
+                pass
+    it = 0
+    while num_meta_iters is None or it < num_meta_iters:
+        last = num_meta_iters is not None and it + 1 == num_meta_iters
         tasks = []
         if tasksets is not None:
             current = prefetched
             tasks = [ts.task_tensors(item, eng, dev, host=fut.result() if fut else None) for ts, item, fut in current]
-            if it + 1 < num_meta_iters:
+            if not last:
                 prefetched = draw_and_prefetch()
         else:
             for t in range(rank, cfg['meta_batch_size'], world):           # synthetic: task t of the meta-batch
@@ -212,20 +283,27 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=2, data
         losses = mt.meta_iteration(tasks, inner_steps=cfg['num_epochs']['train'], bptt_epochs=cfg['bptt_epochs'],
                                    multi_step_bptt_loss=cfg['multi_step_bptt_loss'] or None)
         done = meta_iter + it + 1
+        if dist is not None:                                    # one decision for all ranks
+            flag = torch.tensor([1.0 if stop['flag'] else 0.0], device=mt.state.device)
+            dist.all_reduce(flag)
+            stop['flag'] = bool(flag.item() > 0)
+        last = last or stop['flag']
         if rank == 0:
             print(json.dumps({'mode': 'meta', 'data': 'files' if tasksets is not None else 'synthetic', 'meta_iter': done,
-                              'meta_losses': losses, 'skipped_tasks': mt.skipped_tasks}))
-            if done % cfg['vis_interval'] == 0 or it == num_meta_iters - 1:
+                              'meta_losses': losses, 'skipped_tasks': mt.skipped_tasks}), flush=True)
+            if done == 1 or done % cfg['vis_interval'] == 0 or last:            # train_meta.py:275-286 (+ the last one)
                 save_meta_checkpoint(ck_last, mt.state_dict(), done, 0)
                 if eval_proc is not None:                                   # snapshot for the validation process (atomic)
                     tmp = os.path.join(run_dir, 'eval_snapshot.tmp')
                     save_meta_checkpoint(tmp, mt.state_dict(), done, 0)
                     os.replace(tmp, os.path.join(run_dir, 'eval_snapshot.model'))
+        it += 1
+        if last:
+            break
+    for sig, h in handlers.items():
+        signal.signal(sig, h)
     if pool is not None:
         pool.shutdown(wait=True)
-    if eval_proc is not None:
-        open(os.path.join(run_dir, 'eval_stop'), 'w').close()
-        eval_proc.wait()
     if dist is not None:
         dist.destroy_process_group()
     return mt

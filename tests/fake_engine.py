@@ -40,6 +40,7 @@ class FakeEngine:
         self.infer_fn = None                            # optional (engine, images) -> probs hook of a test
         self._logits = self._x = self._dl = None
         self.last_masks = None
+        self.norm_args = None
         FakeEngine.instances.append(self)
 
     # ---- state ----
@@ -53,8 +54,8 @@ class FakeEngine:
         self.init = flat.detach().float().cpu().clone()
         self.theta = self.init.clone()
 
-    def set_norm(self, *a, **k):
-        pass
+    def set_norm(self, gamma, beta, mean, var, eps=1e-5):
+        self.norm_args = tuple(t.detach().float().cpu().clone() for t in (gamma, beta, mean, var))
 
     def lr_store_count(self, level):
         return {'NEURON': self.n_lr, 'TENSOR': len(self.shapes), 'SINGLE': 1, 'PARAM': self.n_param}[level]

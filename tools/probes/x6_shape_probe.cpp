@@ -198,6 +198,118 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
   }
 }
 
+// Ping-pong: ONE 512-thread workgroup per CU = two 4-wave groups, each with its own tile and its own LDS stage, running
+// the same K loop half a period apart: while group 0 multiplies (MFMA + fragment reads) group 1 splits and stores its
+// next K step (VALU + ds_write), then the roles swap; one workgroup barrier per phase.  Same work per wave as the
+// adopted kernel; what changes is that the two waves of a SIMD are ALWAYS in complementary phases (two independent
+// 256-thread workgroups drift in and out of lockstep).
+template <int PRIO>
+__global__ __launch_bounds__(512, 2) void gemm_pingpong_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                               float* __restrict__ C, int M, int N, int K) {
+  constexpr int BM = 128, BN = 128, BK = 32, NP = 3, PITCH = 96;
+  constexpr int OP_BYTES = NP * BM * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_all[4 * OP_BYTES];
+  const int tid5 = threadIdx.x, grp = tid5 >> 8, tid = tid5 & 255, lane = tid & 63, wave = tid >> 6;
+  unsigned char* As = smem_all + grp * 2 * OP_BYTES;
+  unsigned char* Bs = As + OP_BYTES;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = N / BN;
+  const int tile = 2 * xcd_remap(blockIdx.x, gridDim.x) + grp;
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int c4 = tid & 7;
+  const int j = lane >> 3;
+  const int row = (wave << 3) + ((j & 1) << 1) + ((j >> 1) & 1) + (j & 4);
+  float4 ra[4], rb[4];
+  auto load = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + 32 * i) * K + ks * BK + c4 * 4);
+    }
+  };
+  auto store_op = [&](unsigned char* S, const float4* rv) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = row + 32 * i;
+      float4 v = rv[i];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        uint2 w;
+        w.x = pack_hi(v.x, v.y);
+        w.y = pack_hi(v.z, v.w);
+        *reinterpret_cast<uint2*>(S + p * BM * PITCH + rr * PITCH + c4 * 8) = w;
+        if (p + 1 < NP) { v.x -= trunc_bf16(v.x); v.y -= trunc_bf16(v.y); v.z -= trunc_bf16(v.z); v.w -= trunc_bf16(v.w); }
+      }
+    }
+  };
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+  auto mma = [&]() {
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn) {
+      bf16x8 fa[4][NP], fb[2][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t][p] = *reinterpret_cast<const bf16x8*>(As + p * BM * PITCH + (wm * 64 + t * 16 + r) * PITCH + q * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BM * PITCH + (wn * 64 + (hn * 2 + t) * 16 + r) * PITCH + q * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x4 c = acc[tm][hn * 2 + tn];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm][2], fb[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm][0], fb[tn][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm][1], fb[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm][1], fb[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm][0], fb[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm][0], fb[tn][0], c, 0, 0, 0);
+          acc[tm][hn * 2 + tn] = c;
+        }
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  const int nk = K / BK;
+  // group 0: [load k+1, mma k] [store k+1] ...; group 1 runs the same sequence one phase later
+  load(0);
+  if (grp == 0) { store_op(As, ra); store_op(Bs, rb); }
+  __syncthreads();
+  for (int ph = 0; ph < 2 * nk + 1; ++ph) {
+    const int t = ph - grp;                   // this group's own phase counter
+    if (t >= 0 && t < 2 * nk) {
+      const int ks = t >> 1;
+      if ((t & 1) == 0) {                     // multiply step ks; next step's loads in flight behind it
+        if (ks + 1 < nk) load(ks + 1);
+        mma();
+      } else if (ks + 1 < nk) {               // split + store step ks + 1
+        store_op(As, ra); store_op(Bs, rb);
+      }
+    } else if (t == -1) {                     // group 1's first phase: store its step 0
+      store_op(As, ra); store_op(Bs, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + tm * 16 + 4 * q + e;
+        const int n = n0 + wn * 64 + tn * 16 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e];
+      }
+}
+
 template <int SHAPE, int PITCH, int PRIO>
 static void run(const char* name, const float* dA, const float* dB, float* dC, int M, int N, int K, const std::vector<float>& hA,
                 const std::vector<float>& hB) {
@@ -205,7 +317,10 @@ static void run(const char* name, const float* dA, const float* dB, float* dC, i
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  auto go = [&]() { hipLaunchKernelGGL((gemm_kernel<SHAPE, PITCH, PRIO>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K); };
+  auto go = [&]() {
+    if (SHAPE == 99) hipLaunchKernelGGL((gemm_pingpong_kernel<PRIO>), dim3(tiles / 2), dim3(512), 0, 0, dA, dB, dC, M, N, K);
+    else hipLaunchKernelGGL((gemm_kernel<SHAPE == 99 ? 16 : SHAPE, SHAPE == 99 ? 96 : PITCH, PRIO>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K);
+  };
   for (int i = 0; i < 3; ++i) go();
   CK(hipDeviceSynchronize());
   const int reps = 20;
@@ -252,9 +367,9 @@ int main() {
     CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
     run<32, 80, 0>("32x32x16 pitch80", dA, dB, dC, M, N, K, hA, hB);
     run<16, 96, 0>("16x16x32 pitch96", dA, dB, dC, M, N, K, hA, hB);
-    run<16, 64, 0>("16x16x32 swizzle64", dA, dB, dC, M, N, K, hA, hB);
-    run<32, 80, 1>("32x32x16 pitch80 prio", dA, dB, dC, M, N, K, hA, hB);
     run<16, 96, 1>("16x16x32 pitch96 prio", dA, dB, dC, M, N, K, hA, hB);
+    run<99, 96, 0>("pingpong 2x4 waves", dA, dB, dC, M, N, K, hA, hB);
+    run<99, 96, 1>("pingpong 2x4 waves prio", dA, dB, dC, M, N, K, hA, hB);
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
   }
   return 0;
