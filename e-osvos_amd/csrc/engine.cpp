@@ -199,7 +199,9 @@ struct eosvos_engine {
   std::map<int, float*> wino_V, wino_U, wino_Us, wino_dM;   // Us = a[cout] * U (data gradient), made with U  // dM = A dY A^T: made once per backward, read by wgrad and dgrad
   std::map<int, int> wino_v_batch;                // batch size V was computed for (0 = stale)
   std::map<int, int> wino_dm_batch;               // batch size dM is valid for (0 = stale)
-  std::map<int, int> wino_us_valid;               // Us matches the current weights (set by the forward, cleared by an update)
+  std::map<int, int> wino_us_valid;               // U / Us match the current weights (set when they are made, cleared by every weight change)
+  hipEvent_t ev_wino_w = nullptr;                 // the side stream has made the transformed weights of this forward
+  bool wino_w_wait = false;
   float *wino_m = nullptr, *wino_dv = nullptr;    // forward M planes; data-gradient dV planes (transient)
   int64_t wino_m_n = 0;
   int norm_mode = 0;                  // EOSVOS_NORM_BN_FROZEN / EOSVOS_NORM_GN16
@@ -418,14 +420,16 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     const WinoGeom wg = wino_geom(e, c, B, a.Ho, a.Wo);
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
-    e->wino_us_valid[ci] = 1;
-    if (wg.tm == 4) {
-      launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
-      launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
-    } else {
-      launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
-      launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
+    // U = G w G^T (and a[cout] * U for the data gradient) only when the weights changed since it was last made; a
+    // forward with a side stream has already queued all of them there (forward_impl), beside layer1..3
+    if (e->wino_w_wait) { (void)hipStreamWaitEvent(st, e->ev_wino_w, 0); e->wino_w_wait = false; }
+    if (!e->wino_us_valid[ci]) {
+      if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
+      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
+      e->wino_us_valid[ci] = 1;
     }
+    if (wg.tm == 4) launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
+    else launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
     e->wino_v_batch[ci] = B;
     ConvArgs m = wino_fwd_gemm(e, ci, wg, a.ws);
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
@@ -485,6 +489,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     if (!e->wino_us_valid[ci]) {                     // no forward since the weights changed: rebuild a[cout] * U
       if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s);
       else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s);
+      e->wino_us_valid[ci] = 1;
     }
     ConvArgs m;
     memset(&m, 0, sizeof(m));
@@ -1009,6 +1014,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
 #endif
       e->ev.resize(t.convs.size() + 2);
       for (auto& evt : e->ev) HIPOK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
+      HIPOK(hipEventCreateWithFlags(&e->ev_wino_w, hipEventDisableTiming));
       e->ws_conv2 = e->falloc(conv_ws_floats());
       if (!e->ws_conv2) { eosvos_destroy(e); return fail("hipMalloc side workspace"); }
     }
@@ -1032,6 +1038,7 @@ int eosvos_destroy(eosvos_engine* e) {
   (void)hipStreamSynchronize(e->s);
   if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
   for (auto& evt : e->ev) (void)hipEventDestroy(evt);
+  if (e->ev_wino_w) (void)hipEventDestroy(e->ev_wino_w);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
   return 0;
@@ -1227,6 +1234,23 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
     (void)hipEventRecord(e->ev[ci], s);
     (void)hipStreamWaitEvent(e->s2, e->ev[ci], 0);
   };
+  if (fside && e->ev_wino_w && e->force_algo == 0) {
+    // Winograd-domain weights depend on the weights only: all of them are made on the side stream now, beside the stem
+    // and layer1..3, instead of in front of each Winograd conv on the critical path
+    bool any = false;
+    for (auto& kv : e->wino_us_valid) {
+      const int ci = kv.first;
+      if (kv.second || ci >= (int)e->conv_hin.size() || !e->conv_hin[ci]) continue;
+      const ConvL& c = t.convs[ci];
+      const int Ho = conv_out(e->conv_hin[ci], c.k, c.stride, c.dil, c.pad), Wo = conv_out(e->conv_win[ci], c.k, c.stride, c.dil, c.pad);
+      if (!wino_on(e, ci, B, Ho, Wo)) continue;
+      if (!any) { fork(0); any = true; }
+      if (wino_geom(e, c, B, Ho, Wo).tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s2);
+      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s2);
+      kv.second = 1;
+    }
+    if (any) { (void)hipEventRecord(e->ev_wino_w, e->s2); e->wino_w_wait = true; }
+  }
   for (size_t i = 0; i < t.blocks.size(); ++i) {
     const Block& b = t.blocks[i];
     auto& f = e->bb[i];

@@ -66,8 +66,9 @@ class Dataset:
     """What `evaluate()` touches of `VOSDataset` (vos_dataset.py): sequence / object selection, the train frame,
     the propagated pseudo ground truth, `__getitem__` -> {'image', 'gt', 'file_name'}."""
 
-    def __init__(self, sc, log):
+    def __init__(self, sc, log, hw=None, frame_image=frame_image, object_gt=object_gt):
         self.sc, self.log = sc, log
+        self.hw, self._frame_image, self._object_gt = hw or HW, frame_image, object_gt
         self.seqs_names = list(sc['seqs'])
         self.crop_size = 1
         self.transform = 'random_transform'
@@ -94,10 +95,10 @@ class Dataset:
 
     def __getitem__(self, i):
         obj = self.multi_object_id or 0
-        gt = object_gt(self.seq, obj, HW)
+        gt = self._object_gt(self.seq, obj, self.hw)
         if self.propagate_frame_gt is not None:
             gt = torch.from_numpy(np.ascontiguousarray(self.propagate_frame_gt.transpose(2, 0, 1)))
-        return {'image': frame_image(i, HW), 'gt': gt, 'file_name': f'{i:05d}'}
+        return {'image': self._frame_image(i, self.hw), 'gt': gt, 'file_name': f'{i:05d}'}
 
 
 class TrainLoader:
@@ -152,7 +153,8 @@ class Recorder:
         self.log, self.save_dir, self.name = log, save_dir, name
 
     def imsave(self, path, arr):
-        self.log.append(['imsave', os.path.relpath(path, self.save_dir), np.asarray(arr)[..., 0].astype(int).tolist()])
+        a = np.asarray(arr)[..., 0]
+        self.log.append(['imsave', os.path.relpath(path, self.save_dir), a.astype(int).tolist() if a.size < 4096 else a.astype(np.uint8)])
 
 
 class Plt:
@@ -168,7 +170,12 @@ class Plt:
         self.log.append(['debug_png', os.path.relpath(path, self.save_dir)])
 
 
-def run(sc):
+def run(sc, hw=None, model_factory=None, meta_state=None, run_loader_factory=None, frame_image=frame_image, object_gt=object_gt,
+        log_labels=True):
+    """`evaluate()` on scenario `sc`.  Defaults = G12 (2-parameter model, prescribed probabilities).  make_g17.py passes the
+    reference DeepLabV3Plus (`model_factory(log)`), its learned state (`meta_state`) and a `run_loader` that runs it
+    (`run_loader_factory(log) -> run_loader`; the reference's own `run_loader` dereferences `model.rpn`)."""
+    hw = hw or HW
     log = []
     save_dir = tempfile.mkdtemp()
     model_log = log
@@ -184,7 +191,7 @@ def run(sc):
                               'num_epochs': sc['ona_epochs'], 'min_prop': 0.5},
         'num_epochs': {'eval': sc['eval_epochs'], 'train': 5},
     }
-    train_ds, test_ds, meta_ds = Dataset(sc, log), Dataset(sc, log), Dataset(sc, log)
+    train_ds, test_ds, meta_ds = (Dataset(sc, log, hw, frame_image, object_gt) for _ in range(3))
 
     def data_loaders(_dataset, **_cfg):
         return TrainLoader(train_ds, sc['batch'], log), Loader(test_ds), Loader(meta_ds)
@@ -193,8 +200,10 @@ def run(sc):
         idx = list(loader.sampler.indices)
         obj = loader.dataset.multi_object_id
         log.append(['run_loader', idx, float(start_targets.sum())])
-        probs = torch.stack([prob_map(loader.dataset.seq, obj, f, HW) for f in idx]) if idx else torch.zeros(0, 1, *HW)
+        probs = torch.stack([prob_map(loader.dataset.seq, obj, f, hw) for f in idx]) if idx else torch.zeros(0, 1, *hw)
         return None, None, probs, torch.zeros(len(idx), 1, 4)
+    if run_loader_factory is not None:
+        run_loader = run_loader_factory(log)
 
     orig = {k: getattr(ev, k) for k in ('init_parent_model', 'data_loaders', 'run_loader', 'eval_loader', 'eval_davis_seq',
                                         'imageio', 'plt', 'torch', 'set_random_seeds', 'compute_loss', 'MetaOptimizer')}
@@ -221,7 +230,7 @@ def run(sc):
             log.append(['mo.step'])
             return super().step(loss)
 
-    ev.init_parent_model = lambda **kw: (TinyModel(model_log), {})
+    ev.init_parent_model = (lambda **kw: (model_factory(model_log), {})) if model_factory else (lambda **kw: (TinyModel(model_log), {}))
     ev.data_loaders = data_loaders
     ev.run_loader = run_loader
     ev.eval_loader = lambda *a, **k: (None, None, [0.0], None)
@@ -235,7 +244,7 @@ def run(sc):
     ev.MetaOptimizer = LoggedMetaOptimizer
     try:
         torch.manual_seed(0)
-        msd = MetaOptimizer(TinyModel([]), **cfg['meta_optim_cfg']).state_dict()
+        msd = meta_state if meta_state is not None else MetaOptimizer(TinyModel([]), **cfg['meta_optim_cfg']).state_dict()
         shared = SharedDict(meta_iter=None, best_mean_J=0.0)
         try:
             ev.evaluate(0, 'val', msd, {'meta_iter': 3, 'meta_epoch': 1}, cfg, shared, save_dir, {}, True,

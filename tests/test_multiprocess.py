@@ -84,3 +84,27 @@ def test_evaluation_sharded_over_ranks_equals_single_process(tmp_path):
         assert torch.equal(a['labels'][seq], one['labels'][seq]) and torch.equal(b['labels'][seq], one['labels'][seq])
     assert a['J_seq'] == one['J_seq']
     assert os.path.exists(os.path.join(str(tmp_path / 's2'), 'best_eval_preds', 'DAVIS-2017', 'val_seqs', 'bear', '00000.png'))
+
+
+@pytest.mark.parametrize('mbs', [4, 8])
+def test_meta_iteration_four_ranks_nan_task_and_short_tail(tmp_path, mbs):
+    """world_size 4 (BASELINE configs[3] / [4] shapes): meta_batch_size 4 (one task per rank) and 8 (two per rank: the
+    concurrent-engine path), one NaN task on one rank, one iteration in which some ranks have fewer (or no) tasks -- every
+    rank takes part in every all-reduce and applies the same outer step (`src/util/meta_run.py:39,209-243`,
+    `src/train_meta.py:361-373`); the result equals the single-process run of the same tasks."""
+    out4, out1 = str(tmp_path / 'w4'), str(tmp_path / 'w1')
+    launch('meta_ws_worker.py', [out4, str(mbs)], 4, 29551 + mbs)
+    env = dict(os.environ, OMP_NUM_THREADS='2', WORLD_SIZE='1', RANK='0')
+    env.pop('MASTER_ADDR', None)
+    assert subprocess.Popen([sys.executable, os.path.join(W, 'meta_ws_worker.py'), out1, str(mbs)], env=env).wait(timeout=900) == 0
+    res = [torch.load(f'{out4}.{r}', weights_only=False) for r in range(4)]
+    one = torch.load(f'{out1}.0', weights_only=False)
+    for r in res:
+        assert r['step'] == 4 and r['collectives'] == 4                # no rank skipped a collective, short task list or not
+        assert torch.equal(r['state'], res[0]['state'])                # identical outer step everywhere
+        assert r['engines'] == (2 if mbs == 8 else 1)
+    assert sum(r['skipped'] for r in res) == 1 == one['skipped']       # the NaN task, counted once
+    assert [len(l) for l in res[3]['losses']] == ([1, 1, 1, 0] if mbs == 4 else [2, 2, 2, 1])      # rank 3 lost tasks in the tail
+    assert [len(l) for l in res[0]['losses']] == ([1, 1, 1, 1] if mbs == 4 else [2, 2, 2, 2])
+    assert torch.allclose(one['state'], res[0]['state'], rtol=1e-5, atol=1e-8)
+    assert float((one['state'] - res[0]['state']).abs().max()) < 1e-6
