@@ -39,7 +39,7 @@ H, W, BATCH = 480, 854, 3
 FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad as direct convolutions, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_DENSE_PEAK = 2500.0            # TFLOP/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_dominant_kernel.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant_kernel.json')
 
 
 def matrix_peak(mode):
@@ -50,6 +50,19 @@ def matrix_peak(mode):
 def cpu_threads():
     # oneDNN stops scaling (and thrashes) far below the hardware threads of the GPU box's host
     return min(os.cpu_count() or 1, 32)
+
+
+def cpu_model():
+    """Model string and thread count of the host the CPU baseline runs on ('state core count and CPU model')."""
+    name = None
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                name = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {'model': name, 'hardware_threads': os.cpu_count()}
 
 
 def cpu_baseline_finetune(sd, lrs, x, y, seconds_budget=25.0):
@@ -66,7 +79,7 @@ def cpu_baseline_finetune(sd, lrs, x, y, seconds_budget=25.0):
         dt = time.time() - t0
         if n >= 3 and (dt > seconds_budget or n >= 8):
             break
-    return {'value': n / dt, 'unit': 'finetune_iters/s', 'cores': cores, 'kind': 'port',
+    return {'value': n / dt, 'unit': 'finetune_iters/s', 'cores': cores, 'kind': 'port', 'cpu': cpu_model(),
             'sample': f'{n} batch-{x.shape[0]} fine-tune iterations ({H}x{W}, the benchmarked workload) of the torch-CPU '
                       f'oracle (oracle/meta.py) on {cores} threads in {dt:.1f}s after 1 warm-up iteration'}
 
@@ -80,7 +93,7 @@ def cpu_baseline_meta(sd, lrs, x1, y1, xm, ym):
     t0 = time.time()
     meta.meta_task(sd, lrs, [(x1, y1)] * 5, (xm, ym))
     dt = time.time() - t0
-    return {'value': 1.0 / dt, 'unit': 'meta_tasks/s', 'cores': cores, 'kind': 'port',
+    return {'value': 1.0 / dt, 'unit': 'meta_tasks/s', 'cores': cores, 'kind': 'port', 'cpu': cpu_model(),
             'sample': f'1 meta task (5 inner steps + 1 meta frame, batch 1, {H}x{W}) of the torch-CPU oracle '
                       f'(oracle/meta.py meta_task) on {cores} threads in {dt:.1f}s after 1 warm-up inner step'}
 
@@ -139,6 +152,14 @@ def roofline_from(rows, steps, mode, lib_version, batch, ms_per_step):
     }
 
 
+def timed_median(fn, steps, barrier, dist, dev, repeats=None):
+    """Timed region of EXACTLY `steps` steps; when it is short (< 100 steps) it is run three times and the MEDIAN is
+    reported (one 0.2 s sample is at the mercy of the clock the chip happens to hold).  Returns (seconds, all samples)."""
+    reps = repeats if repeats is not None else (3 if steps < 100 else 1)
+    samples = sorted(timed(fn, steps, barrier, dist, dev) for _ in range(reps))
+    return samples[len(samples) // 2], samples
+
+
 def timed(fn, steps, barrier, dist, dev):
     barrier()
     t0 = time.perf_counter()
@@ -187,8 +208,13 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, m
     mt, step, losses, extra = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory)
     for _ in range(a.warmup):
         step()
-    dt = timed(step, a.steps, barrier, dist, dev)
+    dt, samples = timed_median(step, a.steps, barrier, dist, dev)
     ms_per_step = 1e3 * dt / a.steps
+    mt.profile = {}
+    for _ in range(2):
+        step()                                                                  # all-reduce / outer-step split (drains the GPU per phase)
+    split = {k: v / mt.profile['iterations'] for k, v in mt.profile.items() if k != 'iterations'}
+    mt.profile = None
     rows, _ = profiled_pass(eng, step, min(a.steps, 4))
     roof = roofline_from(rows, min(a.steps, 4), mode, lib_version, 1, ms_per_step)
     cpu = None
@@ -208,7 +234,8 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, m
                        'meta_batch_size': world * tpr, 'tasks_per_rank': tpr, 'inner_steps': 5, 'height': H, 'width': W,
                        'parallelism': f'tasks sharded x{world}'},
             'roofline': roof, 'cpu_baseline': cpu,
-            'extra': {'last_meta_loss': losses[-1], 'matrix_mode': mode, 'lib_version': lib_version},
+            'extra': {'last_meta_loss': losses[-1], 'matrix_mode': mode, 'lib_version': lib_version,
+                      'timed_region_samples_s': samples, 'phase_ms_per_meta_iteration': split},
         }
         print(json.dumps(out), flush=True)
     eng.close()
@@ -282,7 +309,7 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
     step = lambda: eng.finetune_step(xg, yg, sync_loss=False)
     for _ in range(a.warmup):
         step()
-    dt = timed(step, a.steps, barrier, dist, dev)
+    dt, samples = timed_median(step, a.steps, barrier, dist, dev)
     ms_per_step = 1e3 * dt / a.steps
     value = world * a.steps / dt
     last_loss = eng.finetune_step(xg, yg)           # sanity: still finite after K steps
@@ -318,13 +345,47 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
                 'avg_launch_us': 1e3 * ms1 / l1, 'ms_per_step': 1e3 * s1,
                 'all_matrix_kernels_tflops': sum(v[2] for v in mf1.values()) / (sum(v[1] for v in mf1.values()) * 1e-3) / 1e12}
 
-    extra = {'last_loss': last_loss, 'matrix_mode': mode, 'lib_version': lib_version,
+    extra = {'last_loss': last_loss, 'matrix_mode': mode, 'lib_version': lib_version, 'timed_region_samples_s': samples,
              'mfma_probe_fp32_tflops': eng.mfma_probe(),
              'direct_conv_equivalent_tflops': BATCH * FLOPS_PER_FRAME_ITER / (ms_per_step * 1e-3) / 1e12,
              'conv_algorithms': 'fp32 arithmetic throughout; contractions on the bf16 matrix cores by exact 3-way operand '
                                 'split + 6 partial products (bf16x6); 6 of the 63 convs (decoder 3x3 x2, layer4 conv2 x3: '
                                 'Winograd F(4x4,3x3); ASPP d=6: F(2x2,3x3)) run all three passes in the Winograd domain; '
                                 'direct_conv_equivalent_tflops counts 9-tap-equivalent FLOPs, roofline.* executed FLOPs'}
+    # fine-tune iterations/s for the C1 / C3 shapes as well (C2 is the headline).
+    n1 = min(a.steps, 60)
+    step_b1 = lambda: eng.finetune_step(xg[:1], yg[:1], sync_loss=False)
+    for _ in range(3):
+        step_b1()
+    dt1, _ = timed_median(step_b1, n1, barrier, dist, dev)
+    rows_b1, _ = profiled_pass(eng, step_b1, min(n1, 10))
+    fl_b1 = sum(v[2] for k, v in rows_b1.items() if 'fixup' not in k) / min(n1, 10)
+    extra['c1_batch1'] = {'workload': f'BASELINE configs[0] shape: fine-tune iteration at batch 1, {H}x{W} (the reference runs it on CPU)',
+                          'finetune_iters_per_sec': world * n1 / dt1, 'ms_per_step': 1e3 * dt1 / n1,
+                          'whole_step_executed_tflops': fl_b1 / (dt1 / n1) / 1e12,
+                          'whole_step_executed_frac': fl_b1 / (dt1 / n1) / 1e12 / matrix_peak(mode)}
+    # C3: one online-adaptation round of e-OSVOS-100-OnA = 10 iterations on [first frame + 2 pseudo-labelled frames] (batch 3)
+    # + the inference of the next 5 frames (evaluate.py:227-253,293-314); a round restores the first-step weights first
+    xa = torch.cat([xg[:1], torch.roll(xg[:1], 12, dims=3), torch.roll(xg[:1], 16, dims=3)]).contiguous()
+    ya = torch.cat([yg[:1], torch.roll(yg[:1], 12, dims=3), torch.roll(yg[:1], 16, dims=3)]).contiguous()
+    x5 = torch.cat([torch.roll(xg[:1], 4 * i, dims=3) for i in range(5)])[:min(5, BATCH)].contiguous()
+    eng.snapshot()
+
+    def ona_round():
+        eng.restore()
+        for _ in range(10):
+            eng.finetune_step(xa, ya, sync_loss=False)
+        for i in range(0, 5, x5.shape[0]):
+            eng.infer(x5[:min(x5.shape[0], 5 - i)])
+    ona_round()
+    nr = 3
+    dtr, _ = timed_median(ona_round, nr, barrier, dist, dev, repeats=3)
+    extra['c3_online_adaptation_round'] = {
+        'workload': 'BASELINE configs[2] shape: restore first-step weights, 10 fine-tune iterations at batch 3 on [first frame + 2 '
+                    f'pseudo-labelled frames], inference of 5 frames, {H}x{W}',
+        'ms_per_round': 1e3 * dtr / nr, 'finetune_iters_per_sec': world * 10 * nr / dtr,
+        'note': 'iterations/s over the whole round (inference and the weight restore included)'}
+    eng.reset()
     if not a.no_ab and world == 1:
         # same engine, same buffers, fp32-MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split kernels
         engine_mod.set_matrix_mode('f32')
@@ -365,10 +426,22 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
             mt, mstep, _, extra_eng = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory or Engine)
             mstep()                                                             # warm-up
             n_it = 4
-            dtm = timed(mstep, n_it, barrier, dist, dev)
+            dtm, msamples = timed_median(mstep, n_it, barrier, dist, dev, repeats=3)
             extra['meta_tasks_per_sec'] = world * tpr * n_it / dtm
             extra['meta_config'] = (f'meta_batch_size={world * tpr} ({tpr} tasks per GPU in flight on one engine each), 5 inner steps + '
                                     f'1 meta frame, batch 1, {H}x{W}')
+            mt.profile = {}
+            for _ in range(2):
+                mstep()
+            extra['meta_phase_ms_per_meta_iteration'] = {k: v / mt.profile['iterations'] for k, v in mt.profile.items() if k != 'iterations'}
+            mt.profile = None
+            mrows, _ = profiled_pass(eng, mstep, 2)                             # the first engine's launches (one of `tpr` in flight)
+            extra['meta_roofline'] = roofline_from(mrows, 2, mode, lib_version, 1, 1e3 * dtm / n_it)
+            extra['meta_roofline']['note'] = ('HIP-event profile of the first of the engines that run tasks side by side; whole_step_* '
+                                              'fields relate its FLOPs to the whole meta-iteration time and are not meaningful here')
+            extra['meta_timed_region_samples_s'] = msamples
+            if rank == 0 and world == 1 and not a.no_cpu_baseline:
+                extra['meta_cpu_baseline'] = cpu_baseline_meta(sd, lrs, x[:1], y[:1], torch.flip(x[:1], dims=[3]), torch.flip(y[:1], dims=[3]))
             for e in extra_eng:
                 e.close()
         except Exception as exc:                                                # noqa: BLE001

@@ -67,14 +67,23 @@ struct Topo {
   std::vector<int> stage;  // per conv: ResNet layer 0..3 of a bottleneck conv, -1 otherwise
   int layer1_last_block;  // index of the block whose output is the low-level feature
   int aspp[4], pool, project, dec1, dec_a, dec_b, last;
+  int head3 = -1;          // plain DeepLabV3 (networks/deeplabv3.py): the 3x3 conv of DeepLabHead; dec1 / dec_a / dec_b = -1
+  bool v3 = false;
   int64_t nparam, nlr, nnorm;
 };
 
 bool build_topo(int arch, Topo& t) {
   int nb[4];
-  if (arch == EOSVOS_ARCH_RESNET50) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; }
-  else if (arch == EOSVOS_ARCH_RESNET101) { nb[0] = 3; nb[1] = 4; nb[2] = 23; nb[3] = 3; }
+  // EOSVOS_ARCH_V3_*: plain DeepLabV3 (src/networks/deeplabv3.py:10-83): torchvision ResNet with
+  // replace_stride_with_dilation = [False, True, True] and NO stride surgery -> output stride 8 (layer3 dilation 1, 2, 2..,
+  // layer4 dilation 2, 4, 4), DeepLabHead = ASPP[12, 24, 36] -> 3x3 conv + norm + ReLU -> 1x1 conv (+ bias), logits resized x8
+  const bool v3 = arch == EOSVOS_ARCH_V3_RESNET50 || arch == EOSVOS_ARCH_V3_RESNET101;
+  const int base = v3 ? arch - 1000 : arch;
+  if (base == EOSVOS_ARCH_RESNET50) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; }
+  else if (base == EOSVOS_ARCH_RESNET101) { nb[0] = 3; nb[1] = 4; nb[2] = 23; nb[3] = 3; }
   else return false;
+  t.v3 = v3;
+  t.head3 = -1;
   t.convs.clear();
   t.blocks.clear();
   auto add = [&](int cin, int cout, int k, int s, int d, int p, bool norm, bool bias) {
@@ -89,10 +98,13 @@ bool build_topo(int arch, Topo& t) {
     const int w = widths[li];
     for (int bi = 0; bi < nb[li]; ++bi) {
       const bool first = bi == 0;
-      const int s1 = (li == 2 && first) ? 2 : 1;   // reference surgery: layer3[0].conv1 stride 2
+      const int s1 = (!v3 && li == 2 && first) ? 2 : 1;   // reference surgery (DeepLabV3+ only): layer3[0].conv1 stride 2
       const int s2 = (li == 1 && first) ? 2 : 1;   // layer2[0].conv2 stride 2
       int d = 1;
-      if (li == 3) d = bi == 0 ? 2 : (bi == nb[3] - 1 ? 8 : 4);
+      if (v3) {                                    // torchvision dilation rule: the first block keeps the previous dilation
+        if (li == 2) d = bi == 0 ? 1 : 2;
+        if (li == 3) d = bi == 0 ? 2 : 4;
+      } else if (li == 3) d = bi == 0 ? 2 : (bi == nb[3] - 1 ? 8 : 4);
       Block b;
       b.c1 = add(inpl, w, 1, s1, 1, 0, true, false);
       b.c2 = add(w, w, 3, s2, d, d, true, false);
@@ -106,13 +118,18 @@ bool build_topo(int arch, Topo& t) {
     if (li == 0) t.layer1_last_block = (int)t.blocks.size() - 1;
   }
   t.aspp[0] = add(2048, 256, 1, 1, 1, 0, true, false);
-  const int rates[3] = {6, 12, 18};
+  const int rates[3] = {v3 ? 12 : 6, v3 ? 24 : 12, v3 ? 36 : 18};
   for (int i = 0; i < 3; ++i) t.aspp[i + 1] = add(2048, 256, 3, 1, rates[i], rates[i], true, false);
   t.pool = add(2048, 256, 1, 1, 1, 0, true, false);
   t.project = add(1280, 256, 1, 1, 1, 0, true, false);
-  t.dec1 = add(256, 48, 1, 1, 1, 0, true, false);
-  t.dec_a = add(304, 256, 3, 1, 1, 1, true, false);
-  t.dec_b = add(256, 256, 3, 1, 1, 1, true, false);
+  if (v3) {
+    t.dec1 = t.dec_a = t.dec_b = -1;
+    t.head3 = add(256, 256, 3, 1, 1, 1, true, false);
+  } else {
+    t.dec1 = add(256, 48, 1, 1, 1, 0, true, false);
+    t.dec_a = add(304, 256, 3, 1, 1, 1, true, false);
+    t.dec_b = add(256, 256, 3, 1, 1, 1, true, false);
+  }
   t.last = add(256, 1, 1, 1, 1, 0, false, true);
   t.stage.resize(t.convs.size(), -1);
   int64_t po = 0, lo = 0, no = 0;
@@ -858,7 +875,10 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   e->h2 = conv_out(H, 7, 2, 1, 3); e->w2 = conv_out(W, 7, 2, 1, 3);
   e->h4 = conv_out(e->h2, 3, 2, 1, 1); e->w4 = conv_out(e->w2, 3, 2, 1, 1);
   e->h8 = conv_out(e->h4, 3, 2, 1, 1); e->w8 = conv_out(e->w4, 3, 2, 1, 1);
-  e->h16 = conv_out(e->h8, 1, 2, 1, 0); e->w16 = conv_out(e->w8, 1, 2, 1, 0);
+  // (h16, w16) = the map ASPP runs on: stride 16 for DeepLabV3+, the stride-8 map for plain DeepLabV3
+  if (t.v3) { e->h16 = e->h8; e->w16 = e->w8; }
+  else { e->h16 = conv_out(e->h8, 1, 2, 1, 0); e->w16 = conv_out(e->w8, 1, 2, 1, 0); }
+  if (t.v3 && e->gn()) { delete e; return fail("plain DeepLabV3 has no GroupNorm variant (networks/deeplabv3.py)"); }
 
 #define ALLOC(ptr, n)                                                  \
   do {                                                                 \
@@ -968,8 +988,13 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   ALLOC(e->logits, (int64_t)B * H * W); ALLOC(e->dlogits, (int64_t)B * H * W);
   ALLOC(e->loss_dev, 4); ALLOC(e->bce_partial, 4 * 1024 + 16);
   for (int i = 0; i < 4; ++i) track(t.aspp[i], e->h16, e->w16);
-  track(t.project, e->h16, e->w16); track(t.dec1, e->h4, e->w4);
-  track(t.dec_a, e->h4, e->w4); track(t.dec_b, e->h4, e->w4);
+  track(t.project, e->h16, e->w16);
+  if (t.v3) {
+    track(t.head3, e->h16, e->w16);
+  } else {
+    track(t.dec1, e->h4, e->w4);
+    track(t.dec_a, e->h4, e->w4); track(t.dec_b, e->h4, e->w4);
+  }
   for (int b = 1; b <= B; ++b) {
     slabs[0] = max64(slabs[0], (int64_t)stem_wgrad_chunks(b, e->h2, e->w2) * 64 * 147);
     slabs[t.last] = max64(slabs[t.last], (int64_t)last_bwd_chunks((int64_t)b * e->h4 * e->w4) * 257);
@@ -998,10 +1023,14 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   if (e->wino_m_n > 0) { ALLOC(e->wino_m, e->wino_m_n); ALLOC(e->wino_dv, e->wino_m_n); }
   e->ws_conv_n = wsc; e->ws_wg_n = wsw;
 #undef ALLOC
-  if (upload_resize(e, make_resize(e->h16, e->h4, true), e->h16, e->h4, e->up_h)) { eosvos_destroy(e); return 1; }
-  if (upload_resize(e, make_resize(e->w16, e->w4, true), e->w16, e->w4, e->up_w)) { eosvos_destroy(e); return 1; }
-  if (upload_resize(e, make_resize(e->h4, H, false), e->h4, H, e->fin_h)) { eosvos_destroy(e); return 1; }
-  if (upload_resize(e, make_resize(e->w4, W, false), e->w4, W, e->fin_w)) { eosvos_destroy(e); return 1; }
+  if (!t.v3) {       // decoder upsample of the ASPP output onto the stride-4 map
+    if (upload_resize(e, make_resize(e->h16, e->h4, true), e->h16, e->h4, e->up_h)) { eosvos_destroy(e); return 1; }
+    if (upload_resize(e, make_resize(e->w16, e->w4, true), e->w16, e->w4, e->up_w)) { eosvos_destroy(e); return 1; }
+  }
+  // final resize of the 1-channel logits: from the stride-4 decoder map (DeepLabV3+) or straight from the ASPP map (V3)
+  const int hl = t.v3 ? e->h16 : e->h4, wl = t.v3 ? e->w16 : e->w4;
+  if (upload_resize(e, make_resize(hl, H, false), hl, H, e->fin_h)) { eosvos_destroy(e); return 1; }
+  if (upload_resize(e, make_resize(wl, W, false), wl, W, e->fin_w)) { eosvos_destroy(e); return 1; }
   {
     const char* v = getenv("EOSVOS_NO_SIDE_STREAM");
     if (!(v && v[0] == '1')) {
@@ -1267,7 +1296,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
     conv_fwd(e, b.c2, f.t1, cmid, f.Hm, f.Wm, f.t2, cmid, B, nullptr, 0, true);
     if (b.ds >= 0 && fside) (void)hipStreamWaitEvent(s, e->ev[b.c3], 0);
     conv_fwd(e, b.c3, f.t2, cmid, f.Ho, f.Wo, f.out, cout, B, res, ldres, true);
-    if ((int)i == t.layer1_last_block && fside) {
+    if ((int)i == t.layer1_last_block && fside && !t.v3) {
       // decoder.conv1 reads the layer1 feature only: it runs beside layer2..4 + ASPP
       fork(t.dec1);
       conv_fwd(e, t.dec1, f.out, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true, true);
@@ -1288,14 +1317,20 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   }
   launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s);
   conv_fwd(e, t.project, e->cat, 1280, e->h16, e->w16, e->proj, 256, B, nullptr, 0, true);
-  const float* low = e->bb[t.layer1_last_block].out;
-  if (fside) (void)hipStreamWaitEvent(s, e->ev[t.dec_a], 0);
-  else conv_fwd(e, t.dec1, low, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true);
-  launch_resize_fwd(e->proj, 256, e->dcat, 304, B, 256, e->up_h, e->up_w, s);
-  conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, B, nullptr, 0, true);
-  conv_fwd(e, t.dec_b, e->d1, 256, e->h4, e->w4, e->d2, 256, B, nullptr, 0, true);
   const ConvL& lc = t.convs[t.last];
-  launch_last_fwd(e->d2, e->W_(t.last), e->W_(t.last) + lc.wsize(), e->lowlog, (int64_t)B * e->h4 * e->w4, 256, s);
+  if (t.v3) {
+    // DeepLabHead after ASPP: 3x3 conv + norm + ReLU, 1x1 classifier, logits resized from the ASPP map (deeplabv3.py:13)
+    conv_fwd(e, t.head3, e->proj, 256, e->h16, e->w16, e->d1, 256, B, nullptr, 0, true);
+    launch_last_fwd(e->d1, e->W_(t.last), e->W_(t.last) + lc.wsize(), e->lowlog, (int64_t)B * e->h16 * e->w16, 256, s);
+  } else {
+    const float* low = e->bb[t.layer1_last_block].out;
+    if (fside) (void)hipStreamWaitEvent(s, e->ev[t.dec_a], 0);
+    else conv_fwd(e, t.dec1, low, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true);
+    launch_resize_fwd(e->proj, 256, e->dcat, 304, B, 256, e->up_h, e->up_w, s);
+    conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, B, nullptr, 0, true);
+    conv_fwd(e, t.dec_b, e->d1, 256, e->h4, e->w4, e->d2, 256, B, nullptr, 0, true);
+    launch_last_fwd(e->d2, e->W_(t.last), e->W_(t.last) + lc.wsize(), e->lowlog, (int64_t)B * e->h4 * e->w4, 256, s);
+  }
   launch_resize_fwd(e->lowlog, 1, e->logits, 1, B, 1, e->fin_h, e->fin_w, s);
   e->lastB = B;
   e->have_loss_grad = false;
@@ -1317,6 +1352,16 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   const int P16 = e->h16 * e->w16;
   // final resize
   launch_resize_bwd(e->dlogits, 1, e->g_low, 1, nullptr, 0, B, 1, e->fin_h, e->fin_w, s);
+  if (t.v3) {
+    // classifier conv (Cout = 1) and the head's 3x3 conv, both on the ASPP map; the projection output is ReLU-masked
+    const int64_t PA = (int64_t)B * e->h16 * e->w16;
+    const int chunks = last_bwd_chunks(PA);
+    launch_last_bwd(e->d1, e->W_(t.last), e->g_low, e->g_d1, e->ws_wg + e->ws_off[t.last], PA, 256, chunks, s);
+    apply_update(e, t.last, chunks, update, accumulate);
+    int sp = conv_wgrad(e, t.head3, e->g_d1, 256, e->proj, 256, e->h16, e->w16, B);
+    conv_dgrad(e, t.head3, e->g_d1, 256, e->h16, e->w16, e->g_proj, 256, B, false, e->proj, 256, 0);
+    apply_update(e, t.head3, sp, update, accumulate);
+  } else {
   // classifier conv (Cout = 1)
   {
     const int chunks = last_bwd_chunks(P4);
@@ -1334,15 +1379,16 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     apply_update(e, t.dec_a, sp, update, accumulate);
   }
   // decoder.conv1 on the low-level feature: raw gradient into g_out of layer1's last block
-  float* g_low_feat = e->bb[t.layer1_last_block].g_out;
-  const float* low = e->bb[t.layer1_last_block].out;
   {
+    float* g_low_feat = e->bb[t.layer1_last_block].g_out;
+    const float* low = e->bb[t.layer1_last_block].out;
     int sp = conv_wgrad(e, t.dec1, e->g_dcat + 256, 304, low, 256, e->h4, e->w4, B);
     conv_dgrad(e, t.dec1, e->g_dcat + 256, 304, e->h4, e->w4, g_low_feat, 256, B, false, nullptr, 0, 0);
     apply_update(e, t.dec1, sp, update, accumulate);
   }
   // decoder upsample backward (+ ReLU mask of the projection output)
   launch_resize_bwd(e->g_dcat, 304, e->g_proj, 256, e->proj, 256, B, 256, e->up_h, e->up_w, s);
+  }
   // ASPP projection
   {
     int sp = conv_wgrad(e, t.project, e->g_proj, 256, e->cat, 1280, e->h16, e->w16, B);
@@ -1395,7 +1441,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     // gradient w.r.t. the block input: conv1 path + identity / downsample path
     const bool is_first_block = i == 0;
     // the low-level feature already holds decoder.conv1's contribution
-    bool have = (i == t.layer1_last_block + 1);
+    bool have = !t.v3 && (i == t.layer1_last_block + 1);
     const float* inmask = is_first_block ? nullptr : f.xin;   // p1 is a max-pool output: masked in maxpool_bwd
     if (b.ds >= 0) {
       sp = conv_wgrad(e, b.ds, f.g_out, cout, f.xin, f.Cin, f.Hi, f.Wi, B);
@@ -1712,6 +1758,7 @@ int eosvos_profile_read(eosvos_engine* e, int max_kernels, char* names, int64_t*
 int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host, double* flops_host) {
   if (!e || !ms_host || !flops_host || batch < 1 || batch > e->maxB || reps < 1) return fail("bad argument");
   const Topo& t = e->t;
+  if (t.dec_a < 0) return fail("eosvos_time_hot_kernel times the DeepLabV3+ decoder conv; this topology has none");
   hipEvent_t a, b;
   HIPOK(hipEventCreate(&a));
   HIPOK(hipEventCreate(&b));

@@ -16,7 +16,7 @@ import random
 import numpy as np
 import torch
 
-from .networks import DeepLabV3Plus
+from .networks import DeepLabV3, DeepLabV3Plus
 
 
 def compute_loss(loss_func, outputs, gts, loss_kwargs=None):
@@ -44,10 +44,13 @@ def init_parent_model(architecture, encoder, train_encoder, decoder_norm_layer=N
                       replace_batch_with_group_norms=False, batch_norm=None, roi_pool_output_sizes=None,
                       eval_augment_rpn_proposals_mode=None, box_nms_thresh=None, maskrcnn_loss=None, **datasets):
     """Same signature as the reference; returns (model, parent_states)."""
-    if architecture != 'DeepLabV3Plus':
-        raise NotImplementedError(f"architecture='{architecture}': the MI355X engine implements DeepLabV3Plus")
-    model = DeepLabV3Plus(encoder, num_classes=1, batch_norm=batch_norm, train_encoder=train_encoder,
-                          replace_batch_with_group_norms=replace_batch_with_group_norms)
+    if architecture == 'DeepLabV3':                         # helper_func.py:343-344
+        model = DeepLabV3(encoder, num_classes=1, batch_norm=batch_norm, train_encoder=train_encoder)
+    elif architecture == 'DeepLabV3Plus':
+        model = DeepLabV3Plus(encoder, num_classes=1, batch_norm=batch_norm, train_encoder=train_encoder,
+                              replace_batch_with_group_norms=replace_batch_with_group_norms)
+    else:
+        raise NotImplementedError(f"architecture='{architecture}': the MI355X engine implements DeepLabV3Plus and DeepLabV3")
     parent_states = {}
     for k, v in datasets.items():
         parent_states[k] = {

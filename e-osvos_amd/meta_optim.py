@@ -102,6 +102,13 @@ class MetaOptimizer:
     # ---- nn.Module-like surface ---------------------------------------------------------------
     def train(self, mode=True):
         self.training = mode
+        eng = getattr(self.model, 'engine', None)
+        if not mode and eng is not None and getattr(eng, 'in_meta_task', False) and getattr(eng, 'steps_since_reset', 1) == 0:
+            # `reset()` then `eval()` (evaluate.py:196-198): the task that reset() opened in training mode will never
+            # accumulate -- it is an evaluation fine-tune, and the engine may be rebuilt for another frame size during it
+            eng.in_meta_task = False
+        if not mode and getattr(self.model, '_pending_task_begin', False):
+            self.model._pending_task_eval = True         # same, the engine not built yet (networks._ensure_engine)
         return self
 
     def eval(self):
@@ -187,6 +194,7 @@ class MetaOptimizer:
                 m.engine.reset()
         else:
             m._pending_task_begin = self.training   # engine is created at the first forward
+            m._pending_task_eval = False
         self.state['num_steps'] = 0
 
     def set_train_loss(self, train_loss):

@@ -221,15 +221,36 @@ class MetaTrainer:
         default_schedule = not multi_step_bptt_loss and (bptt_epochs or inner_steps) == inner_steps and inner_steps > 0
         same_size = all(t[0].shape[-2:] == (e.height, e.width) and t[0].shape[0] <= e.max_batch and t[2].shape[0] <= e.max_batch
                         for t in local_tasks for e in self.engines)
+        prof = getattr(self, 'profile', None)       # bench.py: {'tasks_ms', 'allreduce_ms', 'outer_step_ms'} summed over calls
+        tick = self._tick if prof is not None else (lambda: 0.0)
+        t0 = tick()
+        self._apply_wg_budget()                     # an evaluation in between may have changed the first engine's budget
         if len(self.engines) > 1 and len(local_tasks) > 1 and default_schedule and same_size:
             losses = self.run_tasks_concurrent(local_tasks, inner_steps)
         else:
             losses = [self.run_task(*t, inner_steps=inner_steps, bptt_epochs=bptt_epochs,
                                     multi_step_bptt_loss=multi_step_bptt_loss) for t in local_tasks]
+        t1 = tick()
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
             self.dist.all_reduce(self.grad)             # sum over ranks, one 161 MB message
+        t2 = tick()
         self.outer_step()
+        if prof is not None:
+            t3 = tick()
+            prof['tasks_ms'] = prof.get('tasks_ms', 0.0) + 1e3 * (t1 - t0)
+            prof['allreduce_ms'] = prof.get('allreduce_ms', 0.0) + 1e3 * (t2 - t1)
+            prof['outer_step_ms'] = prof.get('outer_step_ms', 0.0) + 1e3 * (t3 - t2)
+            prof['iterations'] = prof.get('iterations', 0) + 1
         return losses
+
+    def _tick(self):
+        """Wall clock after everything queued so far has finished (profiling passes only: it drains the GPU)."""
+        import time
+        for e in self.engines:
+            e.synchronize()
+        if self.state.is_cuda:
+            torch.cuda.synchronize(self.state.device)
+        return time.perf_counter()
 
     def outer_step(self):
         eng = self.eng

@@ -43,8 +43,10 @@ class _Param:
 class DeepLabV3Plus:
     def __init__(self, backbone, num_classes, batch_norm=None, train_encoder=True,
                  replace_batch_with_group_norms=False, max_batch=3, device='cuda:0'):
-        if backbone not in ('resnet50', 'resnet101'):
+        if backbone not in ('resnet50', 'resnet101', 'deeplabv3_resnet50', 'deeplabv3_resnet101'):
             raise NotImplementedError(backbone)
+        if backbone.startswith('deeplabv3_') and replace_batch_with_group_norms:
+            raise NotImplementedError('plain DeepLabV3 has no GroupNorm variant (networks/deeplabv3.py)')
         if num_classes != 1:
             raise NotImplementedError('num_classes != 1')
         if not train_encoder:
@@ -191,7 +193,9 @@ class DeepLabV3Plus:
             self.push_state()
         if getattr(self, '_pending_task_begin', False):
             self.engine.meta_task_begin()
-            self._pending_task_begin = False
+            if getattr(self, '_pending_task_eval', False):      # reset() was followed by eval(): an evaluation fine-tune
+                self.engine.in_meta_task = False
+            self._pending_task_begin = self._pending_task_eval = False
         return self.engine
 
     def push_state(self):
@@ -223,6 +227,20 @@ class DeepLabV3Plus:
         return [logits]
 
     forward = __call__
+
+
+class DeepLabV3(DeepLabV3Plus):
+    """Drop-in for `src/networks/deeplabv3.py::DeepLabV3` (`init_parent_model(architecture='DeepLabV3')`,
+    `helper_func.py:343-344`): same constructor (`backbone, num_classes, batch_norm=None, train_encoder=True`), output
+    stride 8, DeepLabHead (ASPP[12, 24, 36] -> 3x3 conv + BN + ReLU -> 1x1 conv), logits resized x8.  The reference class
+    lacks `train_without_dropout()` (its loops call it, so it cannot run there at this commit); here
+    it exists with the DeepLabV3+ meaning: frozen BatchNorm (`deeplabv3.py:56-62`) and Dropout off."""
+
+    def __init__(self, backbone, num_classes, batch_norm=None, train_encoder=True, max_batch=3, device='cuda:0'):
+        super().__init__('deeplabv3_' + backbone if not backbone.startswith('deeplabv3_') else backbone, num_classes,
+                         batch_norm=batch_norm, train_encoder=train_encoder, replace_batch_with_group_norms=False,
+                         max_batch=max_batch, device=device)
+        self._ctor = dict(backbone=backbone, num_classes=num_classes, batch_norm=batch_norm, train_encoder=train_encoder)
 
 
 def conv_names(encoder='resnet50'):

@@ -19,7 +19,7 @@ def synthetic_state(encoder='resnet50', seed=99, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for c in conv_infos(encoder):
-        fan = (c.cin if c.name.startswith('decoder') else c.cout) * c.k * c.k
+        fan = (c.cin if c.name.startswith('decoder') or c.name in ('classifier.1', 'classifier.4') else c.cout) * c.k * c.k
         w = torch.randn(c.cout, c.cin, c.k, c.k, generator=g, dtype=dtype) * math.sqrt(2.0 / fan)
         sd[c.name + '.weight'] = w
         if c.bias:

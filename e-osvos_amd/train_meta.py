@@ -82,7 +82,7 @@ def load_parent_state(model, parent_states, key, encoder, log=None):
         model.load_state_dict(states[0])
         src = 'file'
     else:
-        model.load_state_dict(synthetic.synthetic_state(encoder))
+        model.load_state_dict(synthetic.synthetic_state(getattr(model, 'encoder', encoder)))    # ('deeplabv3_' + encoder for DeepLabV3)
         src = 'synthetic'
     if log is not None:
         log(json.dumps({'parent_state': src, 'dataset_key': key}))

@@ -36,6 +36,12 @@ typedef struct eosvos_engine eosvos_engine;
 
 #define EOSVOS_ARCH_RESNET50 50
 #define EOSVOS_ARCH_RESNET101 101
+/* plain DeepLabV3 (src/networks/deeplabv3.py:10-83; init_parent_model(architecture='DeepLabV3'), helper_func.py:343-344):
+ * torchvision ResNet with replace_stride_with_dilation = [False, True, True] (output stride 8), DeepLabHead =
+ * ASPP[12, 24, 36] -> 3x3 conv + BatchNorm + ReLU -> 1x1 conv, logits resized x8 (align_corners = False); no decoder.
+ * State-dict keys: backbone.*, classifier.0.* (ASPP), classifier.1 / classifier.2 (3x3 conv + norm), classifier.4. */
+#define EOSVOS_ARCH_V3_RESNET50 1050
+#define EOSVOS_ARCH_V3_RESNET101 1101
 #define EOSVOS_NORM_BN_FROZEN 0 /* BatchNorm in eval mode, frozen affine (deeplabv3plus.py:148-155,259-265) */
 #define EOSVOS_NORM_GN16 1      /* GroupNorm(16, C) sharing the frozen BN affine (deeplabv3plus.py:180-191) */
 

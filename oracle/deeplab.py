@@ -20,7 +20,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 import torch
 import torch.nn.functional as F
 
-from .topology import bottleneck_cfg, conv_list
+from .topology import bottleneck_cfg, conv_list, is_v3
 
 EPS = 1e-5
 
@@ -79,6 +79,12 @@ def forward(P, x, encoder='resnet50', norm='bn', taps=None):
     x = cnr(torch.cat(branches, dim=1), a + '.project.0')
     if taps is not None:
         taps['aspp'] = x
+    if is_v3(encoder):          # DeepLabHead tail + _SimpleSegmentationModel.forward (networks/deeplabv3.py:13,64-83)
+        x = cnr(x, 'classifier.1')
+        x = _conv(P, x, convs['classifier.4'])
+        if taps is not None:
+            taps['low_logits'] = x
+        return F.interpolate(x, size=inp_hw, mode='bilinear', align_corners=False)
     # decoder
     low = cnr(low, 'decoder.conv1')
     x = F.interpolate(x, size=low.shape[-2:], mode='bilinear', align_corners=True)

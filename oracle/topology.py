@@ -24,9 +24,19 @@ Conv = namedtuple('Conv', 'name cin cout k stride dil pad norm bias')
 _BLOCKS = {'resnet50': (3, 4, 6, 3), 'resnet101': (3, 4, 23, 3)}
 
 
+def is_v3(encoder):
+    """'deeplabv3_<resnet>': plain DeepLabV3, `src/networks/deeplabv3.py:10-83` -- torchvision
+    ``resnet(replace_stride_with_dilation=[False, True, True])`` untouched (output stride 8: layer3 dilations 1, 2, 2, ...,
+    layer4 2, 4, 4 by the rule "the first block of a dilated layer keeps the previous dilation"), DeepLabHead =
+    ASPP[12, 24, 36] -> Conv3x3(256) + BN + ReLU -> Conv1x1(num_classes); `_SimpleSegmentationModel.forward` resizes the
+    logits to the input size (bilinear, align_corners=False)."""
+    return encoder.startswith('deeplabv3_')
+
+
 def bottleneck_cfg(encoder):
     """Per block: (prefix, inplanes, width, stride_conv1, stride_conv2, dil, has_ds, ds_stride)."""
-    blocks = _BLOCKS[encoder]
+    v3 = is_v3(encoder)
+    blocks = _BLOCKS[encoder.split('_')[-1]]
     out = []
     inplanes = 64
     # (width, stride on conv1, stride on conv2, dilations per block)
@@ -39,6 +49,9 @@ def bottleneck_cfg(encoder):
         # override of the last block: 2, 4, ..., 4, 8
         (512, 1, 1, [2] + [4] * (blocks[3] - 2) + [8]),
     ]
+    if v3:          # no surgery: strides replaced by dilation in layer3 / layer4
+        layer_cfg[2] = (256, 1, 1, [1] + [2] * (blocks[2] - 1))
+        layer_cfg[3] = (512, 1, 1, [2] + [4] * (blocks[3] - 1))
     for li, (width, s1, s2, dils) in enumerate(layer_cfg, start=1):
         for bi, d in enumerate(dils):
             first = bi == 0
@@ -64,10 +77,14 @@ def conv_list(encoder='resnet50'):
                           p + '.downsample.1', False))
     a = 'classifier.0'
     L.append(Conv(a + '.convs.0.0', 2048, 256, 1, 1, 1, 0, a + '.convs.0.1', False))
-    for i, r in enumerate((6, 12, 18), start=1):
+    for i, r in enumerate((12, 24, 36) if is_v3(encoder) else (6, 12, 18), start=1):
         L.append(Conv(f'{a}.convs.{i}.0', 2048, 256, 3, 1, r, r, f'{a}.convs.{i}.1', False))
     L.append(Conv(a + '.convs.4.1', 2048, 256, 1, 1, 1, 0, a + '.convs.4.2', False))
     L.append(Conv(a + '.project.0', 1280, 256, 1, 1, 1, 0, a + '.project.1', False))
+    if is_v3(encoder):
+        L.append(Conv('classifier.1', 256, 256, 3, 1, 1, 1, 'classifier.2', False))
+        L.append(Conv('classifier.4', 256, 1, 1, 1, 1, 0, None, True))
+        return L
     L.append(Conv('decoder.conv1', 256, 48, 1, 1, 1, 0, 'decoder.bn1', False))
     L.append(Conv('decoder.last_conv.0', 304, 256, 3, 1, 1, 1, 'decoder.last_conv.1', False))
     L.append(Conv('decoder.last_conv.4', 256, 256, 3, 1, 1, 1, 'decoder.last_conv.5', False))

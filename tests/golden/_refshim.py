@@ -132,6 +132,31 @@ class ASPP(nn.Module):
         return self.project(torch.cat([c(x) for c in self.convs], dim=1))
 
 
+class DeepLabHead(nn.Sequential):
+    """torchvision 0.4 `segmentation/deeplabv3.py`: ASPP[12, 24, 36] -> Conv3x3 -> BN -> ReLU -> Conv1x1."""
+
+    def __init__(self, in_channels, num_classes):
+        super().__init__(ASPP(in_channels, [12, 24, 36]), nn.Conv2d(256, 256, 3, padding=1, bias=False), nn.BatchNorm2d(256),
+                         nn.ReLU(), nn.Conv2d(256, num_classes, 1))
+
+
+class SimpleSegmentationModel(nn.Module):
+    """torchvision 0.4 `segmentation/_utils.py::_SimpleSegmentationModel` (base of DeepLabV3): backbone features 'out' ->
+    classifier -> bilinear resize to the input size, align_corners=False; result dict {'out': logits}."""
+
+    def __init__(self, backbone, classifier, aux_classifier=None):
+        super().__init__()
+        self.backbone, self.classifier, self.aux_classifier = backbone, classifier, aux_classifier
+
+    def forward(self, x):
+        input_shape = x.shape[-2:]
+        features = self.backbone(x)
+        result = OrderedDict()
+        x = self.classifier(features['out'])
+        result['out'] = F.interpolate(x, size=input_shape, mode='bilinear', align_corners=False)
+        return result
+
+
 class _Any:
     """Permissive dummy: any attribute / call / subscript yields another dummy."""
 
@@ -171,8 +196,7 @@ def install(ref_src='/root/reference/src'):
     res = _mod('torchvision.models.resnet', resnet50=resnet50, resnet101=resnet101,
                ResNet=ResNet, Bottleneck=Bottleneck)
     dl = _mod('torchvision.models.segmentation.deeplabv3', ASPP=ASPP,
-              DeepLabV3=type('DeepLabV3', (nn.Module,), {}),
-              DeepLabHead=type('DeepLabHead', (nn.Sequential,), {}))
+              DeepLabV3=type('DeepLabV3', (SimpleSegmentationModel,), {}), DeepLabHead=DeepLabHead)
     seg = _mod('torchvision.models.segmentation', deeplabv3=dl)
     ut = _mod('torchvision.models.utils', load_state_dict_from_url=lambda *a, **k: {})
     _ut = _mod('torchvision.models._utils', IntermediateLayerGetter=IntermediateLayerGetter)
