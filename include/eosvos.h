@@ -52,8 +52,12 @@ const char* eosvos_last_error(void);
 /* How the fp32 contractions of the convolutions run on the matrix cores (process-wide; results agree to fp32
  * rounding):
  *   BF16X6 (default): every fp32 operand is split exactly into three bf16 pieces and the product is accumulated
- *          in fp32 from the six leading partial products on v_mfma_f32_32x32x16_bf16 (error <= fp32 MFMA's);
- *   F32:   v_mfma_f32_32x32x2_f32 (1/16 of the bf16 rate on CDNA4).  Also selected by EOSVOS_MFMA=f32. */
+ *          in fp32 from the six leading partial products on v_mfma_f32_16x16x32_bf16 (error <= fp32 MFMA's);
+ *   F32:   v_mfma_f32_32x32x2_f32 (1/16 of the bf16 rate on CDNA4).  Also selected by EOSVOS_MFMA=f32.
+ * Special values (tests/test_gpu_conv_algos.py::test_bf16x6_special_values_propagate): a NaN operand gives NaN in both
+ * modes; a +-inf operand gives +-inf in F32 and NaN in BF16X6 (the remainder inf - top16(inf) is NaN) -- non-finite
+ * either way, which is what the meta loop's NaN-skip (meta_run.py:209-211) needs: an overflowed task shows up as a NaN
+ * loss; denormal operands contribute nothing in either mode; finite values up to FLT_MAX split exactly. */
 #define EOSVOS_MATRIX_F32 0
 #define EOSVOS_MATRIX_BF16X6 1
 int eosvos_set_matrix_mode(int mode);

@@ -155,3 +155,49 @@ def test_bf16x6_is_at_least_as_accurate_as_the_fp32_mfma(eng):
     for i in range(4):
         assert res['bf16x6'][i] <= 1.25 * res['f32'][i] + 1e-9, res
     assert res['bf16x6'][0] < 3e-7 and res['bf16x6'][1] < 1e-6
+
+
+def test_bf16x6_special_values_propagate(eng):
+    """Non-finite and denormal operands in the split mode vs the fp32-MFMA mode (the NaN-skip rule of the meta loop,
+    `src/util/meta_run.py:209-211`, relies on a diverged task staying visibly non-finite):
+      NaN      -> NaN in both modes (every output the element reaches);
+      +-inf    -> non-finite in both; the split mode yields NaN where the fp32 MFMA yields +-inf (inf - top16(inf) is NaN:
+                  documented in include/eosvos.h), untouched outputs stay exact;
+      denormal -> treated as (at most) zero by both: outputs agree to fp32 rounding of the normal terms;
+      values near FLT_MAX split exactly (no spurious overflow of the pieces)."""
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Ci, Co = 1, 8, 16, 64, 64
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    x[0, 3, 1, 2] = float('nan')                 # pixel (1,2): every output channel becomes NaN
+    x[0, 5, 2, 3] = float('inf')                 # pixel (2,3): +-inf by the sign of w[:, 5]
+    x[0, 7, 3, 4] = float('-inf')
+    x[0, 9, 4, 5] = 1e-41                        # denormal activation
+    w[11, 13, 0, 0] = 1e-40                      # denormal weight
+    x[0, 15, 5, 6] = 3.0e38                      # near FLT_MAX, times a small weight: stays finite
+    w[:, 15] = w[:, 15] * 1e-3
+    res = {}
+    try:
+        for mode in ('f32', 'bf16x6'):
+            engine_mod.set_matrix_mode(mode)
+            res[mode] = eng.test_conv_algo('direct', nhwc(x), w.to(DEV), None, None, None, False, 1, 1, 0).permute(0, 3, 1, 2).cpu()
+    finally:
+        engine_mod.set_matrix_mode('bf16x6')
+    a, b = res['f32'], res['bf16x6']
+    assert bool(torch.isnan(a[0, :, 1, 2]).all()) and bool(torch.isnan(b[0, :, 1, 2]).all())
+    for (py, px) in ((2, 3), (3, 4)):
+        assert bool(torch.isinf(a[0, :, py, px]).all())                           # fp32 MFMA: +-inf
+        assert not bool(torch.isfinite(b[0, :, py, px]).any())                    # split mode: non-finite (NaN)
+    clean = torch.ones(H, W, dtype=torch.bool)
+    for (py, px) in ((1, 2), (2, 3), (3, 4)):
+        clean[py, px] = False
+    assert bool(torch.isfinite(a[0][:, clean]).all()) and bool(torch.isfinite(b[0][:, clean]).all())
+    xz = x.clone()
+    xz[0, 9, 4, 5] = 0.0
+    wz = w.clone()
+    wz[11, 13, 0, 0] = 0.0
+    ref = F.conv2d(torch.nan_to_num(xz, nan=0.0, posinf=0.0, neginf=0.0).double(), wz.double())
+    scale = float(ref[0][:, clean].abs().max())
+    assert float((b[0][:, clean].double() - ref[0][:, clean]).abs().max()) <= 2e-6 * scale       # denormals contribute nothing
+    assert float((a[0][:, clean].double() - ref[0][:, clean]).abs().max()) <= 2e-6 * scale
+    assert abs(float(b[0, 0, 5, 6]) - float(ref[0, 0, 5, 6])) <= 2e-6 * abs(float(ref[0, 0, 5, 6]))   # 3e38 * 1e-3 * w: exact split
