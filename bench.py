@@ -396,14 +396,18 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         eng.reset()
         extra['fp32_mfma_mode_ms_per_step'] = 1e3 * dt32 / min(a.steps, 30)
     if not a.no_ab and world == 1 and torch.cuda.is_available():
-        # the objects of a multi-object sequence are independent fine-tunes (evaluate.py:132): three of them in flight on
-        # one engine each fill the tails / small grids one iteration leaves idle.  Not the headline (one object per rank).
+        # the objects of a multi-object sequence are independent fine-tunes (evaluate.py:132): three of them in flight, one
+        # engine and ONE queue each (no side stream, each launch planned for half the chip: evaluate.run_objects_in_flight),
+        # fill the tails / small grids one iteration leaves idle.  Not the headline (one object per rank).
         others = []
         for _ in range(2):
             with torch.cuda.stream(torch.cuda.Stream()):
                 e2 = Engine('resnet50', H, W, max_batch=BATCH, device=dev)
                 e2.load_model_state(sd, lrs)
             others.append(e2)
+        for e3 in [eng] + others:
+            e3.set_side_stream(False)
+            e3.set_wg_budget(256)
 
         def step3():
             step()
@@ -417,6 +421,8 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         extra['finetune_iters_per_sec_3_objects_in_flight'] = 3 * n3 / dt3
         for e2 in others:
             e2.close()
+        eng.set_side_stream(True)
+        eng.set_wg_budget(0)
     if not a.no_meta:
         # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4]), tasks in flight together.
         # An extra of this line: a failure here (every rank raises alike: the only rank-dependent step is the all-reduce)

@@ -183,6 +183,7 @@ struct eosvos_engine {
   int arch, H, W, maxB, dev;
   hipStream_t s;
   hipStream_t s2 = nullptr;            // side stream: weight-gradient kernels run beside the dgrad chain
+  hipStream_t s2_parked = nullptr;     // eosvos_set_side_stream(e, 0) parks it here
   std::vector<hipEvent_t> ev;          // one fork event per conv + a join event
   bool side_used = false;
   std::vector<std::function<void()>> side_q;   // weight-gradient launches waiting for the next fork (see side_flush)
@@ -828,6 +829,24 @@ int eosvos_set_wg_budget(eosvos_engine* e, int workgroups) {
   return e->wg_budget;
 }
 
+int eosvos_set_side_stream(eosvos_engine* e, int on) {
+  if (!e) { fail("null engine"); return -1; }
+  if (hipSetDevice(e->dev) != hipSuccess) { fail("hipSetDevice"); return -1; }
+  if (!on && e->s2) {
+    (void)hipStreamSynchronize(e->s);
+    (void)hipStreamSynchronize(e->s2);
+    e->s2_parked = e->s2;          // kept for a later on = 1 (the events and the side workspace stay as they are)
+    e->s2 = nullptr;
+    e->side_used = false;
+    e->side_q.clear();
+  } else if (on && !e->s2 && e->s2_parked) {
+    (void)hipStreamSynchronize(e->s);
+    e->s2 = e->s2_parked;
+    e->s2_parked = nullptr;
+  }
+  return e->s2 ? 1 : 0;
+}
+
 int eosvos_num_convs(int arch) {
   Topo t;
   if (!build_topo(arch, t)) return -1;
@@ -1066,6 +1085,7 @@ int eosvos_destroy(eosvos_engine* e) {
   if (!e) return 0;
   (void)hipStreamSynchronize(e->s);
   if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
+  if (e->s2_parked) (void)hipStreamDestroy(e->s2_parked);
   for (auto& evt : e->ev) (void)hipEventDestroy(evt);
   if (e->ev_wino_w) (void)hipEventDestroy(e->ev_wino_w);
   for (void* p : e->allocs) (void)hipFree(p);

@@ -1234,9 +1234,13 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
             for (int j = 0; j < 4; ++j) {
               const int ux = flip ? W - 1 - (sx + j) : sx + j;
               float t = R[ux] * (cy[i] * cx[j]);
+#ifndef EOSVOS_WARP_PACKED_AB          // A/B build: let the compiler pair the taps into packed-fp32 instructions again
               asm volatile("" : "+v"(t));
+#endif
               r = j == 0 ? t : r + t;
+#ifndef EOSVOS_WARP_PACKED_AB
               asm volatile("" : "+v"(r));
+#endif
             }
             sum = i == 0 ? r : sum + r;
           }

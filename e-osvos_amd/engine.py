@@ -282,6 +282,13 @@ class Engine:
             _ffi.check(1)
         return r
 
+    def set_side_stream(self, on):
+        """`eosvos_set_side_stream`: False for engines that run side by side (one queue each); returns the state in effect."""
+        r = self.lib.eosvos_set_side_stream(self.h, int(bool(on)))
+        if r < 0:
+            _ffi.check(1)
+        return bool(r)
+
     def time_hot_kernel(self, batch, reps=20):
         ms, fl = ctypes.c_float(), ctypes.c_double()
         _ffi.check(self.lib.eosvos_time_hot_kernel(self.h, batch, reps, ctypes.byref(ms), ctypes.byref(fl)))

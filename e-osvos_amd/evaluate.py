@@ -198,10 +198,13 @@ def run_objects_in_flight(workers, meta_optim_state_dict, frames, gts, cfg, augm
         torch.cuda.current_stream(frames.device).synchronize()      # frames / masks were produced on this stream
     pending = list(range(len(gts)))
     active = {}                                                     # worker index -> (object index, generator)
-    budget = workers[0].wg_budget if min(len(gts), len(workers)) > 1 else 0   # alone on the GPU: plan for the whole chip
+    together = min(len(gts), len(workers)) > 1
+    budget = workers[0].wg_budget if together else 0   # alone on the GPU: plan for the whole chip
     for w in workers:
         if hasattr(w.model, 'set_wg_budget'):
             w.model.set_wg_budget(budget)
+        if hasattr(w.model, 'set_side_stream'):        # side by side: one queue per engine (include/eosvos.h eosvos_set_side_stream)
+            w.model.set_side_stream(not together)
     while pending or active:
         for wi, w in enumerate(workers):
             if wi not in active and pending:
@@ -357,6 +360,8 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         else:
             if workers is not None:
                 model.set_wg_budget(0)                                          # alone on the GPU
+                if hasattr(model, 'set_side_stream'):
+                    model.set_side_stream(True)
             for o in mine:
                 probs[o], _ = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gts[o], cfg,
                                               train_frame_id=fids[o])
@@ -380,6 +385,8 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         pool.shutdown(wait=True)
     if workers is not None and hasattr(model, 'set_wg_budget'):
         model.set_wg_budget(budget_before)              # worker 0 is the caller's model: leave it as it was handed in
+        if hasattr(model, 'set_side_stream'):
+            model.set_side_stream(True)
     mean_J = float(np.mean(J_seq)) if J_seq else 0.0
     out_best = best_mean_J
     if rank == 0 and save_dir is not None and not dataset.test_mode:

@@ -176,10 +176,13 @@ class MetaTrainer:
 
     # ---- one meta-iteration --------------------------------------------------------------
     def _apply_wg_budget(self):
-        """(Re)apply the budget: the first engine is the model's and an evaluation in between may have changed it."""
+        """(Re)apply the budget: the first engine is the model's and an evaluation in between may have changed it.
+        Engines that run side by side also give up their side stream (one queue each: `eosvos_set_side_stream`)."""
         for e in self.engines:
             if hasattr(e, 'set_wg_budget'):
                 e.set_wg_budget(self.wg_budget)
+            if len(self.engines) > 1 and hasattr(e, 'set_side_stream') and os.environ.get('EOSVOS_INFLIGHT_SIDE_STREAM', '0') != '1':
+                e.set_side_stream(False)
 
     def run_tasks_concurrent(self, tasks, inner_steps):
         """The default schedule (one meta frame after `inner_steps` steps) for several tasks at once, task i on engine

@@ -156,6 +156,13 @@ class DeepLabV3Plus:
         m.training, m._dropout_off = self.training, self._dropout_off
         return m
 
+    def set_side_stream(self, on):
+        """`eosvos_set_side_stream` of this model's engine, now and whenever the engine is rebuilt (False while it runs
+        beside other engines: `evaluate.run_objects_in_flight`)."""
+        self.side_stream = bool(on)
+        if self.engine is not None and hasattr(self.engine, 'set_side_stream'):
+            self.engine.set_side_stream(self.side_stream)
+
     def set_wg_budget(self, workgroups):
         """`eosvos_set_wg_budget` of this model's engine, now and whenever the engine is rebuilt."""
         self.wg_budget = int(workgroups)
@@ -183,6 +190,8 @@ class DeepLabV3Plus:
             self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm)
             if getattr(self, 'wg_budget', 0) and hasattr(self.engine, 'set_wg_budget'):
                 self.engine.set_wg_budget(self.wg_budget)
+            if not getattr(self, 'side_stream', True) and hasattr(self.engine, 'set_side_stream'):
+                self.engine.set_side_stream(False)
             self.max_batch = max(batch, self.max_batch)
             self._dirty = True
             if carry is not None:

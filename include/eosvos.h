@@ -73,6 +73,15 @@ int eosvos_get_matrix_mode(void);
  * No reference counterpart (the reference runs one task per process and lets cuDNN choose). */
 int eosvos_set_wg_budget(eosvos_engine* e, int workgroups);
 
+/* An engine alone on the GPU runs its weight-gradient launches on a second (side) stream beside the data-gradient chain
+ * (on = 1, the default).  Engines that run side by side -- the tasks of a meta-batch in flight on one GPU, the objects of
+ * a sequence (evaluate.py:132) -- are better off with ONE queue each (on = 0): the other engines fill the chip, and the
+ * fork / join events between the two streams of every engine only add bubbles.  Measured on one MI355X at 480x854
+ * (tools/inflight_sweep.py, profiles/r03_inflight_sweep.txt): 4 engines at batch 1, 192 -> 264 fine-tune iterations/s;
+ * 3 engines at batch 3, 95.6 -> 105.5.  Call it while the engine is idle.  Results do not change (same kernels, same
+ * order per engine).  Returns 0 / 1 = the state now in effect, -1 on error. */
+int eosvos_set_side_stream(eosvos_engine* e, int on);
+
 /* Number of convolutions of DeepLabV3+ on `arch` (63 for ResNet-50); -1 on bad arch.
  * Replaces: module enumeration of networks/deeplabv3plus.py:104-155. */
 int eosvos_num_convs(int arch);
