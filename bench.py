@@ -29,7 +29,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')     # before the HIP runtime initialises: see e-osvos_amd/__init__.py
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -180,11 +182,19 @@ def meta_setup(eng, dist, world, rank, sd, lrs, dev, tasks_per_rank, engine_fact
     from eosvos_amd import synthetic
     from eosvos_amd.meta_run import MetaTrainer
     extra = []
-    for _ in range(tasks_per_rank - 1):
-        if torch.cuda.is_available():
+    real = engine_factory.__name__ == 'Engine' and torch.cuda.is_available()
+    if real and tasks_per_rank > 1:
+        # Engines in flight: one queue each, every one built fresh and back to back on a new stream.  ROCm deals streams onto
+        # its hardware queues in creation order; engines whose queues share one or sit on the same pipe lose a quarter of
+        # their rate (33 instead of 41 tasks/s, profiles/r03_hw_queue_sweep.txt), so the headline's engine (default stream +
+        # its side stream) is left out of this.
+        fresh = []
+        for _ in range(tasks_per_rank):
             with torch.cuda.stream(torch.cuda.Stream()):
-                extra.append(engine_factory('resnet50', H, W, max_batch=1, device=dev))
-        else:
+                fresh.append(engine_factory('resnet50', H, W, max_batch=1, device=dev, side_stream=False))
+        eng, extra = fresh[0], fresh[1:]
+    else:
+        for _ in range(tasks_per_rank - 1):
             extra.append(engine_factory('resnet50', H, W, max_batch=1, device=dev))
     mt = MetaTrainer(eng, dist=dist, meta_batch_size=world * tasks_per_rank, extra_engines=extra)
     mt.load_state(sd, lrs)
@@ -197,7 +207,7 @@ def meta_setup(eng, dist, world, rank, sd, lrs, dev, tasks_per_rank, engine_fact
 
     def step():
         losses[:] = mt.meta_iteration(tasks, inner_steps=5)
-    return mt, step, losses, extra
+    return mt, step, losses, (extra + [eng] if real and tasks_per_rank > 1 else extra)
 
 
 def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, mode, lib_version, engine_factory):
@@ -386,45 +396,10 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         'ms_per_round': 1e3 * dtr / nr, 'finetune_iters_per_sec': world * 10 * nr / dtr,
         'note': 'iterations/s over the whole round (inference and the weight restore included)'}
     eng.reset()
-    if not a.no_ab and world == 1:
-        # same engine, same buffers, fp32-MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split kernels
-        engine_mod.set_matrix_mode('f32')
-        for _ in range(3):
-            step()
-        dt32 = timed(step, min(a.steps, 30), barrier, dist, dev)
-        engine_mod.set_matrix_mode(mode)
-        eng.reset()
-        extra['fp32_mfma_mode_ms_per_step'] = 1e3 * dt32 / min(a.steps, 30)
-    if not a.no_ab and world == 1 and torch.cuda.is_available():
-        # the objects of a multi-object sequence are independent fine-tunes (evaluate.py:132): three of them in flight, one
-        # engine and ONE queue each (no side stream, each launch planned for half the chip: evaluate.run_objects_in_flight),
-        # fill the tails / small grids one iteration leaves idle.  Not the headline (one object per rank).
-        others = []
-        for _ in range(2):
-            with torch.cuda.stream(torch.cuda.Stream()):
-                e2 = Engine('resnet50', H, W, max_batch=BATCH, device=dev)
-                e2.load_model_state(sd, lrs)
-            others.append(e2)
-        for e3 in [eng] + others:
-            e3.set_side_stream(False)
-            e3.set_wg_budget(256)
-
-        def step3():
-            step()
-            for e2 in others:
-                with torch.cuda.stream(e2.stream):
-                    e2.finetune_step(xg, yg, sync_loss=False)
-        for _ in range(3):
-            step3()
-        n3 = min(a.steps, 30)
-        dt3 = timed(step3, n3, barrier, dist, dev)
-        extra['finetune_iters_per_sec_3_objects_in_flight'] = 3 * n3 / dt3
-        for e2 in others:
-            e2.close()
-        eng.set_side_stream(True)
-        eng.set_wg_budget(0)
     if not a.no_meta:
         # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4]), tasks in flight together.
+        # (Before the A/B extras below: they create and destroy streams, and which hardware queue a later stream lands on
+        # depends on that history -- engines whose streams share a pipe lose a quarter of their rate, profiles/r03_hw_queue_sweep.txt.)
         # An extra of this line: a failure here (every rank raises alike: the only rank-dependent step is the all-reduce)
         # is recorded, not allowed to take the headline with it.
         tpr = a.tasks_per_rank
@@ -454,6 +429,38 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
             extra['meta_tasks_per_sec'] = None
             extra['meta_error'] = f'{type(exc).__name__}: {exc}'
 
+    if not a.no_ab and world == 1:
+        # same engine, same buffers, fp32-MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split kernels
+        engine_mod.set_matrix_mode('f32')
+        for _ in range(3):
+            step()
+        dt32 = timed(step, min(a.steps, 30), barrier, dist, dev)
+        engine_mod.set_matrix_mode(mode)
+        eng.reset()
+        extra['fp32_mfma_mode_ms_per_step'] = 1e3 * dt32 / min(a.steps, 30)
+    if not a.no_ab and world == 1 and torch.cuda.is_available():
+        # the objects of a multi-object sequence are independent fine-tunes (evaluate.py:132): three of them in flight, one
+        # engine and ONE queue each (no side stream, each launch planned for half the chip, fresh consecutive streams:
+        # evaluate.run_objects_in_flight), fill the tails / small grids one iteration leaves idle.  Not the headline.
+        others = []
+        for _ in range(3):
+            with torch.cuda.stream(torch.cuda.Stream()):
+                e2 = Engine('resnet50', H, W, max_batch=BATCH, device=dev, side_stream=False)
+                e2.load_model_state(sd, lrs)
+                e2.set_wg_budget(256)
+            others.append(e2)
+
+        def step3():
+            for e2 in others:
+                with torch.cuda.stream(e2.stream):
+                    e2.finetune_step(xg, yg, sync_loss=False)
+        for _ in range(3):
+            step3()
+        n3 = min(a.steps, 30)
+        dt3 = timed(step3, n3, barrier, dist, dev)
+        extra['finetune_iters_per_sec_3_objects_in_flight'] = 3 * n3 / dt3
+        for e2 in others:
+            e2.close()
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_finetune(sd, lrs, x, y)

@@ -8,4 +8,17 @@ reference's operator interface for that path (`networks.DeepLabV3Plus`,
 `meta_optim.MetaOptimizer`, `helper_func.compute_loss/init_parent_model`, `radam.RAdam`).
 There is no CPU fallback: without the built library every op raises.
 """
-__version__ = '0.1.0'
+import os as _os_env
+
+# ROCm deals HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: the first streams get a queue each, later ones
+# the least-referenced queue) and the queues onto 4 pipes.  Engines that run side by side -- meta tasks / objects in
+# flight, one stream each -- lose a quarter of their rate when two of their streams share a queue or a pipe, and with 4
+# queues which ones do depends on every stream the process created before (tools/stream_queue_probe*.py,
+# profiles/r03_stream_queue_probe.txt, r03_hw_queue_sweep.txt: 41 vs 29-35 meta-tasks/s, 107 vs 85 iterations/s).  With
+# more queues than streams every stream owns one, and engines built back to back WITHOUT a side stream sit on consecutive
+# queues = different pipes.  A lone engine is unaffected (90.1 / 90.3 / 90.2 it/s with 4 / 8 / 16 queues).
+# The HIP runtime reads this when it initialises (first GPU call), so it is set as early as this package can.
+_os_env.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
+del _os_env
+
+__version__ = '0.3.0'

@@ -183,7 +183,6 @@ struct eosvos_engine {
   int arch, H, W, maxB, dev;
   hipStream_t s;
   hipStream_t s2 = nullptr;            // side stream: weight-gradient kernels run beside the dgrad chain
-  hipStream_t s2_parked = nullptr;     // eosvos_set_side_stream(e, 0) parks it here
   std::vector<hipEvent_t> ev;          // one fork event per conv + a join event
   bool side_used = false;
   std::vector<std::function<void()>> side_q;   // weight-gradient launches waiting for the next fork (see side_flush)
@@ -810,7 +809,7 @@ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 
 extern "C" {
 
-const char* eosvos_version(void) { return "eosvos-mi355x 0.3 (gfx950, fp32 implicit GEMM on the bf16 matrix cores: exact 3-way split, 6 partial products)"; }
+const char* eosvos_version(void) { return "eosvos-mi355x 0.4 (gfx950, fp32 implicit GEMM on the bf16 matrix cores: exact 3-way split, 6 partial products on v_mfma_f32_16x16x32_bf16)"; }
 const char* eosvos_last_error(void) { return g_err.c_str(); }
 
 int eosvos_set_matrix_mode(int mode) {
@@ -833,16 +832,19 @@ int eosvos_set_side_stream(eosvos_engine* e, int on) {
   if (!e) { fail("null engine"); return -1; }
   if (hipSetDevice(e->dev) != hipSuccess) { fail("hipSetDevice"); return -1; }
   if (!on && e->s2) {
+    // The stream is DESTROYED, not parked: an idle second stream per engine still costs the engines that run side by side
+    // a quarter of their throughput once every stream has a hardware queue of its own (GPU_MAX_HW_QUEUES >= 6; measured
+    // 41 -> 29 meta-tasks/s with four engines, profiles/r03_hw_queue_sweep.txt).
     (void)hipStreamSynchronize(e->s);
     (void)hipStreamSynchronize(e->s2);
-    e->s2_parked = e->s2;          // kept for a later on = 1 (the events and the side workspace stay as they are)
+    (void)hipStreamDestroy(e->s2);
     e->s2 = nullptr;
     e->side_used = false;
     e->side_q.clear();
-  } else if (on && !e->s2 && e->s2_parked) {
+    e->wino_w_wait = false;
+  } else if (on && !e->s2 && e->ws_conv2) {          // (engines built under EOSVOS_NO_SIDE_STREAM=1 have no side workspace)
     (void)hipStreamSynchronize(e->s);
-    e->s2 = e->s2_parked;
-    e->s2_parked = nullptr;
+    if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess) { e->s2 = nullptr; fail("hipStreamCreate"); return -1; }
   }
   return e->s2 ? 1 : 0;
 }
@@ -1085,7 +1087,6 @@ int eosvos_destroy(eosvos_engine* e) {
   if (!e) return 0;
   (void)hipStreamSynchronize(e->s);
   if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
-  if (e->s2_parked) (void)hipStreamDestroy(e->s2_parked);
   for (auto& evt : e->ev) (void)hipEventDestroy(evt);
   if (e->ev_wino_w) (void)hipEventDestroy(e->ev_wino_w);
   for (void* p : e->allocs) (void)hipFree(p);

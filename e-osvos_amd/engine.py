@@ -33,8 +33,26 @@ def get_matrix_mode():
     return 'bf16x6' if _ffi.load().eosvos_get_matrix_mode() == 1 else 'f32'
 
 
+_POOL_WARMED = []
+
+
+def warm_stream_pool(device):
+    """ROCm deals HIP streams onto GPU_MAX_HW_QUEUES (4) hardware queues: the first streams get a queue each, later ones
+    the least-referenced queue, and engines that run side by side lose a quarter of their rate when two of their streams
+    share a queue (tools/stream_queue_probe.py, profiles/r03_stream_queue_probe.txt: 4 engines at batch 1, 207 vs 263
+    iterations/s).  torch hands out its 32 pooled streams in order; four consecutive ones sit on four different queues
+    EXCEPT among the first three of the pool, which are dealt while the queue pool is still filling.  So the pool is
+    instantiated, and its first three streams are burnt, before this package creates any stream of its own."""
+    if _POOL_WARMED or not torch.cuda.is_available():
+        return
+    _POOL_WARMED.extend(torch.cuda.Stream(device) for _ in range(3))
+
+
 class Engine:
-    def __init__(self, encoder='resnet50', height=480, width=854, max_batch=3, device='cuda:0', norm='bn'):
+    def __init__(self, encoder='resnet50', height=480, width=854, max_batch=3, device='cuda:0', norm='bn', side_stream=True):
+        """`side_stream=False`: an engine that will run beside others (one queue each, `eosvos_set_side_stream`) is built
+        without the second stream in the first place -- which hardware queue / pipe a stream lands on depends on every
+        stream created before it, and engines whose queues share a pipe run at three quarters of their rate."""
         if not torch.cuda.is_available():
             raise _ffi.EosvosError('no GPU visible: the e-osvos_amd engine has no CPU path')
         self.lib = _ffi.load()
@@ -51,10 +69,22 @@ class Engine:
         self.lr_level, self.lr_log = 'NEURON', False
         self.n_lr_store = self.n_lr
         torch.cuda.set_device(self.device)
+        warm_stream_pool(self.device)
         self.stream = torch.cuda.current_stream(self.device)
         h = ctypes.c_void_p()
-        _ffi.check(self.lib.eosvos_create(ctypes.byref(h), self.arch, 1 if norm == 'gn' else 0, height, width, max_batch,
-                                          self.device.index or 0, ctypes.c_void_p(self.stream.cuda_stream)))
+        import os
+        had = os.environ.get('EOSVOS_NO_SIDE_STREAM')
+        if not side_stream:
+            os.environ['EOSVOS_NO_SIDE_STREAM'] = '1'        # read by eosvos_create
+        try:
+            _ffi.check(self.lib.eosvos_create(ctypes.byref(h), self.arch, 1 if norm == 'gn' else 0, height, width, max_batch,
+                                              self.device.index or 0, ctypes.c_void_p(self.stream.cuda_stream)))
+        finally:
+            if not side_stream:
+                if had is None:
+                    os.environ.pop('EOSVOS_NO_SIDE_STREAM', None)
+                else:
+                    os.environ['EOSVOS_NO_SIDE_STREAM'] = had
         self.h = h
         self._loss = torch.zeros(1, device=self.device)
         # host-side view of the engine's state (networks.DeepLabV3Plus carries it across an engine re-creation)

@@ -173,16 +173,20 @@ class _NullCtx:
 
 
 def object_workers(model, meta_optim, meta_optim_cfg, n, wg_budget=256):
-    """`n` workers for `run_objects_in_flight`: the given pair (on the current stream) plus n - 1 spawned ones, each on
-    its own stream with its own engine.  The objects of a multi-object sequence are independent fine-tunes
-    (`evaluate.py:132`); three of them in flight fill the tails and small grids one leaves idle (+8 % iterations/s at
-    batch 3, 480x854, `bench.py` extra).  Engines that share the GPU plan for `wg_budget` workgroups per launch."""
+    """`n` workers for `run_objects_in_flight`, each a spawned copy of `model` (same construction and learned state) with
+    its own engine on its own NEW stream and no side stream: one hardware queue per engine.  The caller's model is not one
+    of them -- its engine lives on the caller's (default) stream, and which hardware queue the next new stream shares with
+    it is not under our control (`engine.warm_stream_pool`); consecutive new streams do sit on different queues.
+    The objects of a multi-object sequence are independent fine-tunes (`evaluate.py:132`); three of them in flight fill
+    the tails and small grids one leaves idle (+19 % iterations/s at batch 3, 480x854, `bench.py` extra).  Engines that
+    share the GPU plan for `wg_budget` workgroups per launch."""
     from .meta_optim import MetaOptimizer
-    ws = [ObjectWorker(model, meta_optim, torch.cuda.current_stream(model.device) if model.device.type == 'cuda' else None)]
-    for _ in range(n - 1):
+    ws = []
+    on_gpu = model.device.type == 'cuda'
+    for _ in range(n):
         m = model.spawn()
-        ws.append(ObjectWorker(m, MetaOptimizer(m, **meta_optim_cfg),
-                               torch.cuda.Stream(model.device) if model.device.type == 'cuda' else None))
+        m.side_stream = os.environ.get('EOSVOS_INFLIGHT_SIDE_STREAM', '0') == '1'      # default: one queue per engine
+        ws.append(ObjectWorker(m, MetaOptimizer(m, **meta_optim_cfg), torch.cuda.Stream(model.device) if on_gpu else None))
     for w in ws:
         w.wg_budget = wg_budget
     return ws
@@ -203,8 +207,6 @@ def run_objects_in_flight(workers, meta_optim_state_dict, frames, gts, cfg, augm
     for w in workers:
         if hasattr(w.model, 'set_wg_budget'):
             w.model.set_wg_budget(budget)
-        if hasattr(w.model, 'set_side_stream'):        # side by side: one queue per engine (include/eosvos.h eosvos_set_side_stream)
-            w.model.set_side_stream(not together)
     while pending or active:
         for wi, w in enumerate(workers):
             if wi not in active and pending:
@@ -302,7 +304,7 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     workers = None
     if objects_in_flight > 1:
         workers = getattr(model, '_object_workers', None)
-        if workers is None or len(workers) != objects_in_flight or workers[0].meta_optim is not meta_optim:
+        if workers is None or len(workers) != objects_in_flight:
             workers = model._object_workers = object_workers(model, meta_optim, cfg['meta_optim_cfg'], objects_in_flight)
     J_seq, labels_out, item, eval_time, num_frames = [], {}, 0, 0.0, 0
     # File readers (`prefetchable`) are used through shallow copies on two worker threads: sequence k + 1 is decoded while
@@ -360,8 +362,6 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         else:
             if workers is not None:
                 model.set_wg_budget(0)                                          # alone on the GPU
-                if hasattr(model, 'set_side_stream'):
-                    model.set_side_stream(True)
             for o in mine:
                 probs[o], _ = finetune_object(model, meta_optim, meta_optim_state_dict, frames, gts[o], cfg,
                                               train_frame_id=fids[o])
@@ -384,9 +384,7 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     if pool:
         pool.shutdown(wait=True)
     if workers is not None and hasattr(model, 'set_wg_budget'):
-        model.set_wg_budget(budget_before)              # worker 0 is the caller's model: leave it as it was handed in
-        if hasattr(model, 'set_side_stream'):
-            model.set_side_stream(True)
+        model.set_wg_budget(budget_before)
     mean_J = float(np.mean(J_seq)) if J_seq else 0.0
     out_best = best_mean_J
     if rank == 0 and save_dir is not None and not dataset.test_mode:

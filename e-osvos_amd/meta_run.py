@@ -231,8 +231,11 @@ class MetaTrainer:
         if len(self.engines) > 1 and len(local_tasks) > 1 and default_schedule and same_size:
             losses = self.run_tasks_concurrent(local_tasks, inner_steps)
         else:
-            losses = [self.run_task(*t, inner_steps=inner_steps, bptt_epochs=bptt_epochs,
-                                    multi_step_bptt_loss=multi_step_bptt_loss) for t in local_tasks]
+            with _on_stream(self.eng):
+                losses = [self.run_task(*t, inner_steps=inner_steps, bptt_epochs=bptt_epochs,
+                                        multi_step_bptt_loss=multi_step_bptt_loss) for t in local_tasks]
+            if self.state.is_cuda and getattr(self.eng, 'stream', None) is not None:
+                torch.cuda.current_stream(self.state.device).wait_stream(self.eng.stream)
         t1 = tick()
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
             self.dist.all_reduce(self.grad)             # sum over ranks, one 161 MB message
@@ -270,6 +273,12 @@ class MetaTrainer:
             if fp:
                 ranges.append((nl, nl + fp, 0.0, self.wd))
             ranges.append((nl + fp, self.state.numel(), self.model_init_lr, self.wd))
+        # the gradient was summed by torch on the CURRENT stream; the engine's kernels run on ITS stream (the same one for an
+        # engine built on the default stream, a different one for engines built for side-by-side work)
+        es = getattr(eng, 'stream', None)
+        cur = torch.cuda.current_stream(self.state.device) if self.state.is_cuda else None
+        if es is not None and cur is not None and es != cur:
+            es.wait_stream(cur)
         for lo, hi, lr, wd in ranges:
             eng.radam_step(self.state[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                            lr, wd, self.step, grad_scale=scale, grad_clip=clip)
@@ -277,6 +286,8 @@ class MetaTrainer:
             eng.clamp(self.state[:nl], -33.0, float('inf') if self.max_lr is None else math.log(self.max_lr))
         else:
             eng.clamp(self.state[:nl], 0.0, float('inf') if self.max_lr is None else float(self.max_lr))
+        if es is not None and cur is not None and es != cur:
+            cur.wait_stream(es)
         self.grad.zero_()
         self._push_state()
 

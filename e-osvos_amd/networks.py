@@ -187,7 +187,8 @@ class DeepLabV3Plus:
                 if e.steps_since_reset > 0 and not self._dirty:
                     carry = e.get_params()
                 e.close()
-            self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm)
+            self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm,
+                                 **({} if getattr(self, 'side_stream', True) else {'side_stream': False}))
             if getattr(self, 'wg_budget', 0) and hasattr(self.engine, 'set_wg_budget'):
                 self.engine.set_wg_budget(self.wg_budget)
             if not getattr(self, 'side_stream', True) and hasattr(self.engine, 'set_side_stream'):

@@ -213,6 +213,8 @@ def _run(cfg, run, run_dir, meta_mode, eval_proc, height, width, num_frames, num
         raise ValueError('meta_batch_size must be a multiple of the number of ranks (train_meta.py:150)')
     sub = cfg['meta_batch_size'] // world
     oc = cfg['meta_optim_optim_cfg']
+    if sub > 1 and dev.startswith('cuda'):
+        model.side_stream = False          # several tasks per rank run side by side: one queue per engine (eosvos_set_side_stream)
     eng = model._ensure_engine(height, width, max(cfg['data_cfg']['batch_sizes'].values()))
     # several tasks per rank: up to 4 of them in flight together, one engine each on its own stream (a batch-1 task alone
     # leaves CUs idle in its tails; measured 26.8 -> 34.2 tasks/s per GPU at 480x854)
@@ -221,8 +223,8 @@ def _run(cfg, run, run_dir, meta_mode, eval_proc, height, width, num_frames, num
         from .engine import Engine
         for _ in range(min(sub, 4) - 1):
             with torch.cuda.stream(torch.cuda.Stream()):
-                extra_engines.append(Engine(pm['encoder'], height, width, max(cfg['data_cfg']['batch_sizes'].values()), dev,
-                                            norm=model.norm))
+                extra_engines.append(Engine(model.encoder, height, width, max(cfg['data_cfg']['batch_sizes'].values()), dev,
+                                            norm=model.norm, side_stream=False))
     mt = MetaTrainer(eng, dist=dist, extra_engines=extra_engines, meta_batch_size=cfg['meta_batch_size'], model_init_lr=oc['model_init_lr'],
                      log_init_lr_lr=oc['log_init_lr_lr'], model_init_weight_decay=oc['model_init_weight_decay'],
                      grad_clip=oc['grad_clip'], max_lr=cfg['meta_optim_cfg']['max_lr'],

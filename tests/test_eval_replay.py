@@ -221,8 +221,12 @@ def test_objects_in_flight_replay_the_same_work(tmp_path, monkeypatch):
     for seq in sc['seqs']:
         assert torch.equal(res_con['labels'][seq], res_seq['labels'][seq])
     # same multiset of events; the in-flight run interleaves the two objects of 'bear' (its forward batches alternate)
+    # (theta <- init events excepted: every worker engine uploads the learned init once more when it is built, and the
+    # in-flight run builds one engine per worker on top of the caller's; per-object resets are pinned by the replay above)
     key = lambda e: json.dumps(e)
-    assert sorted(map(key, ev_con)) == sorted(map(key, ev_seq))
+    strip = lambda ev: sorted(map(key, (e for e in ev if e != ['reset'])))
+    assert strip(ev_con) == strip(ev_seq)
+    assert sum(e == ['reset'] for e in ev_con) >= sum(e == ['reset'] for e in ev_seq)
     assert [e for e in ev_con if e[0] != 'seed'] != [e for e in ev_seq if e[0] != 'seed']
     inf = [e[1] for e in ev_con if e[0] == 'infer'][:6]
     assert inf == [1, 2, 3, 1, 2, 3]                                     # one inference batch of object 0, one of object 1, ...
@@ -247,7 +251,7 @@ def test_more_objects_than_workers():
            for o in range(5)]
     one = [finetune_object(model, mo, msd, frames, g, cfg) for g in gts]
     workers = object_workers(model, mo, cfg['meta_optim_cfg'], 2)
-    assert len(workers) == 2 and workers[1].model is not model
+    assert len(workers) == 2 and all(w.model is not model for w in workers)
     con = run_objects_in_flight(workers, msd, frames, gts, cfg)
     assert len(con) == 5
     for (p2, h2), (p1, h1) in zip(con, one):

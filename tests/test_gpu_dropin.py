@@ -202,9 +202,12 @@ def test_objects_in_flight_equal_one_after_the_other(model_and_optim):
     rows = torch.arange(H).view(-1, 1)
     objs = [(gt[0] * (rows < H // 2)).float(), (gt[0] * (rows >= H // 2)).float()]
     workers = object_workers(model, mo, MO_CFG, 2)
-    assert workers[0].model is model and workers[1].model is not model and workers[1].stream != workers[0].stream
+    assert all(w.model is not model for w in workers) and workers[1].stream != workers[0].stream
     res = run_objects_in_flight(workers, msd, seq, objs, cfg)
-    assert model.engine.set_wg_budget(256) == 256 and workers[1].model.engine is not model.engine
+    assert workers[1].model.engine is not workers[0].model.engine
+    assert not workers[0].model.engine.set_side_stream(True)            # built for side-by-side work: one queue, no second stream
+    model._ensure_engine(H, W, 3)
+    assert model.engine.set_wg_budget(256) == 256
     torch.cuda.synchronize()
     one = [finetune_object(model, mo, msd, seq, g, cfg) for g in objs]              # same budget, one engine
     for (p2, h2), (p1, h1) in zip(res, one):
@@ -213,7 +216,7 @@ def test_objects_in_flight_equal_one_after_the_other(model_and_optim):
     whole = [finetune_object(model, mo, msd, seq, g, cfg) for g in objs]
     for (p2, _), (p0, _) in zip(res, whole):
         assert float((p2 - p0).abs().max()) < 1e-3
-    for w in workers[1:]:
+    for w in workers:
         w.model.engine.close()
 
 

@@ -1,16 +1,16 @@
 #!/bin/bash
 # Produces the per-round evidence under gpurun_out/$R (copy what is to be judged into profiles/):
-#   PMC passes of the step's dominant kernel (-> profiles/r02_pmc_dominant_kernel.json, read by bench.py for roofline.traffic),
+#   PMC passes of the step's dominant kernel (-> profiles/$R_pmc_dominant_kernel.json, read by bench.py for roofline.traffic),
 #   the bench lines (fine-tune + meta), rocprofv3 --kernel-trace --stats of the same bench command, per-layer reports.
-# usage: tools/round_artifacts.sh r02
-R=${1:-r02}
+# usage: tools/round_artifacts.sh r03
+R=${1:-r03}
 O=$PWD/gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --no-cpu-baseline --no-meta --no-ab > $O/bench_quick.json 2> $O/bench_quick.err
 K=$(python3 -c "import json;print(json.load(open('$O/bench_quick.json'))['roofline']['kernel'])")
 echo "dominant kernel: $K"
 tools/pmc_dominant.sh $R "$K" 3
-cp $O/pmc_dominant_kernel.json profiles/r02_pmc_dominant_kernel.json
+cp $O/pmc_dominant_kernel.json profiles/${R}_pmc_dominant_kernel.json
 python3 bench.py > $O/bench_b3.json 2> $O/bench.err; tail -c 400 $O/bench_b3.json
 python3 bench.py --metric meta > $O/bench_meta_b1.json 2> $O/bench_meta.err; tail -c 300 $O/bench_meta_b1.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline --no-meta --no-ab > $O/prof_bench.json 2> $O/prof.err
