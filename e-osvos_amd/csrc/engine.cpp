@@ -183,6 +183,9 @@ struct eosvos_engine {
   int arch, H, W, maxB, dev;
   hipStream_t s;
   hipStream_t s2 = nullptr;            // side stream: weight-gradient kernels run beside the dgrad chain
+  hipStream_t s3 = nullptr;            // EOSVOS_TUNE_SIDE_STREAMS=2 (experiment): weight gradients alternate between s2 and s3
+  hipEvent_t ev_s3 = nullptr;
+  unsigned wg_rr = 0;
   std::vector<hipEvent_t> ev;          // one fork event per conv + a join event
   bool side_used = false;
   std::vector<std::function<void()>> side_q;   // weight-gradient launches waiting for the next fork (see side_flush)
@@ -573,6 +576,7 @@ void side_flush(eosvos_engine* e) {
   if (e->side_q.empty()) return;
   (void)hipEventRecord(e->ev[0], e->s);            // everything the queued launches read is complete here
   (void)hipStreamWaitEvent(e->s2, e->ev[0], 0);
+  if (e->s3) (void)hipStreamWaitEvent(e->s3, e->ev[0], 0);
   for (auto& f : e->side_q) f();
   e->side_q.clear();
   e->side_used = true;
@@ -753,7 +757,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     nslabs = a.splits;
   }
   if (e->s2) {
-    hipStream_t s2 = e->s2;
+    hipStream_t s2 = (e->s3 && !wino && (e->wg_rr++ & 1)) ? e->s3 : e->s2;
     e->side_q.push_back([go, s2]() { go(s2); });
     if ((int)e->side_q.size() >= (B == 1 ? EOSVOS_SIDE_BATCH : 1)) side_flush(e);
   } else {
@@ -1065,6 +1069,10 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
       e->ev.resize(t.convs.size() + 2);
       for (auto& evt : e->ev) HIPOK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
       HIPOK(hipEventCreateWithFlags(&e->ev_wino_w, hipEventDisableTiming));
+      if (getenv("EOSVOS_TUNE_SIDE_STREAMS") && atoi(getenv("EOSVOS_TUNE_SIDE_STREAMS")) >= 2) {
+        HIPOK(hipStreamCreateWithFlags(&e->s3, hipStreamNonBlocking));
+        HIPOK(hipEventCreateWithFlags(&e->ev_s3, hipEventDisableTiming));
+      }
       e->ws_conv2 = e->falloc(conv_ws_floats());
       if (!e->ws_conv2) { eosvos_destroy(e); return fail("hipMalloc side workspace"); }
     }
@@ -1089,6 +1097,8 @@ int eosvos_destroy(eosvos_engine* e) {
   if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
   for (auto& evt : e->ev) (void)hipEventDestroy(evt);
   if (e->ev_wino_w) (void)hipEventDestroy(e->ev_wino_w);
+  if (e->s3) { (void)hipStreamSynchronize(e->s3); (void)hipStreamDestroy(e->s3); }
+  if (e->ev_s3) (void)hipEventDestroy(e->ev_s3);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
   return 0;
@@ -1446,6 +1456,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
         side_flush(e);
         (void)hipEventRecord(e->ev[t.convs.size()], e->s);      // their dgrads were the last readers of W
         (void)hipStreamWaitEvent(e->s2, e->ev[t.convs.size()], 0);
+        if (e->s3) { (void)hipEventRecord(e->ev_s3, e->s3); (void)hipStreamWaitEvent(e->s2, e->ev_s3, 0); }   // slabs written on s3
         if (flush_updates(e, B, update, accumulate, 0, e->s2)) return 1;
         e->side_used = true;
       } else if (flush_updates(e, B, update, accumulate, 0, e->s)) return 1;
@@ -1495,6 +1506,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     apply_update(e, 0, chunks, update, accumulate);
   }
   if (e->s2) side_flush(e);
+  if (e->s3 && e->side_used) { (void)hipEventRecord(e->ev_s3, e->s3); (void)hipStreamWaitEvent(e->s, e->ev_s3, 0); }
   if (e->s2 && e->side_used) {           // join: the update reads every slab
     (void)hipEventRecord(e->ev.back(), e->s2);
     (void)hipStreamWaitEvent(e->s, e->ev.back(), 0);

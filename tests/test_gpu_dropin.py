@@ -407,3 +407,79 @@ def test_dropin_bptt_schedules_vs_golden(golden_dir, tag, bptt, multi):
     last = init_g[-2].cpu().numpy()
     assert np.abs(last - g[tag + '_init_grad_last']).max() <= 6e-4 * np.abs(g[tag + '_init_grad_last']).max()
     model.engine.close()
+
+
+class _MixedSizeSequences:
+    """Reader with two sequences of DIFFERENT frame sizes (YouTube-VOS has many): `evaluate_dataset` must rebuild the engine
+    between them although the first one left a first-step snapshot behind (online adaptation)."""
+    test_mode = False
+    multi_object = 'single_id'
+    all_frames = False
+    seqs_names = ['wide', 'small']
+    SIZES = {'wide': (96, 160), 'small': (64, 96)}
+
+    def _objects(self, seq):
+        h, w = self.SIZES[seq]
+        frames, gt = synthetic.synthetic_frames(1, h, w, seed=21 + len(seq), second_object=True)
+        top = (torch.arange(h).view(-1, 1) < h // 2)
+        return frames, [(gt[0] * top).float(), (gt[0] * ~top).float()]
+
+    def sequence_tensors(self, seq, device='cpu', with_frame_ids=False):
+        frames, gts = self._objects(seq)
+        seq_frames = torch.cat([torch.roll(frames, shifts=4 * i, dims=3) for i in range(5)])
+        out = (seq_frames.to(device), [g.to(device) for g in gts])
+        return out + ([0, 0],) if with_frame_ids else out
+
+    def frame_names(self, seq):
+        return [f'{i:05d}' for i in range(5)]
+
+    def label_maps(self, seq):
+        _, gts = self._objects(seq)
+        h, w = self.SIZES[seq]
+        lab = torch.zeros(h, w, dtype=torch.uint8)
+        for o, g in enumerate(gts):
+            lab[g[0] > 0] = o + 1
+        return np.stack([torch.roll(lab, shifts=4 * i, dims=1).numpy() for i in range(5)])
+
+
+@pytest.mark.parametrize('in_flight', [1, 2])
+def test_evaluate_dataset_with_mixed_frame_sizes(model_and_optim, tmp_path, in_flight):
+    from eosvos_amd import config
+    from eosvos_amd.evaluate import evaluate_dataset
+    model, mo, msd = model_and_optim
+    cfg = config.parse_cli(['with', 'DAVIS-2017', 'e-OSVOS-OnA', 'num_epochs.eval=2', 'eval_online_adapt.num_epochs=1',
+                            'eval_online_adapt.step=2'])
+    cfg['datasets']['val'] = {'name': 'synthetic', 'split': 'val', 'eval': True}
+    res = evaluate_dataset(model, mo, msd, _MixedSizeSequences(), cfg, 'val', save_dir=str(tmp_path), objects_in_flight=in_flight)
+    assert res['labels']['wide'].shape == (5, 96, 160) and res['labels']['small'].shape == (5, 64, 96)
+    for seq in ('wide', 'small'):
+        assert set(res['labels'][seq].unique().tolist()) <= {0, 1, 2}
+        assert np.array_equal(res['labels'][seq][0].numpy(), _MixedSizeSequences().label_maps(seq)[0])     # train frame = GT
+    assert len(res['J_seq']) == 2 and all(np.isfinite(j) for j in res['J_seq'])
+    for w in getattr(model, '_object_workers', None) or []:
+        if w.model.engine is not None:
+            w.model.engine.close()
+    model._object_workers = None
+
+
+def test_cli_loads_the_parent_checkpoint_into_the_engine(tmp_path, capsys):
+    """`parent_model.train.paths` (`src/train_meta.py:91-96`): a parent `.model` file with NON-synthetic BatchNorm statistics
+    -> `train_meta.main` -> the folded norm scale the engine holds (`eosvos_set_norm`) is that file's."""
+    import json
+    from eosvos_amd import train_meta
+    sd = synthetic.synthetic_state('resnet50')
+    sd['backbone.bn1.running_var'] = sd['backbone.bn1.running_var'] * 3.0 + 0.5
+    sd['backbone.bn1.running_mean'] = sd['backbone.bn1.running_mean'] + 0.25
+    torch.save(sd, tmp_path / 'parent.model')
+    mt = train_meta.main(['with', 'YouTube-VOS', 'meta_batch_size=1', 'num_epochs.train=1', f'save_dir={tmp_path}', 'env_suffix=par',
+                          f'parent_model.train.paths=[{tmp_path / "parent.model"}]'], height=96, width=160, num_meta_iters=1,
+                         data_root=str(tmp_path / 'no_data'), eval_cmd=False)
+    out = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith('{')]
+    assert {'parent_state': 'file', 'dataset_key': 'train'} in out
+    a = mt.eng.debug_tensor('norm_a').flatten()[:64].cpu()
+    b = mt.eng.debug_tensor('norm_b').flatten()[:64].cpu()
+    ref_a = sd['backbone.bn1.weight'] / torch.sqrt(sd['backbone.bn1.running_var'] + 1e-5)
+    ref_b = sd['backbone.bn1.bias'] - sd['backbone.bn1.running_mean'] * ref_a
+    assert torch.allclose(a, ref_a, rtol=1e-6, atol=1e-7) and torch.allclose(b, ref_b, rtol=1e-5, atol=1e-6)
+    syn = synthetic.synthetic_state('resnet50')
+    assert not torch.allclose(a, syn['backbone.bn1.weight'] / torch.sqrt(syn['backbone.bn1.running_var'] + 1e-5), rtol=1e-3)
