@@ -632,8 +632,11 @@ bool wgrad_groupable(const eosvos_engine* e, int ci) {
   // Measured at batch 3 (profiles/r03_ab_wgrad_group.txt): grouping layer3 (30 / 14 splits per conv -> 2, 578 -> 57 MB of
   // slabs) leaves the two-stream step time unchanged; grouping layer2 / layer1 as well makes it 1 % LONGER although the
   // summed kernel time drops by 0.3 ms -- their grouped launches start only after the stage's data-gradient chain and
-  // the last one runs with nothing beside it.  Default: layer3 only.
-  static const int min_stage = getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE") ? atoi(getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE")) : 2;
+  // the last one runs with nothing beside it.  Default with a side stream: layer3 only.
+  // An engine WITHOUT a side stream (it runs beside other engines, eosvos_set_side_stream) has no such overlap to lose:
+  // every stage is grouped (4 tasks in flight at batch 1: 41.0 -> 41.9 meta-tasks/s).
+  static const int env_stage = getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE") ? atoi(getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE")) : -1;
+  const int min_stage = env_stage >= 0 ? env_stage : (e->s2 ? 2 : 0);
   return !off && e->wg_group_on && conv_mfma_mode() == 1 && e->force_algo == 0 && ci < (int)e->t.stage.size() &&
          e->t.stage[ci] >= min_stage && e->t.stage[ci] <= 2 && !e->conv_hin.empty();
 }
@@ -846,9 +849,11 @@ int eosvos_set_side_stream(eosvos_engine* e, int on) {
     e->side_used = false;
     e->side_q.clear();
     e->wino_w_wait = false;
+    for (auto& tab : e->upd_tab) tab = nullptr;      // which stages group their weight gradients (hence the split counts) changes
   } else if (on && !e->s2 && e->ws_conv2) {          // (engines built under EOSVOS_NO_SIDE_STREAM=1 have no side workspace)
     (void)hipStreamSynchronize(e->s);
     if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess) { e->s2 = nullptr; fail("hipStreamCreate"); return -1; }
+    for (auto& tab : e->upd_tab) tab = nullptr;
   }
   return e->s2 ? 1 : 0;
 }

@@ -274,7 +274,8 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
     `objects_in_flight` (default: EOSVOS_OBJECTS_IN_FLIGHT, else 3 on a GPU): how many of a sequence's objects this
     rank fine-tunes side by side, one engine and stream each (`run_objects_in_flight`); 1 = one after the other.
     Engines that run side by side plan every launch for half the chip (`eosvos_set_wg_budget` 256), an object alone on
-    the GPU for all of it: the budget changes the split-K partition, i.e. the order of fp32 partial sums, so the last
+    the GPU for all of it, and engines built for side-by-side work have no side stream (every stage's weight gradients
+    grouped): budget and grouping change the split-K partition, i.e. the order of fp32 partial sums, so the last
     bits of a result (not its parity margins, `profiles/*parity_margins*`) depend on how many objects of the sequence
     landed on this rank.  EOSVOS_OBJECTS_IN_FLIGHT=1 gives one schedule-independent order.
     Returns dict(J_seq, mean_J, best_mean_J, time_per_frame, labels={seq: (N,H,W) uint8})."""

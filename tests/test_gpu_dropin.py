@@ -208,11 +208,13 @@ def test_objects_in_flight_equal_one_after_the_other(model_and_optim):
     assert not workers[0].model.engine.set_side_stream(True)            # built for side-by-side work: one queue, no second stream
     model._ensure_engine(H, W, 3)
     assert model.engine.set_wg_budget(256) == 256
+    model.set_side_stream(False)         # the workers' configuration: the split plan (= fp32 summation order) depends on it
     torch.cuda.synchronize()
     one = [finetune_object(model, mo, msd, seq, g, cfg) for g in objs]              # same budget, one engine
     for (p2, h2), (p1, h1) in zip(res, one):
         assert h2 == h1 and torch.equal(p2, p1)
     model.set_wg_budget(0)
+    model.set_side_stream(True)
     whole = [finetune_object(model, mo, msd, seq, g, cfg) for g in objs]
     for (p2, _), (p0, _) in zip(res, whole):
         assert float((p2 - p0).abs().max()) < 1e-3
