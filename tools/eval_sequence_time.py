@@ -23,7 +23,7 @@ for name, extra in (('e-OSVOS-50', ['num_epochs.eval=50']),
         model.to('cuda:0')
         model.max_batch = 3
         model.load_state_dict(synthetic.synthetic_state(cfg['parent_model']['encoder']))
-        mo = MetaOptimizer(model, **cfg['meta_optim_cfg'])
+        torch.manual_seed(1); mo = MetaOptimizer(model, **cfg['meta_optim_cfg'])      # (the lr init draws from torch's global RNG)
         msd = mo.state_dict()
         ev.evaluate_dataset(model, mo, msd, data.SyntheticSequences(1, 4, H, W, seed=3), dict(cfg, num_epochs=dict(cfg['num_epochs'], eval=2)),
                             'val', objects_in_flight=in_flight)                      # warm-up: engines, tap tables
