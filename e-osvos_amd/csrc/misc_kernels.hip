@@ -1812,46 +1812,45 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
   }
 }
-// dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][6x6][cin]) G
+// dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][6x6][cin]) G.  One thread per (cout, cin): the decoder convs have only
+// 256 x 304 of them, and a float4-per-thread version (64 workgroups of long dependent load chains) ran at 2 TB/s.
 __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ ws, int splits, int Cout, int Cin,
                                                                   float* __restrict__ dst) {
-  const int C4 = Cin >> 2;
-  const long n = (long)Cout * C4;
+  const long n = (long)Cout * Cin;
   GRID_STRIDE(e, n) {
-    const int c4 = (int)(e % C4), co = (int)(e / C4);
-    float4 t[3][6];                        // t = G^T u, streamed over the rows a of u (each summed over the splits)
+    const int ci = (int)(e % Cin), co = (int)(e / Cin);
+    float t[3][6];                         // t = G^T u, streamed over the rows a of u (each summed over the splits)
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) t[r][j] = w4::zero4();
+      for (int j = 0; j < 6; ++j) t[r][j] = 0.f;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      float4 u[6];                         // one row of dU, its 6 loads per split in flight together
+      float u[6];                          // one row of dU, its 6 loads per split in flight together
 #pragma unroll
-      for (int j = 0; j < 6; ++j) u[j] = w4::zero4();
+      for (int j = 0; j < 6; ++j) u[j] = 0.f;
       for (int z = 0; z < splits; ++z) {
-        float4 v[6];
+        float v[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          v[j] = *reinterpret_cast<const float4*>(ws + (((size_t)z * Cout + co) * 36 + (a * 6 + j)) * Cin + c4 * 4);
+        for (int j = 0; j < 6; ++j) v[j] = ws[(((size_t)z * Cout + co) * 36 + (a * 6 + j)) * Cin + ci];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { u[j].x += v[j].x; u[j].y += v[j].y; u[j].z += v[j].z; u[j].w += v[j].w; }
+        for (int j = 0; j < 6; ++j) u[j] += v[j];
       }
 #pragma unroll
       for (int j = 0; j < 6; ++j)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-          if (w4::G[a][r] != 0.f) w4::fma4(t[r][j], w4::G[a][r], u[j]);
+          if (w4::G[a][r] != 0.f) t[r][j] = fmaf(w4::G[a][r], u[j], t[r][j]);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        float4 v = w4::zero4();
+        float v = 0.f;
 #pragma unroll
         for (int j = 0; j < 6; ++j)
-          if (w4::G[j][q] != 0.f) w4::fma4(v, w4::G[j][q], t[r][j]);
-        *reinterpret_cast<float4*>(dst + ((size_t)co * 9 + r * 3 + q) * Cin + c4 * 4) = v;
+          if (w4::G[j][q] != 0.f) v = fmaf(w4::G[j][q], t[r][j], v);
+        dst[((size_t)co * 9 + r * 3 + q) * Cin + ci] = v;
       }
   }
 }
@@ -1975,7 +1974,7 @@ void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, 
                      scale, bias, relu, y, ldy);
 }
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
-  const long n = (long)Cout * (Cin / 4);
+  const long n = (long)Cout * Cin;
   hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, ws, splits, Cout, Cin, dst);
 }
 void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
