@@ -20,6 +20,7 @@
 #include "kernels.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -430,8 +431,9 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
   constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
   const int c_c4 = threadIdx.x % CF4, c_r = threadIdx.x / CF4;
-  const int n = n0 + c_c4 * 4;
-  if (n >= p.N) return;
+  const unsigned yseen = amax_peek(p.amax_y);
+  const bool act = n0 + c_c4 * 4 < p.N;          // threads past the last column only take part in the absmax reduction
+  const int n = act ? n0 + c_c4 * 4 : n0;
   // blockIdx.y selects one eighth of the tile's rows (more, shorter workgroups: the sum is latency
   // bound); every global operand of the thread's rows is requested before the first is consumed
   constexpr int RPB = BM / 8 / CROWS;          // rows per thread: 2 (BN = 128) or 1 (BN = 64)
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   for (int j = 0; j < RPB; ++j) {
     rows[j] = blockIdx.y * (BM / 8) + c_r + j * CROWS;
     const int m = m0 + rows[j];
-    ok[j] = m < p.M;
+    ok[j] = act && m < p.M;
     md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
     sum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.res) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
@@ -471,6 +473,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
       for (int j = 0; j < RPB; ++j) { sum[j].x += t[i][j].x; sum[j].y += t[i][j].y; sum[j].z += t[i][j].z; sum[j].w += t[i][j].w; }
     }
   }
+  unsigned ymax = 0;
 #pragma unroll
   for (int j = 0; j < RPB; ++j) {
     if (!ok[j]) continue;
@@ -485,7 +488,9 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
       v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
     }
     *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+    ymax = amax_f4(ymax, v);
   }
+  if (p.amax_y) amax_block_commit(ymax, p.amax_y, yseen);
 }
 
 static int env_int(const char* name, int dflt);
@@ -596,6 +601,66 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned out[3]) {
     if (p < 2) { a -= x6_lo(out[p]); b -= x6_hi(out[p]); }
   }
 }
+// ---- "f16x3": 2-way fp16 split, 3 partial products (NP = 2) ---------------------------------------------------------
+// a * s = h0 + h1 + e with h0 = rn16(a * s), h1 = rn16(a * s - h0): |e| <= 1 ulp of the fp32 value while h1 is a normal
+// fp16 number.  s is a power of two per operand TENSOR that puts the tensor's largest magnitude into [2^14, 2^15) (fp16
+// overflows at 65504); elements below 2^-16 of that maximum start to lose relative precision (h1 goes subnormal: absolute
+// error floor 2^-40 of the maximum -- the matrix cores keep fp16 subnormals).  The product drops h1a * h1b <= 2^-22 |ab|.
+// Half the MFMAs, a third less LDS traffic than bf16x6; measured on the bare GEMM loop 238-276 TFLOP/s against 163-188 and
+// a smaller error than bf16x6 on well-scaled data (tools/probes/f16x3_probe.cpp, profiles/r03_f16x3_probe.txt).
+// The scale comes from the absmax slots the engine maintains (uint bit patterns of max|x|, atomicMax'ed by absmax_kernel
+// or by the kernel that produced the tensor); a NaN / inf slot yields NaN outputs, as in the other modes.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned h3_pack(float e0, float e1) {          // v_cvt_pk_f16_f32, round to nearest even
+  f32x2v v = {e0, e1};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
+}
+__device__ __forceinline__ f32x2v h3_unpack(unsigned w) { return __builtin_convertvector(__builtin_bit_cast(f16x2v, w), f32x2v); }
+// scale 2^(141 - e) for a tensor whose absmax has the biased exponent e (largest magnitude -> [2^14, 2^15)), and 1 / scale.
+// `amax2`: optional second factor of the staged values (the per-channel norm scale of the data gradient).
+__device__ __forceinline__ float h3_scale(const unsigned* amax, const unsigned* amax2, float& inv) {
+  float m = __uint_as_float(*amax);
+  if (amax2) m *= __uint_as_float(*amax2);
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  int f = 268 - e;
+  f = f < 1 ? 1 : (f > 254 ? 254 : f);
+  inv = __uint_as_float((unsigned)(254 - f) << 23);
+  return __uint_as_float((unsigned)f << 23);
+}
+// four consecutive-k values -> NP pieces of 4 x 16 bit (8 bytes) each.  NP = 3: exact bf16 split (s unused); NP = 2: fp16.
+template <int NP>
+__device__ __forceinline__ void xs_split4(float a, float b, float c, float d, float s, uint2 (&out)[NP]) {
+  if (NP == 3) {
+    uint2 t[3];
+    x6_split4(a, b, c, d, t);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) out[p] = t[p];
+  } else {
+    a *= s; b *= s; c *= s; d *= s;
+    out[0].x = h3_pack(a, b);
+    out[0].y = h3_pack(c, d);
+    const f32x2v u0 = h3_unpack(out[0].x), u1 = h3_unpack(out[0].y);
+    out[NP - 1].x = h3_pack(a - u0.x, b - u0.y);
+    out[NP - 1].y = h3_pack(c - u1.x, d - u1.y);
+  }
+}
+template <int NP>
+__device__ __forceinline__ void xs_split2(float a, float b, float s, unsigned (&out)[NP]) {
+  if (NP == 3) {
+    unsigned t[3];
+    x6_split2(a, b, t);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) out[p] = t[p];
+  } else {
+    a *= s; b *= s;
+    out[0] = h3_pack(a, b);
+    const f32x2v u = h3_unpack(out[0]);
+    out[NP - 1] = h3_pack(a - u.x, b - u.y);
+  }
+}
 __device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 // LDS row of a K-major operand tile of width W <-> channel inside the tile
 __device__ __forceinline__ int x6_row_chan(int R, int W) { return 4 * (R % (W / 4)) + R / (W / 4); }
@@ -617,14 +682,14 @@ __device__ __forceinline__ int x6_kmaj_kq_64(int tid) { return ((tid >> 2) & 7) 
 // one 32-deep K step of a wave's (16*TM) x (16*TN) tile: 6*TM*TN MFMAs.  Fragments are taken MB x 2 at a time:
 // MB = TM reads every fragment once (3*(TM + TN) ds_read_b128); MB = 2 re-reads the B fragments per A pair
 // (3*(TM + TN*TM/2) reads) and keeps only 12 fragments live -- for the conv kernels, whose gather state needs the registers.
-template <int TM, int TN, int MB = TM>
+template <int TM, int TN, int MB = TM, int NP = 3>
 __device__ __forceinline__ void x6_mma_step(const unsigned char* As, const unsigned char* Bs, int a_rows, int b_rows, int a_row0,
                                             int b_row0, int r16, int q, f32x4 (&acc)[TM][TN]) {
 #pragma unroll
   for (int hm = 0; hm < TM; hm += MB) {
-    bf16x8 fa[MB][3];
+    bf16x8 fa[MB][NP];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int t = 0; t < MB; ++t)
         fa[t][p] = *reinterpret_cast<const bf16x8*>(As + (p * a_rows + a_row0 + (hm + t) * 16 + r16) * X6_ROWB + q * 16);
@@ -633,9 +698,9 @@ __device__ __forceinline__ void x6_mma_step(const unsigned char* As, const unsig
     if (MB != TM) asm volatile("" : "+v"(boff));
 #pragma unroll
     for (int hn = 0; hn < TN; hn += 2) {
-      bf16x8 fb[2][3];
+      bf16x8 fb[2][NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           fb[t][p] = *reinterpret_cast<const bf16x8*>(Bs + boff + (p * b_rows + (hn + t) * 16) * X6_ROWB);
@@ -644,25 +709,32 @@ __device__ __forceinline__ void x6_mma_step(const unsigned char* As, const unsig
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
           f32x4 c = acc[hm + tm][hn + tn];
-          c = MFMA_BF16(fa[tm][2], fb[tn][0], c);            // smallest terms first
-          c = MFMA_BF16(fa[tm][0], fb[tn][2], c);
-          c = MFMA_BF16(fa[tm][1], fb[tn][1], c);
-          c = MFMA_BF16(fa[tm][1], fb[tn][0], c);
-          c = MFMA_BF16(fa[tm][0], fb[tn][1], c);
-          c = MFMA_BF16(fa[tm][0], fb[tn][0], c);
+          if (NP == 3) {
+            c = MFMA_BF16(fa[tm][NP - 1], fb[tn][0], c);            // smallest terms first
+            c = MFMA_BF16(fa[tm][0], fb[tn][NP - 1], c);
+            c = MFMA_BF16(fa[tm][1], fb[tn][1], c);
+            c = MFMA_BF16(fa[tm][1], fb[tn][0], c);
+            c = MFMA_BF16(fa[tm][0], fb[tn][1], c);
+            c = MFMA_BF16(fa[tm][0], fb[tn][0], c);
+          } else {
+            c = MFMA_F16(__builtin_bit_cast(f16x8, fa[tm][1]), __builtin_bit_cast(f16x8, fb[tn][0]), c);
+            c = MFMA_F16(__builtin_bit_cast(f16x8, fa[tm][0]), __builtin_bit_cast(f16x8, fb[tn][1]), c);
+            c = MFMA_F16(__builtin_bit_cast(f16x8, fa[tm][0]), __builtin_bit_cast(f16x8, fb[tn][0]), c);
+          }
           acc[hm + tm][hn + tn] = c;
         }
     }
   }
 }
 
-template <int BN, bool KMAJOR>
-__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
+constexpr int xs_max(int a, int b) { return a > b ? a : b; }
+// LDS of a conv workgroup: NP operand planes, or the C tile that the epilogue stages through the same bytes
+template <int BN, int NP> constexpr int conv_xs_smem() { return xs_max(NP * (128 + BN) * X6_ROWB, 128 * (BN + 4) * 4); }
+template <int BN, bool KMAJOR, int NP>
+__device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* smem) {
   constexpr int BM = 128, BK = 32;
-  constexpr int A_BYTES = 3 * BM * X6_ROWB, B_BYTES = 3 * BN * X6_ROWB, SMEM = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = NP * BM * X6_ROWB;
   constexpr int LDC = BN + 4;
-  static_assert(BM * LDC * 4 <= SMEM, "the C tile is staged through the operand buffers");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   unsigned char* const As = smem;
   unsigned char* const Bs = smem + A_BYTES;
 
@@ -696,7 +768,16 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   constexpr int TN = BN / 32;                            // 16-column fragments per wave
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (p.plane_rows ? (long)p.nplanes : 1L) * p.wN * T * p.wK * 4);
+  float sa = 1.f, sb = 1.f, inv_ab = 1.f;
+  if (NP == 2) {
+    float ia, ib;
+    sa = h3_scale(p.amax_x, KMAJOR ? p.amax_ks : nullptr, ia);
+    sb = h3_scale(p.amax_w, nullptr, ib);
+    inv_ab = ia * ib;
+  }
 
+  unsigned ymax = 0;           // f16x3: absmax of what this workgroup writes (-> p.amax_y)
+  const unsigned yseen = NP == 2 ? amax_peek(p.amax_y) : 0u;
   for (long u = u_begin;;) {
     int tile, ks_begin, ks_end = ksteps;
     const bool dp = dp_i < p.dp_q;
@@ -811,34 +892,34 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     auto store_tiles = [&]() {
 #pragma unroll
       for (int i = 0; i < APASS; ++i) {
-        uint2 pc[3];
-        x6_split4(ra[i].x, ra[i].y, ra[i].z, ra[i].w, pc);
+        uint2 pc[NP];
+        xs_split4<NP>(ra[i].x, ra[i].y, ra[i].z, ra[i].w, sa, pc);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(As + (q * BM + a_r + i * 32) * X6_ROWB + a_c4 * 8) = pc[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(As + (q * BM + a_r + i * 32) * X6_ROWB + a_c4 * 8) = pc[q];
       }
       if (!KMAJOR) {
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
-          uint2 pc[3];
-          x6_split4(rb[i].x, rb[i].y, rb[i].z, rb[i].w, pc);
+          uint2 pc[NP];
+          xs_split4<NP>(rb[i].x, rb[i].y, rb[i].z, rb[i].w, sb, pc);
 #pragma unroll
-          for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(Bs + (q * BN + b_r + i * 32) * X6_ROWB + b_c4 * 8) = pc[q];
+          for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Bs + (q * BN + b_r + i * 32) * X6_ROWB + b_c4 * 8) = pc[q];
         }
       } else if (RPT == 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {            // column 4*n4 + j of the tile lives in LDS row j*NQ + n4
-          uint2 pc[3];
-          x6_split4(f4c(rb[0], j), f4c(rb[1], j), f4c(rb[RPT == 4 ? 2 : 0], j), f4c(rb[RPT == 4 ? 3 : 0], j), pc);
+          uint2 pc[NP];
+          xs_split4<NP>(f4c(rb[0], j), f4c(rb[1], j), f4c(rb[RPT == 4 ? 2 : 0], j), f4c(rb[RPT == 4 ? 3 : 0], j), sb, pc);
 #pragma unroll
-          for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(Bs + (q * BN + j * NQ + b_n4) * X6_ROWB + b_kq * 8) = pc[q];
+          for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(Bs + (q * BN + j * NQ + b_n4) * X6_ROWB + b_kq * 8) = pc[q];
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          unsigned pc[3];
-          x6_split2(f4c(rb[0], j), f4c(rb[1], j), pc);
+          unsigned pc[NP];
+          xs_split2<NP>(f4c(rb[0], j), f4c(rb[1], j), sb, pc);
 #pragma unroll
-          for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned*>(Bs + (q * BN + j * NQ + b_n4) * X6_ROWB + b_kq * 4) = pc[q];
+          for (int q = 0; q < NP; ++q) *reinterpret_cast<unsigned*>(Bs + (q * BN + j * NQ + b_n4) * X6_ROWB + b_kq * 4) = pc[q];
         }
       }
     };
@@ -861,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
       const bool more = (ks + 1) < ks_end;
       if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
       __builtin_amdgcn_s_setprio(1);
-      x6_mma_step<TM, TN, (BN == 128 ? 2 : TM)>(As, Bs, BM, BN, wm * 64, wn * (BN / 2), fr, fq, acc);
+      x6_mma_step<TM, TN, (BN == 128 ? 2 : TM), NP>(As, Bs, BM, BN, wm * 64, wn * (BN / 2), fr, fq, acc);
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();                       // every wave is done reading the stage
       if (more) store_tiles();
@@ -889,7 +970,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
           const int Rb = wn * (BN / 2) + tn * 16 + fr;
           const int ncol = KMAJOR ? x6_row_chan(Rb, BN) : Rb;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) Cs[(wm * 64 + tm * 16 + 4 * fq + e) * LDC + ncol] = acc[tm][tn][e];
+          for (int e = 0; e < 4; ++e) Cs[(wm * 64 + tm * 16 + 4 * fq + e) * LDC + ncol] = NP == 2 ? acc[tm][tn][e] * inv_ab : acc[tm][tn][e];
         }
       __syncthreads();
       if (full) {
@@ -930,7 +1011,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
                 v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
                 v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
               }
-              if (ok[j]) *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+              if (ok[j]) {
+                *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+                if (NP == 2) ymax = amax_f4(ymax, v);
+              }
             }
           }
         }
@@ -943,15 +1027,27 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     }
     if (!dp) u += ks_end - ks_begin;
   }
+  if (NP == 2 && p.amax_y) amax_block_commit(ymax, p.amax_y, yseen);
+}
+
+template <int BN, bool KMAJOR>
+__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[conv_xs_smem<BN, 3>()];
+  conv_xs_body<BN, KMAJOR, 3>(p, smem);
+}
+template <int BN, bool KMAJOR>
+__global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[conv_xs_smem<BN, 2>()];
+  conv_xs_body<BN, KMAJOR, 2>(p, smem);
 }
 
 // Weight gradient on the bf16 matrix cores: same split, both operands K-major (a pixel's channels are contiguous).
-template <int BMO, int BNI>
+template <int BMO, int BNI, int NP> constexpr int wgrad_xs_smem() { return xs_max(NP * (BMO + BNI) * X6_ROWB, BMO * (BNI + 4) * 4); }
+template <int BMO, int BNI, int NP = 3>
 __device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid, unsigned char* smem) {
   constexpr int BKP = 32;
-  constexpr int A_BYTES = 3 * BMO * X6_ROWB, B_BYTES = 3 * BNI * X6_ROWB, SMEM = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = NP * BMO * X6_ROWB;
   constexpr int LDC = BNI + 4;
-  static_assert(BMO * LDC * 4 <= SMEM, "the C tile is staged through the operand buffers");
   unsigned char* const As = smem;
   unsigned char* const Bs = smem + A_BYTES;
 
@@ -994,6 +1090,13 @@ __device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid,
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.g + tap * p.g_tap_stride, (long)p.B * p.Ho * p.Wo * p.ldg * 4);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + tap * p.x_tap_stride, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
+  float sa = 1.f, sb = 1.f, inv_ab = 1.f;
+  if (NP == 2) {
+    float ia, ib;
+    sa = h3_scale(p.amax_g, nullptr, ia);
+    sb = h3_scale(p.amax_x, nullptr, ib);
+    inv_ab = ia * ib;
+  }
   const int hw = hv * wv > 0 ? hv * wv : 1, wv1 = wv > 0 ? wv : 1;
   const float inv_hw = 1.0f / (float)hw, inv_wv = 1.0f / (float)wv1;
   // contributing pixel q -> (image, row, column) of the rectangle; q < 2^24, so one float multiply +- 1 is exact
@@ -1045,19 +1148,19 @@ __device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid,
       }
     }
   };
-  auto store_op = [&](unsigned char* S, const float4* rv, int W, int NQ_, int RPT_, int c4, int kq) {
+  auto store_op = [&](unsigned char* S, const float4* rv, int W, int NQ_, int RPT_, int c4, int kq, float sc) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {              // channel 4*c4 + j of the tile lives in LDS row j*NQ + c4
       if (RPT_ == 4) {
-        uint2 pc[3];
-        x6_split4(f4c(rv[0], j), f4c(rv[1], j), f4c(rv[RPT_ == 4 ? 2 : 0], j), f4c(rv[RPT_ == 4 ? 3 : 0], j), pc);
+        uint2 pc[NP];
+        xs_split4<NP>(f4c(rv[0], j), f4c(rv[1], j), f4c(rv[RPT_ == 4 ? 2 : 0], j), f4c(rv[RPT_ == 4 ? 3 : 0], j), sc, pc);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(S + (q * W + j * NQ_ + c4) * X6_ROWB + kq * 8) = pc[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(S + (q * W + j * NQ_ + c4) * X6_ROWB + kq * 8) = pc[q];
       } else {
-        unsigned pc[3];
-        x6_split2(f4c(rv[0], j), f4c(rv[1], j), pc);
+        unsigned pc[NP];
+        xs_split2<NP>(f4c(rv[0], j), f4c(rv[1], j), sc, pc);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned*>(S + (q * W + j * NQ_ + c4) * X6_ROWB + kq * 4) = pc[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<unsigned*>(S + (q * W + j * NQ_ + c4) * X6_ROWB + kq * 4) = pc[q];
       }
     }
   };
@@ -1073,20 +1176,20 @@ __device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid,
 
   if (st_begin < st_end) {
     load_tiles(st_begin);
-    store_op(As, ra, BMO, ANQ, ARPT, a_c4, a_kq);
-    store_op(Bs, rb, BNI, BNQ, BRPT, b_c4, b_kq);
+    store_op(As, ra, BMO, ANQ, ARPT, a_c4, a_kq, sa);
+    store_op(Bs, rb, BNI, BNQ, BRPT, b_c4, b_kq, sb);
   }
   __syncthreads();
   for (int st = st_begin; st < st_end; ++st) {
     const bool more = (st + 1) < st_end;
     if (more) load_tiles(st + 1);
     __builtin_amdgcn_s_setprio(1);
-    x6_mma_step<TM, TN>(As, Bs, BMO, BNI, wm * (BMO / 2), wn * (BNI / 2), fr, fq, acc);
+    x6_mma_step<TM, TN, TM, NP>(As, Bs, BMO, BNI, wm * (BMO / 2), wn * (BNI / 2), fr, fq, acc);
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (more) {
-      store_op(As, ra, BMO, ANQ, ARPT, a_c4, a_kq);
-      store_op(Bs, rb, BNI, BNQ, BRPT, b_c4, b_kq);
+      store_op(As, ra, BMO, ANQ, ARPT, a_c4, a_kq, sa);
+      store_op(Bs, rb, BNI, BNQ, BRPT, b_c4, b_kq, sb);
     }
     __syncthreads();
   }
@@ -1106,7 +1209,7 @@ __device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ch = x6_row_chan(wm * (BMO / 2) + tm * 16 + 4 * fq + e, BMO);
-        Cs[ch * LDC + ncol] = acc[tm][tn][e];
+        Cs[ch * LDC + ncol] = NP == 2 ? acc[tm][tn][e] * inv_ab : acc[tm][tn][e];
       }
     }
   __syncthreads();
@@ -1123,19 +1226,90 @@ __device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid,
 
 template <int BMO, int BNI>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (BMO + BNI) * X6_ROWB];
-  wgrad_x6_body<BMO, BNI>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_xs_smem<BMO, BNI, 3>()];
+  wgrad_x6_body<BMO, BNI, 3>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+template <int BMO, int BNI>
+__global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_xs_smem<BMO, BNI, 2>()];
+  wgrad_x6_body<BMO, BNI, 2>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 // Several weight gradients in one launch (the independent GEMMs of a ResNet stage): workgroup w works on entry
 // map[w].x of the table as its workgroup map[w].y.  Grouped, the small layers fill the chip with a few K splits each
 // instead of 30-240 (fewer parked slabs, no per-launch tails).
 template <int BMO, int BNI>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_group_kernel(const WgradArgs* __restrict__ tab, const int2* __restrict__ map) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (BMO + BNI) * X6_ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_xs_smem<BMO, BNI, 3>()];
   const int2 m = map[xcd_remap(blockIdx.x, gridDim.x)];
   const int ent = __builtin_amdgcn_readfirstlane(m.x), bid = __builtin_amdgcn_readfirstlane(m.y);
   const WgradArgs p = tab[ent];
-  wgrad_x6_body<BMO, BNI>(p, bid, smem);
+  wgrad_x6_body<BMO, BNI, 3>(p, bid, smem);
+}
+template <int BMO, int BNI>
+__global__ __launch_bounds__(256, 2) void wgrad_h3_group_kernel(const WgradArgs* __restrict__ tab, const int2* __restrict__ map) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_xs_smem<BMO, BNI, 2>()];
+  const int2 m = map[xcd_remap(blockIdx.x, gridDim.x)];
+  const int ent = __builtin_amdgcn_readfirstlane(m.x), bid = __builtin_amdgcn_readfirstlane(m.y);
+  const WgradArgs p = tab[ent];
+  wgrad_x6_body<BMO, BNI, 2>(p, bid, smem);
+}
+
+// max|x| of a [rows x C] view (row pitch ld floats) -> atomicMax of the bit pattern (|x| compares like an unsigned
+// integer; a NaN compares above every number and so survives).  HBM-bound: one read of the view.
+__device__ __forceinline__ unsigned absmax4(const float4& v, unsigned m) { return amax_f4(m, v); }
+__device__ __forceinline__ void absmax_finish(unsigned m, unsigned* slot) { amax_block_commit(m, slot); }
+// dense view: n4 float4 in a row
+__global__ __launch_bounds__(256) void absmax_flat_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ slot) {
+  unsigned m = 0;
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 v0 = x[i], v1 = x[i + stride], v2 = x[i + 2 * stride], v3 = x[i + 3 * stride];
+    m = absmax4(v0, m); m = absmax4(v1, m); m = absmax4(v2, m); m = absmax4(v3, m);
+  }
+  for (; i < n4; i += stride) m = absmax4(x[i], m);
+  absmax_finish(m, slot);
+}
+// strided view: 2^txs threads walk the C4 float4 of a row, 256 >> txs rows per workgroup pass
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, int rows, int C4, int ld, int txs,
+                                                          unsigned* __restrict__ slot) {
+  const int tx = 1 << txs, col = threadIdx.x & (tx - 1), rl = threadIdx.x >> txs, rp = 256 >> txs;
+  unsigned m = 0;
+  for (int r = blockIdx.x * rp + rl; r < rows; r += gridDim.x * rp) {
+    const float* row = x + (size_t)r * ld;
+    for (int c = col; c < C4; c += tx) m = absmax4(ldg4(row + c * 4), m);
+  }
+  absmax_finish(m, slot);
+}
+void launch_absmax(const float* x, long rows, int C, int ld, unsigned* slot, hipStream_t s) {
+  const int C4 = C / 4;
+  if (ld == C || rows == 1) {
+    const long n4 = rows * C4;
+    long g = (n4 + 256 * 8 - 1) / (256 * 8);
+    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    hipLaunchKernelGGL(absmax_flat_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4, slot);
+    return;
+  }
+  int txs = 0;
+  while ((1 << txs) < C4 && txs < 8) ++txs;
+  const int rp = 256 >> txs;
+  long g = (rows + (long)rp * 4 - 1) / ((long)rp * 4);
+  g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (int)rows, C4, ld, txs, slot);
+}
+// one launch for many dense tensors (the weights): segment blockIdx.y = floats [off[y], off[y] + n[y]) of base
+__global__ __launch_bounds__(256) void absmax_segments_kernel(const float* __restrict__ base, const long* __restrict__ off,
+                                                              const int* __restrict__ n, unsigned* __restrict__ slots) {
+  const int y = blockIdx.y;
+  const int n4 = n[y] >> 2;
+  if (n4 <= 0) return;
+  const float4* x = reinterpret_cast<const float4*>(base + off[y]);
+  unsigned m = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) m = absmax4(x[i], m);
+  absmax_finish(m, slots + y);
+}
+void launch_absmax_segments(const float* base, const long* dev_off, const int* dev_n, int nseg, unsigned* slots, hipStream_t s) {
+  hipLaunchKernelGGL(absmax_segments_kernel, dim3(64, (unsigned)nseg), dim3(256), 0, s, base, dev_off, dev_n, slots);
 }
 
 // EOSVOS_MFMA=f32 selects the fp32-MFMA kernels (A/B and fallback); default: bf16x6
@@ -1147,11 +1321,11 @@ static int g_mfma_mode = -1;
 int conv_mfma_mode() {
   if (g_mfma_mode < 0) {
     const char* v = getenv("EOSVOS_MFMA");
-    g_mfma_mode = (v && v[0] == 'f') ? 0 : 1;
+    g_mfma_mode = (v && !strcmp(v, "f32")) ? 0 : (v && !strcmp(v, "f16x3")) ? 2 : 1;
   }
   return g_mfma_mode;
 }
-void conv_set_mfma_mode(int mode) { g_mfma_mode = mode ? 1 : 0; }
+void conv_set_mfma_mode(int mode) { g_mfma_mode = mode == 2 ? 2 : (mode ? 1 : 0); }
 
 
 // ---------------------------------------------------------------------------------------
@@ -1169,7 +1343,10 @@ const char* const kProfNames[] = {
     "conv_igemm_kernel<128, false, *>", "conv_igemm_kernel<128, true, *>", "conv_igemm_kernel<64, false, 0>", "conv_igemm_kernel<64, true, 0>",
     "wgrad_kernel<128, 128>", "wgrad_kernel<128, 64>", "wgrad_kernel<64, 128>", "wgrad_kernel<64, 64>",
     "conv_fixup_kernel",
-    "wgrad_x6_group_kernel<128, 128>", "wgrad_x6_group_kernel<128, 64>", "wgrad_x6_group_kernel<64, 128>", "wgrad_x6_group_kernel<64, 64>"};
+    "wgrad_x6_group_kernel<128, 128>", "wgrad_x6_group_kernel<128, 64>", "wgrad_x6_group_kernel<64, 128>", "wgrad_x6_group_kernel<64, 64>",
+    "conv_h3_kernel<128, false>", "conv_h3_kernel<128, true>", "conv_h3_kernel<64, false>", "conv_h3_kernel<64, true>",
+    "wgrad_h3_kernel<128, 128>", "wgrad_h3_kernel<128, 64>", "wgrad_h3_kernel<64, 128>", "wgrad_h3_kernel<64, 64>",
+    "wgrad_h3_group_kernel<128, 128>", "wgrad_h3_group_kernel<128, 64>", "wgrad_h3_group_kernel<64, 128>", "wgrad_h3_group_kernel<64, 64>"};
 constexpr int kProfKernels = sizeof(kProfNames) / sizeof(kProfNames[0]);
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -1257,7 +1434,7 @@ int conv_plan(ConvArgs& a) {
   const int T = a.KH * a.KW;
   long ksteps = (long)T * ((a.Kc + EOSVOS_BK - 1) / EOSVOS_BK);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
-  const bool x6 = conv_mfma_mode() == 1;
+  const bool x6 = conv_mfma_mode() >= 1;
 #ifndef EOSVOS_NO_DEEP
   // 3-workgroups-per-CU kernel for long-K layers with many tiles (measured: decoder 3x3 fwd/dgrad at batch >= 2)
 #ifndef EOSVOS_DEEP_BATCHED
@@ -1305,10 +1482,19 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const int nwg = conv_plan(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   const dim3 grid(nwg), block(256);
-  const int pk = (conv_mfma_mode() == 1 ? 0 : 8) + (bn == 128 ? 0 : 2) + (a.kmajor ? 1 : 0);
+  const int mode = conv_mfma_mode();
+  const int pk = (mode == 2 ? 21 : mode == 1 ? 0 : 8) + (bn == 128 ? 0 : 2) + (a.kmajor ? 1 : 0);
   {
   ProfScope ps(pk, 2.0 * a.M * a.N * a.KH * a.KW * a.Kc * conv_exec_frac(a), s);
-  if (conv_mfma_mode() == 1) {
+  if (mode == 2) {
+    if (a.kmajor) {
+      if (bn == 128) hipLaunchKernelGGL((conv_h3_kernel<128, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv_h3_kernel<64, true>), grid, block, 0, s, a);
+    } else {
+      if (bn == 128) hipLaunchKernelGGL((conv_h3_kernel<128, false>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv_h3_kernel<64, false>), grid, block, 0, s, a);
+    }
+  } else if (mode == 1) {
     if (a.kmajor) {
       if (bn == 128) hipLaunchKernelGGL((conv_x6_kernel<128, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((conv_x6_kernel<64, true>), grid, block, 0, s, a);
@@ -1548,7 +1734,15 @@ int wgrad_group_tile(int channels) { return wg_tile(channels); }
 void launch_wgrad_group(const WgradArgs* dev_tab, const int* dev_map, int nwg, int bm, int bn, double flops, hipStream_t s) {
   const dim3 grid(nwg), block(256);
   const int2* map = reinterpret_cast<const int2*>(dev_map);
-  ProfScope ps(17 + (bm == 128 ? 0 : 2) + (bn == 128 ? 0 : 1), flops, s);
+  const bool h3 = conv_mfma_mode() == 2;
+  ProfScope ps((h3 ? 29 : 17) + (bm == 128 ? 0 : 2) + (bn == 128 ? 0 : 1), flops, s);
+  if (h3) {
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_h3_group_kernel<128, 128>), grid, block, 0, s, dev_tab, map);
+    else if (bm == 128) hipLaunchKernelGGL((wgrad_h3_group_kernel<128, 64>), grid, block, 0, s, dev_tab, map);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_h3_group_kernel<64, 128>), grid, block, 0, s, dev_tab, map);
+    else hipLaunchKernelGGL((wgrad_h3_group_kernel<64, 64>), grid, block, 0, s, dev_tab, map);
+    return;
+  }
   if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_x6_group_kernel<128, 128>), grid, block, 0, s, dev_tab, map);
   else if (bm == 128) hipLaunchKernelGGL((wgrad_x6_group_kernel<128, 64>), grid, block, 0, s, dev_tab, map);
   else if (bn == 128) hipLaunchKernelGGL((wgrad_x6_group_kernel<64, 128>), grid, block, 0, s, dev_tab, map);
@@ -1562,9 +1756,17 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
   const int T = a.KH * a.KW;
   const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * T;
   const dim3 grid(tiles * a.splits), block(256);
-  ProfScope ps((conv_mfma_mode() == 1 ? 4 : 12) + (bm == 128 ? 0 : 2) + (bn == 128 ? 0 : 1),
+  const int mode = conv_mfma_mode();
+  ProfScope ps((mode == 2 ? 25 : mode == 1 ? 4 : 12) + (bm == 128 ? 0 : 2) + (bn == 128 ? 0 : 1),
                2.0 * a.Cout * a.Cin * T * (double)P * wgrad_exec_frac(a), s);
-  if (conv_mfma_mode() == 1) {
+  if (mode == 2) {
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_h3_kernel<128, 128>), grid, block, 0, s, a);
+    else if (bm == 128) hipLaunchKernelGGL((wgrad_h3_kernel<128, 64>), grid, block, 0, s, a);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_h3_kernel<64, 128>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad_h3_kernel<64, 64>), grid, block, 0, s, a);
+    return;
+  }
+  if (mode == 1) {
     if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_x6_kernel<128, 128>), grid, block, 0, s, a);
     else if (bm == 128) hipLaunchKernelGGL((wgrad_x6_kernel<128, 64>), grid, block, 0, s, a);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128>), grid, block, 0, s, a);

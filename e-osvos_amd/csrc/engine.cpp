@@ -249,6 +249,23 @@ struct eosvos_engine {
   int force_algo = 0;                 // EOSVOS_ALGO_*: 0 = plan by work size; the op-level parity tests force one path
   int wg_budget = 0;                  // eosvos_set_wg_budget: workgroups a launch plans for (0 = the whole chip)
 
+  // f16x3 matrix mode: absmax slots (bit patterns of max|x|), kind-major [AM_KINDS][nconv]; see amax_get()
+  unsigned* amax = nullptr;
+  struct AmaxRec { const void* ptr = nullptr; long epoch = -1, zero_epoch = -1; };
+  std::vector<AmaxRec> amax_rec;
+  long fwd_epoch = 0, bwd_epoch = 0;
+  bool w_amax_valid = false;         // W slots match the current weights
+  long us_zero_epoch = -1;           // forward epoch whose start zeroed the U / US slots of the stale Winograd weights
+  long* amax_w_off = nullptr;        // device tables of launch_absmax_segments over the parameter arena
+  int* amax_w_n = nullptr;
+  std::vector<char> ks_amax_valid;   // KS slots match the current norm scales
+  // tensor slots: absmax accumulated by the kernels that WRITE a tensor (conv epilogue, fix-up, Winograd output
+  // transforms); phase 0 = activations of this forward, phase 1 = gradients of this backward.  `valid`: the last
+  // writer that covered the whole tensor, and every writer since, had the fused absmax -- only then a consumer trusts it
+  struct TRec { int idx; bool valid; };
+  std::map<const float*, TRec> treg[2];
+  static constexpr int TSLOTS = 384;   // per phase
+
   int64_t max_alloc_floats = 0;      // largest single allocation (every conv operand is one of them)
   // EOSVOS_DEBUG_GUARD=1: every buffer sits between two 256 KB guard bands filled with a pattern;
   // eosvos_debug_check_guards reports bands a kernel wrote into (out-of-bounds writes)
@@ -285,6 +302,147 @@ namespace {
 // the weights changed: the scaled Winograd weights a[cout] * U of the last forward are stale
 void wino_weights_changed(eosvos_engine* e) {
   for (auto& kv : e->wino_us_valid) kv.second = 0;
+  e->w_amax_valid = false;
+}
+
+// ---- f16x3 mode: per-tensor absmax slots ---------------------------------------------------------------------------
+// The fp16 split needs a power-of-two scale per operand tensor (conv_kernels.hip, h3_scale); the kernels read it from a
+// device word that holds the bit pattern of max|x|.  Slots, per conv: X input activation (made by the forward pass, reused
+// by the weight gradient), V its Winograd-domain planes, G gradient w.r.t. the conv output (shared by the data and the
+// weight gradient), DM its Winograd-domain planes, W weights, U / US Winograd-domain weights, KS the frozen-norm scale
+// that the data gradient multiplies into G while staging.  X / V live for one forward epoch, G / DM for one backward
+// epoch; W / U / US / KS until the weights / norm change.
+bool trace_on();
+enum { AM_X = 0, AM_V = 1, AM_G = 2, AM_DM = 3, AM_W = 4, AM_U = 5, AM_US = 6, AM_KS = 7, AM_KINDS = 8 };
+inline bool h3_mode() { return conv_mfma_mode() == 2; }
+int amax_init(eosvos_engine* e) {
+  if (e->amax) return 0;
+  const size_t n = (size_t)AM_KINDS * e->t.convs.size() + 2 * eosvos_engine::TSLOTS;
+  e->amax = (unsigned*)e->falloc((int64_t)n);
+  if (!e->amax) return 1;
+  (void)hipMemsetAsync(e->amax, 0, n * 4, e->s);
+  e->amax_rec.assign((size_t)AM_KINDS * e->t.convs.size(), eosvos_engine::AmaxRec());
+  e->ks_amax_valid.assign(e->t.convs.size(), 0);
+  return 0;
+}
+inline unsigned* amax_slot(eosvos_engine* e, int kind, int ci) { return e->amax + (size_t)kind * e->t.convs.size() + ci; }
+// slot of the tensor that starts at `key` (phase 0: activation, 1: gradient); nullptr when the table is full
+unsigned* tslot(eosvos_engine* e, int phase, const float* key) {
+  auto& reg = e->treg[phase];
+  auto it = reg.find(key);
+  if (it == reg.end()) {
+    if ((int)reg.size() >= eosvos_engine::TSLOTS) return nullptr;
+    it = reg.emplace(key, eosvos_engine::TRec{(int)reg.size(), false}).first;
+  }
+  return e->amax + (size_t)AM_KINDS * e->t.convs.size() + (size_t)phase * eosvos_engine::TSLOTS + it->second.idx;
+}
+// a kernel with the fused absmax is about to write the tensor at `key` (full = every element): returns the slot to pass
+unsigned* twrite_fused(eosvos_engine* e, int phase, const float* key, bool full) {
+  if (!h3_mode() || amax_init(e)) return nullptr;
+  unsigned* sl = tslot(e, phase, key);
+  if (sl && full) e->treg[phase][key].valid = true;
+  return sl;
+}
+// a kernel WITHOUT the fused absmax writes into the tensor at `key`
+void twrite_plain(eosvos_engine* e, int phase, const float* key) {
+  if (!h3_mode()) return;
+  auto it = e->treg[phase].find(key);
+  if (it != e->treg[phase].end()) it->second.valid = false;
+}
+// every writer of the tensor since the phase began went into its slot (the caller has checked that)
+void tmark_valid(eosvos_engine* e, int phase, const float* key) {
+  auto it = e->treg[phase].find(key);
+  if (it != e->treg[phase].end()) it->second.valid = true;
+}
+// consumer: the tensor's slot if it can be trusted
+const unsigned* tlookup(eosvos_engine* e, int phase, const float* key) {
+  auto it = e->treg[phase].find(key);
+  if (it == e->treg[phase].end() || !it->second.valid) return nullptr;
+  return e->amax + (size_t)AM_KINDS * e->t.convs.size() + (size_t)phase * eosvos_engine::TSLOTS + it->second.idx;
+}
+// a new forward (phase 0) / backward (phase 1) epoch: its slots are zeroed in one memset
+void amax_new_phase(eosvos_engine* e, int phase) {
+  if (!h3_mode() || amax_init(e)) return;
+  const size_t nc = e->t.convs.size();
+  long& ep = phase == 0 ? e->fwd_epoch : e->bwd_epoch;
+  ++ep;
+  const int k0 = phase == 0 ? AM_X : AM_G;
+  (void)hipMemsetAsync(e->amax + k0 * nc, 0, 2 * nc * 4, e->s);
+  for (size_t i = k0 * nc; i < (k0 + 2) * nc; ++i) e->amax_rec[i].zero_epoch = ep;
+  (void)hipMemsetAsync(e->amax + AM_KINDS * nc + (size_t)phase * eosvos_engine::TSLOTS, 0, eosvos_engine::TSLOTS * 4, e->s);
+  for (auto& kv : e->treg[phase]) kv.second.valid = false;
+}
+// absmax of the [rows x C] view at `ptr` into slot (kind, ci) -- computed once per epoch and view
+const unsigned* amax_get(eosvos_engine* e, int kind, int ci, const float* ptr, long rows, int C, int ld, hipStream_t st) {
+  if (amax_init(e)) return nullptr;
+  const long ep = (kind == AM_X || kind == AM_V) ? e->fwd_epoch : e->bwd_epoch;
+  unsigned* slot = amax_slot(e, kind, ci);
+  auto& r = e->amax_rec[slot - e->amax];
+  if (r.epoch == ep && r.ptr == ptr) return slot;
+  if (trace_on()) fprintf(stderr, "EOSVOS_AMAX kind=%d conv=%d rows=%ld C=%d ld=%d memset=%d\n", kind, ci, rows, C, ld, (int)(r.zero_epoch != ep));
+  if (r.zero_epoch != ep) (void)hipMemsetAsync(slot, 0, 4, st);      // not covered by the epoch's bulk zeroing, or used since
+  launch_absmax(ptr, rows, C, ld, slot, st);
+  r.epoch = ep; r.zero_epoch = -1; r.ptr = ptr;
+  return slot;
+}
+// slot (kind, ci) is about to be filled by the kernel that writes the tensor at `ptr` (V, DM: the Winograd transforms)
+unsigned* amax_fused_slot(eosvos_engine* e, int kind, int ci, const float* ptr, hipStream_t st) {
+  if (!h3_mode() || amax_init(e)) return nullptr;
+  const long ep = (kind == AM_X || kind == AM_V) ? e->fwd_epoch : e->bwd_epoch;
+  unsigned* slot = amax_slot(e, kind, ci);
+  auto& r = e->amax_rec[slot - e->amax];
+  if (r.zero_epoch != ep) (void)hipMemsetAsync(slot, 0, 4, st);
+  r.epoch = ep; r.zero_epoch = -1; r.ptr = ptr;
+  return slot;
+}
+// a slot that lives until the weights / the norm change (W, U, US, KS): the caller tracks validity
+const unsigned* amax_make(eosvos_engine* e, int kind, int ci, const float* ptr, long rows, int C, int ld, hipStream_t st) {
+  if (amax_init(e)) return nullptr;
+  unsigned* slot = amax_slot(e, kind, ci);
+  (void)hipMemsetAsync(slot, 0, 4, st);
+  launch_absmax(ptr, rows, C, ld, slot, st);
+  return slot;
+}
+// W slots of every conv (one pass over the parameter arena), on stream st
+void amax_weights(eosvos_engine* e, hipStream_t st) {
+  if (e->w_amax_valid || amax_init(e)) return;
+  const size_t nc = e->t.convs.size();
+  if (!e->amax_w_off) {
+    std::vector<long> off(nc);
+    std::vector<int> n(nc);
+    for (size_t ci = 0; ci < nc; ++ci) {
+      const ConvL& c = e->t.convs[ci];
+      off[ci] = (long)c.poff;
+      n[ci] = ((c.cin & 3) || (c.poff & 3)) ? 0 : (int)c.wsize();      // the stem (cin 3) has its own kernels
+    }
+    e->amax_w_off = (long*)e->falloc((int64_t)nc * 2);
+    e->amax_w_n = (int*)e->falloc((int64_t)nc);
+    if (!e->amax_w_off || !e->amax_w_n) return;
+    (void)hipMemcpy(e->amax_w_off, off.data(), nc * sizeof(long), hipMemcpyHostToDevice);
+    (void)hipMemcpy(e->amax_w_n, n.data(), nc * sizeof(int), hipMemcpyHostToDevice);
+  }
+  (void)hipMemsetAsync(e->amax + AM_W * nc, 0, nc * 4, st);
+  launch_absmax_segments(e->Wp, e->amax_w_off, e->amax_w_n, (int)nc, e->amax + AM_W * nc, st);
+  e->w_amax_valid = true;
+}
+const unsigned* amax_ks(eosvos_engine* e, int ci, hipStream_t st) {
+  if (amax_init(e) || !e->A_(ci)) return nullptr;
+  if (!e->ks_amax_valid[ci]) {
+    amax_make(e, AM_KS, ci, e->A_(ci), 1, e->t.convs[ci].cout, e->t.convs[ci].cout, st);
+    e->ks_amax_valid[ci] = 1;
+  }
+  return amax_slot(e, AM_KS, ci);
+}
+// Winograd-domain weights are about to be (re)made on stream st: zeroes the U and US slots (adjacent kinds), which the
+// transform kernel then fills; returns the U slot (US = U slot + nconv), nullptr outside the f16x3 mode
+unsigned* amax_wino_weights(eosvos_engine* e, int ci, hipStream_t st) {
+  if (!h3_mode() || amax_init(e)) return nullptr;
+  unsigned* u = amax_slot(e, AM_U, ci);
+  if (e->us_zero_epoch != e->fwd_epoch) {          // else: forward_impl zeroed every U / US slot of this epoch at once
+    (void)hipMemsetAsync(u, 0, 4, st);
+    (void)hipMemsetAsync(amax_slot(e, AM_US, ci), 0, 4, st);
+  }
+  return u;
 }
 
 int upload_resize(eosvos_engine* e, const HostResize& h, int in, int out, ResizeTab& tab) {
@@ -421,7 +579,10 @@ ConvArgs wino_fwd_gemm(eosvos_engine* e, int ci, const WinoGeom& wg, float* ws) 
 // `side`: launch on the side stream with its own stream-K workspace (forward branches that do not depend on
 // each other: downsample convs, decoder.conv1)
 void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi, float* y, int ldy, int B,
-              const float* res, int ldres, bool relu, bool side = false) {
+              const float* res, int ldres, bool relu, bool side = false, const float* xkey = nullptr, const float* ykey = nullptr) {
+  // xkey / ykey: first element of the tensors that x / y are views of (f16x3 absmax slots are kept per tensor)
+  if (!xkey) xkey = x;
+  if (!ykey) ykey = y;
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -444,22 +605,28 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     // forward with a side stream has already queued all of them there (forward_impl), beside layer1..3
     if (e->wino_w_wait) { (void)hipStreamWaitEvent(st, e->ev_wino_w, 0); e->wino_w_wait = false; }
     if (!e->wino_us_valid[ci]) {
-      if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
-      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st);
+      unsigned* us = amax_wino_weights(e, ci, st);
+      if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st, us, us ? us + e->t.convs.size() : nullptr);
+      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], st, us, us ? us + e->t.convs.size() : nullptr);
       e->wino_us_valid[ci] = 1;
     }
-    if (wg.tm == 4) launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
-    else launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st);
+    unsigned* vslot = amax_fused_slot(e, AM_V, ci, e->wino_V[ci], st);   // the input transform accumulates max|V| itself
+    if (wg.tm == 4) launch_wino4_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st, vslot);
+    else launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st, vslot);
     e->wino_v_batch[ci] = B;
     ConvArgs m = wino_fwd_gemm(e, ci, wg, a.ws);
+    if (vslot) { m.amax_x = vslot; m.amax_w = amax_slot(e, AM_U, ci); }
+    // the output transform writes y (directly, or the raw conv output of the GroupNorm mode)
+    unsigned* yslot = gn ? nullptr : twrite_fused(e, 0, ykey, ldy == c.cout);
+    if (gn) twrite_plain(e, 0, ykey);
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
     if (wg.tm == 4)
       launch_wino4_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
-                          (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
+                          (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st, yslot);
     else
       launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
-                         (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st);
+                         (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st, yslot);
     if (gn)
       launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
                         a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st);
@@ -472,6 +639,14 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
   }
   attach_tap_table(e, ci, 0, B, a);
+  if (h3_mode() && !amax_init(e)) {
+    amax_weights(e, st);
+    a.amax_x = tlookup(e, 0, xkey);
+    if (!a.amax_x) a.amax_x = amax_get(e, AM_X, ci, x, (long)B * Hi * Wi, c.cin, ldx, st);
+    a.amax_w = amax_slot(e, AM_W, ci);
+    if (gn) twrite_plain(e, 0, ykey);              // y is written by the GroupNorm kernel
+    else a.amax_y = twrite_fused(e, 0, ykey, ldy == c.cout);
+  }
   trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a), conv_exec_frac(a));
   launch_conv(a, st);
   if (gn)
@@ -480,12 +655,15 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
 }
 // gx[B,Hin,Win,cin] (ld ldgx) (+)= dgrad of conv ci applied to g[B,Ho,Wo,cout] (ld ldg)
 void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int Win, float* gx, int ldgx, int B,
-                bool accum, const float* mask, int ldmask, int mask_c0, const float* add = nullptr, int ldadd = 0) {
+                bool accum, const float* mask, int ldmask, int mask_c0, const float* add = nullptr, int ldadd = 0,
+                const float* gkey = nullptr, const float* gxkey = nullptr) {
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.wg_budget = e->wg_budget;
-  if (e->gn() && c.norm) { g = e->zbuf[ci]; ldg = c.cout; }   // gradient w.r.t. the raw conv output (conv_wgrad made it)
+  if (!gkey) gkey = g;
+  if (!gxkey) gxkey = gx;
+  if (e->gn() && c.norm) { g = e->zbuf[ci]; ldg = c.cout; gkey = g; }   // gradient w.r.t. the raw conv output (conv_wgrad made it)
   a.x = g; a.w = e->W_(ci); a.y = gx; a.ws = e->ws_conv;
   a.B = B; a.Hi = conv_out(Hin, c.k, c.stride, c.dil, c.pad); a.Wi = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   a.ldx = ldg; a.Kc = c.cout;
@@ -495,25 +673,41 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.kscale = e->A_(ci);
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
   a.res = add; a.ldres = ldadd;
-  if (!add && wino_on(e, ci, B, Hin, Win)) {
+  const bool wino_dg = !add && wino_on(e, ci, B, Hin, Win);
+  if (h3_mode() && !wino_dg && !amax_init(e)) {
+    amax_weights(e, e->s);
+    a.amax_x = tlookup(e, 1, gkey);
+    if (!a.amax_x) a.amax_x = amax_get(e, AM_G, ci, g, (long)B * a.Hi * a.Wi, c.cout, ldg, e->s);
+    a.amax_w = amax_slot(e, AM_W, ci);
+    a.amax_ks = amax_ks(e, ci, e->s);
+    a.amax_y = twrite_fused(e, 1, gxkey, ldgx == c.cin);
+  }
+  if (wino_dg) {
     // Winograd data gradient: dV[p] = dM[p] (a[cout] U[p]), 16 GEMMs [tiles x cout] x [cout x cin] in one batched
     // launch, then dX = mask(B dV B^T) gathered per 2x2 pixel block
     const WinoGeom wg = wino_geom(e, c, B, Hin, Win);
     const int th = wg.th, tw = wg.tw;
     const long prow = wg.prow;
     if (e->wino_dm_batch[ci] != B) {
-      if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
-      else launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s);
+      unsigned* dms = amax_fused_slot(e, AM_DM, ci, e->wino_dM[ci], e->s);
+      if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s, dms);
+      else launch_wino_grad(g, ldg, c.cout, B, Hin, Win, th, tw, wg.d, prow, e->wino_dM[ci], e->s, dms);
     }
     e->wino_dm_batch[ci] = 0;
     if (!e->wino_us_valid[ci]) {                     // no forward since the weights changed: rebuild a[cout] * U
-      if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s);
-      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s);
+      unsigned* us = amax_wino_weights(e, ci, e->s);
+      if (wg.tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s, us, us ? us + e->t.convs.size() : nullptr);
+      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s, us, us ? us + e->t.convs.size() : nullptr);
       e->wino_us_valid[ci] = 1;
     }
     ConvArgs m;
     memset(&m, 0, sizeof(m));
     m.wg_budget = e->wg_budget;
+    if (h3_mode() && !amax_init(e)) {
+      m.amax_x = amax_get(e, AM_DM, ci, e->wino_dM[ci], (long)wg.np * prow, c.cout, c.cout, e->s);   // made by the transform
+      m.amax_w = amax_slot(e, AM_US, ci);
+    }
+    unsigned* gxs = twrite_fused(e, 1, gxkey, ldgx == c.cin);
     m.x = e->wino_dM[ci]; m.w = e->wino_Us[ci]; m.y = e->wino_dv; m.ws = e->ws_conv; m.nplanes = wg.np;
     m.B = 1; m.Hi = 1; m.Wi = (int)(wg.np * prow); m.ldx = c.cout; m.Kc = c.cout;
     m.Ho = 1; m.Wo = m.Wi; m.N = c.cin; m.ldy = c.cin; m.KH = m.KW = 1; m.mul = 1;
@@ -532,9 +726,9 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
       launch_conv(m, e->s);
     }
     if (wg.tm == 4)
-      launch_wino4_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
+      launch_wino4_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s, gxs);
     else
-      launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s);
+      launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s, gxs);
     return;
   }
   if (c.k == 1 && c.stride == 2 && !add) {
@@ -637,7 +831,7 @@ bool wgrad_groupable(const eosvos_engine* e, int ci) {
   // every stage is grouped (4 tasks in flight at batch 1: 41.0 -> 41.9 meta-tasks/s).
   static const int env_stage = getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE") ? atoi(getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE")) : -1;
   const int min_stage = env_stage >= 0 ? env_stage : (e->s2 ? 2 : 0);
-  return !off && e->wg_group_on && conv_mfma_mode() == 1 && e->force_algo == 0 && ci < (int)e->t.stage.size() &&
+  return !off && e->wg_group_on && conv_mfma_mode() >= 1 && e->force_algo == 0 && ci < (int)e->t.stage.size() &&
          e->t.stage[ci] >= min_stage && e->t.stage[ci] <= 2 && !e->conv_hin.empty();
 }
 // Launch the queued weight gradients (all of one stage) -- on the side stream when there is one.
@@ -702,20 +896,25 @@ int flush_wgrad_group(eosvos_engine* e, int stage, int B) {
   return 0;
 }
 // slabs of dW into ws_wg; returns the number of slabs (-1: queued for the stage's grouped launch, flush_wgrad_group)
-int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x, int ldx, int Hin, int Win, int B) {
+int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x, int ldx, int Hin, int Win, int B,
+               const float* gkey = nullptr, const float* xkey = nullptr) {
   const ConvL& c = e->t.convs[ci];
+  if (!gkey) gkey = g;
+  if (!xkey) xkey = x;
   if (e->gn() && c.norm) {        // dz = GroupNorm backward of G_u, written over the stored raw output
     const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
     launch_gn_backward(e->zbuf[ci], c.cout, g, ldg, e->G_(ci), e->gn_stats[ci], e->gn_sums, e->gn_partial, B, Ho * Wo, c.cout,
                        e->s);
-    g = e->zbuf[ci]; ldg = c.cout;
+    g = e->zbuf[ci]; ldg = c.cout; gkey = g;
+    twrite_plain(e, 1, gkey);
   }
   const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   const bool wino = wino_on(e, ci, B, Ho, Wo);
   if (wino) {                       // dM feeds this weight gradient (side stream) and the data gradient (main stream)
     const WinoGeom wg = wino_geom(e, c, B, Ho, Wo);
-    if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
-    else launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s);
+    unsigned* dms = amax_fused_slot(e, AM_DM, ci, e->wino_dM[ci], e->s);
+    if (wg.tm == 4) launch_wino4_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s, dms);
+    else launch_wino_grad(g, ldg, c.cout, B, Ho, Wo, wg.th, wg.tw, wg.d, wg.prow, e->wino_dM[ci], e->s, dms);
     e->wino_dm_batch[ci] = B;
   }
   WgradArgs a;
@@ -735,10 +934,19 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, wg.np, e->wg_budget);
     trace("wgrad", ci, c.cout, (long)c.cin * wg.np, ntile, a.splits);
     const int cin = c.cin, cout = c.cout;
+    const bool h3 = h3_mode() && !amax_init(e);
+    if (h3) {
+      a.amax_g = amax_get(e, AM_DM, ci, e->wino_dM[ci], (long)wg.np * prow, c.cout, c.cout, e->s);
+      a.amax_x = amax_slot(e, AM_V, ci);
+      if (!need_v && (e->amax_rec[a.amax_x - e->amax].epoch != e->fwd_epoch))      // V of a forward in another mode
+        a.amax_x = amax_get(e, AM_V, ci, V, (long)wg.np * prow, c.cin, c.cin, e->s);
+    }
+    unsigned* vslot = h3 ? amax_slot(e, AM_V, ci) : nullptr;
     go = [=](hipStream_t ws) {
       if (need_v) {
-        if (wg.tm == 4) launch_wino4_input(x, ldx, cin, B, Hin, Win, wg.th, wg.tw, wg.d, prow, V, ws);
-        else launch_wino_input(x, ldx, cin, B, Hin, Win, wg.th, wg.tw, wg.d, prow, V, ws);
+        if (h3) (void)hipMemsetAsync(vslot, 0, 4, ws);
+        if (wg.tm == 4) launch_wino4_input(x, ldx, cin, B, Hin, Win, wg.th, wg.tw, wg.d, prow, V, ws, vslot);
+        else launch_wino_input(x, ldx, cin, B, Hin, Win, wg.th, wg.tw, wg.d, prow, V, ws, vslot);
       }
       launch_wgrad(a, ws);
       if (wg.tm == 4) launch_wino4_wgrad_finish(a.ws, a.splits, cout, cin, final_slab, ws);
@@ -750,6 +958,17 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     a.B = B; a.Ho = Ho; a.Wo = Wo;
     a.ldg = ldg; a.Cout = c.cout; a.Hi = Hin; a.Wi = Win; a.ldx = ldx; a.Cin = c.cin;
     a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = c.dil;
+    if (h3_mode() && !amax_init(e)) {
+      a.amax_g = tlookup(e, 1, gkey);
+      if (!a.amax_g) a.amax_g = amax_get(e, AM_G, ci, g, (long)B * Ho * Wo, c.cout, ldg, e->s);
+      // the input activation: the slot of its tensor or of this conv's view from the forward pass, else it is made now
+      a.amax_x = tlookup(e, 0, xkey);
+      if (!a.amax_x) {
+        unsigned* xs = amax_slot(e, AM_X, ci);
+        auto& r = e->amax_rec[xs - e->amax];
+        a.amax_x = (r.epoch == e->fwd_epoch && r.ptr == x) ? xs : amax_get(e, AM_X, ci, x, (long)B * Hin * Win, c.cin, ldx, e->s);
+      }
+    }
     if (wgrad_groupable(e, ci)) {
       e->wg_pending.push_back({ci, a});
       return -1;
@@ -796,6 +1015,7 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
       u.n = (int)(c.wsize() + (c.bias ? c.cout : 0)); u.slab = u.n;
       u.splits = e->upd_splits[ci]; u.rowlen = c.T() * c.cin;
       u.lr_off = (int)c.lroff; u.norm_off = (c.norm && !e->gn()) ? (int)c.noff : -1; u.blk0 = blk;
+      u.amax_idx = ((c.cin & 3) || (u.n & 3)) ? -1 : ci;      // tensors the matrix kernels read (not the stem, not conv + bias)
       blk += (u.n + 1024 * UPD_CHUNKS - 1) / (1024 * UPD_CHUNKS);
     }
     UpdEntry* d = (UpdEntry*)e->falloc((int64_t)(tab.size() * sizeof(UpdEntry) + 3) / 4);
@@ -803,10 +1023,22 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
     HIPOK(hipMemcpy(d, tab.data(), tab.size() * sizeof(UpdEntry), hipMemcpyHostToDevice));
     e->upd_tab[slot] = d; e->upd_blocks[slot] = blk;
   }
-  if (update) wino_weights_changed(e);
+  // f16x3: the update kernel refreshes max|w| of the tensors it rewrites (their slots are zeroed first, on the same
+  // stream), so the W slots stay valid across the update.  The slots of the other part are not touched: the rest of
+  // the backward pass (main stream) reads only those.
+  unsigned* amax_w = nullptr;
+  if (update) {
+    for (auto& kv : e->wino_us_valid) kv.second = 0;
+    if (h3_mode() && !amax_init(e) && e->w_amax_valid) {
+      amax_w = e->amax + AM_W * t.convs.size();
+      (void)hipMemsetAsync(amax_w + lo, 0, (size_t)(hi - lo) * 4, stream);
+    } else {
+      e->w_amax_valid = false;
+    }
+  }
   launch_sgd_update_all(e->upd_tab[slot], hi - lo, e->upd_blocks[slot], e->Wp, e->ws_wg, e->na,
                         update ? e->lr : nullptr, (update && e->lr_level == EOSVOS_LR_PARAM) ? e->lr_elem : nullptr,
-                        accumulate ? e->gsum : nullptr, e->keep_grads ? e->gout : nullptr, stream);
+                        accumulate ? e->gsum : nullptr, e->keep_grads ? e->gout : nullptr, stream, amax_w);
   return 0;
 }
 
@@ -820,7 +1052,7 @@ const char* eosvos_version(void) { return "eosvos-mi355x 0.4 (gfx950, fp32 impli
 const char* eosvos_last_error(void) { return g_err.c_str(); }
 
 int eosvos_set_matrix_mode(int mode) {
-  if (mode != EOSVOS_MATRIX_F32 && mode != EOSVOS_MATRIX_BF16X6) return fail("unknown matrix mode");
+  if (mode != EOSVOS_MATRIX_F32 && mode != EOSVOS_MATRIX_BF16X6 && mode != EOSVOS_MATRIX_F16X3) return fail("unknown matrix mode");
   conv_set_mfma_mode(mode);
   return 0;
 }
@@ -1236,6 +1468,7 @@ int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, con
                     const float* var, float eps) {
   if (!e || !gamma || !beta || !mean || !var) return fail("null argument");
   wino_weights_changed(e);
+  std::fill(e->ks_amax_valid.begin(), e->ks_amax_valid.end(), 0);
   if (e->gn()) {                  // GroupNorm shares the (frozen) affine only (deeplabv3plus.py:186-188)
     HIPOK(hipMemcpyAsync(e->na, gamma, (size_t)e->t.nnorm * 4, hipMemcpyDeviceToDevice, e->s));
     HIPOK(hipMemcpyAsync(e->nb, beta, (size_t)e->t.nnorm * 4, hipMemcpyDeviceToDevice, e->s));
@@ -1280,6 +1513,16 @@ int eosvos_restore_params(eosvos_engine* e) {
 static int forward_impl(eosvos_engine* e, const float* images, int B) {
   const Topo& t = e->t;
   hipStream_t s = e->s;
+  amax_new_phase(e, 0);
+  if (h3_mode() && !amax_init(e)) {
+    amax_weights(e, s);
+    bool stale = false, fresh = false;
+    for (auto& kv : e->wino_us_valid) { stale |= !kv.second; fresh |= kv.second != 0; }
+    if (stale && !fresh) {                          // every Winograd-domain weight is remade by this forward
+      (void)hipMemsetAsync(e->amax + AM_U * t.convs.size(), 0, 2 * t.convs.size() * 4, s);
+      e->us_zero_epoch = e->fwd_epoch;
+    }
+  }
   launch_nchw_to_nhwc_pad(images, e->xpad, B, 3, e->H, e->W, 3, s);
   if (e->gn()) {
     launch_stem_fwd(e->xpad, e->W_(0), nullptr, nullptr, e->zbuf[0], B, e->H, e->W, e->h2, e->w2, s);
@@ -1310,8 +1553,9 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
       const int Ho = conv_out(e->conv_hin[ci], c.k, c.stride, c.dil, c.pad), Wo = conv_out(e->conv_win[ci], c.k, c.stride, c.dil, c.pad);
       if (!wino_on(e, ci, B, Ho, Wo)) continue;
       if (!any) { fork(0); any = true; }
-      if (wino_geom(e, c, B, Ho, Wo).tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s2);
-      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s2);
+      unsigned* us = amax_wino_weights(e, ci, e->s2);
+      if (wino_geom(e, c, B, Ho, Wo).tm == 4) launch_wino4_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s2, us, us ? us + t.convs.size() : nullptr);
+      else launch_wino_weight(e->W_(ci), c.cout, c.cin, e->A_(ci), e->wino_U[ci], e->wino_Us[ci], e->s2, us, us ? us + t.convs.size() : nullptr);
       kv.second = 1;
     }
     if (any) { (void)hipEventRecord(e->ev_wino_w, e->s2); e->wino_w_wait = true; }
@@ -1342,7 +1586,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   const float* l4 = e->bb.back().out;
   const int P16 = e->h16 * e->w16;
   for (int i = 0; i < 4; ++i)
-    conv_fwd(e, t.aspp[i], l4, 2048, e->h16, e->w16, e->cat + 256 * i, 1280, B, nullptr, 0, true);
+    conv_fwd(e, t.aspp[i], l4, 2048, e->h16, e->w16, e->cat + 256 * i, 1280, B, nullptr, 0, true, false, nullptr, e->cat);
   launch_colsum(l4, 2048, e->vec, B, P16, 2048, 1.0f / (float)P16, e->colscratch, s);
   if (e->gn()) {
     launch_gemv_fwd(e->W_(t.pool), e->vec, nullptr, nullptr, e->zbuf[t.pool], B, 256, 2048, s);
@@ -1352,6 +1596,10 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
     launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, s);
   }
   launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s);
+  if (h3_mode() && !e->gn() && !amax_init(e)) {
+    // cat = 4 conv outputs (their epilogues fed the tensor's slot) + the broadcast pooling branch (its B x 256 values here)
+    if (unsigned* cs = tslot(e, 0, e->cat)) { launch_absmax(e->poolout, 1, B * 256, B * 256, cs, s); tmark_valid(e, 0, e->cat); }
+  }
   conv_fwd(e, t.project, e->cat, 1280, e->h16, e->w16, e->proj, 256, B, nullptr, 0, true);
   const ConvL& lc = t.convs[t.last];
   if (t.v3) {
@@ -1386,6 +1634,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   if (accumulate && !e->gsum) return fail("accumulate without eosvos_meta_task_begin");
   const int64_t P4 = (int64_t)B * e->h4 * e->w4;
   const int P16 = e->h16 * e->w16;
+  amax_new_phase(e, 1);
   // final resize
   launch_resize_bwd(e->dlogits, 1, e->g_low, 1, nullptr, 0, B, 1, e->fin_h, e->fin_w, s);
   if (t.v3) {
@@ -1393,6 +1642,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     const int64_t PA = (int64_t)B * e->h16 * e->w16;
     const int chunks = last_bwd_chunks(PA);
     launch_last_bwd(e->d1, e->W_(t.last), e->g_low, e->g_d1, e->ws_wg + e->ws_off[t.last], PA, 256, chunks, s);
+    twrite_plain(e, 1, e->g_d1);
     apply_update(e, t.last, chunks, update, accumulate);
     int sp = conv_wgrad(e, t.head3, e->g_d1, 256, e->proj, 256, e->h16, e->w16, B);
     conv_dgrad(e, t.head3, e->g_d1, 256, e->h16, e->w16, e->g_proj, 256, B, false, e->proj, 256, 0);
@@ -1402,6 +1652,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   {
     const int chunks = last_bwd_chunks(P4);
     launch_last_bwd(e->d2, e->W_(t.last), e->g_low, e->g_d2, e->ws_wg + e->ws_off[t.last], P4, 256, chunks, s);
+    twrite_plain(e, 1, e->g_d2);
     apply_update(e, t.last, chunks, update, accumulate);
   }
   // decoder 3x3 convs
@@ -1418,12 +1669,13 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   {
     float* g_low_feat = e->bb[t.layer1_last_block].g_out;
     const float* low = e->bb[t.layer1_last_block].out;
-    int sp = conv_wgrad(e, t.dec1, e->g_dcat + 256, 304, low, 256, e->h4, e->w4, B);
-    conv_dgrad(e, t.dec1, e->g_dcat + 256, 304, e->h4, e->w4, g_low_feat, 256, B, false, nullptr, 0, 0);
+    int sp = conv_wgrad(e, t.dec1, e->g_dcat + 256, 304, low, 256, e->h4, e->w4, B, e->g_dcat);
+    conv_dgrad(e, t.dec1, e->g_dcat + 256, 304, e->h4, e->w4, g_low_feat, 256, B, false, nullptr, 0, 0, nullptr, 0, e->g_dcat);
     apply_update(e, t.dec1, sp, update, accumulate);
   }
   // decoder upsample backward (+ ReLU mask of the projection output)
   launch_resize_bwd(e->g_dcat, 304, e->g_proj, 256, e->proj, 256, B, 256, e->up_h, e->up_w, s);
+  twrite_plain(e, 1, e->g_proj);
   }
   // ASPP projection
   {
@@ -1443,13 +1695,14 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     }
     launch_gemv_bwd(e->W_(t.pool), e->vec, gpz, e->A_(t.pool), e->gvec, e->ws_wg + e->ws_off[t.pool], B, 256, 2048, s);
     launch_bcast_pixels(e->gvec, g_l4, 2048, B, P16, 2048, 1.0f / (float)P16, s);
+    twrite_plain(e, 1, g_l4);
     apply_update(e, t.pool, 1, update, accumulate);
   }
   for (int i = 0; i < 4; ++i) {
-    int sp = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B);
+    int sp = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B, e->g_cat);
     const bool lastone = i == 3;
     conv_dgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, e->h16, e->w16, g_l4, 2048, B, true,
-               lastone ? l4 : nullptr, 2048, 0);
+               lastone ? l4 : nullptr, 2048, 0, nullptr, 0, e->g_cat);
     apply_update(e, t.aspp[i], sp, update, accumulate);
   }
   // bottlenecks, last to first.  g_out of each block = dL/d(pre-ReLU block output).
@@ -2008,6 +2261,7 @@ int eosvos_test_conv_algo(eosvos_engine* e, int algo, const float* x, const floa
   ScratchEngine se(e, algo, B, H, W, Cin, Cout, k, stride, dil, pad, scale != nullptr);
   if (!se.ok) return fail("scratch engine: shape not eligible for the requested algorithm, or out of memory");
   eosvos_engine* t = &se.t;
+  amax_new_phase(t, 0);
   launch_oihw_to_ohwi(w_oihw, t->Wp, Cout, Cin, k * k, t->s);
   if (scale) {
     HIPOK(hipMemcpyAsync(t->na, scale, (size_t)Cout * 4, hipMemcpyDeviceToDevice, t->s));
@@ -2030,6 +2284,8 @@ int eosvos_test_conv_bwd_algo(eosvos_engine* e, int algo, const float* x, const 
   if (!se.ok) return fail("scratch engine: shape not eligible for the requested algorithm, or out of memory");
   eosvos_engine* t = &se.t;
   const int T = k * k;
+  amax_new_phase(t, 0);
+  amax_new_phase(t, 1);
   launch_oihw_to_ohwi(w_oihw, t->Wp, Cout, Cin, T, t->s);
   if (scale) HIPOK(hipMemcpyAsync(t->na, scale, (size_t)Cout * 4, hipMemcpyDeviceToDevice, t->s));
   // the order of the backward pass: weight gradient first (it makes the shared Winograd-domain dM), then data gradient

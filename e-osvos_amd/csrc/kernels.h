@@ -6,6 +6,36 @@
 #include <stdint.h>
 
 namespace eosvos {
+#if defined(__HIPCC__)
+// absmax bookkeeping of the f16x3 matrix mode: |x| bit patterns compare like unsigned integers (NaN above everything)
+__device__ __forceinline__ unsigned amax_f4(unsigned m, const float4& v) {
+  const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+  const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  const unsigned q = ab > cd ? ab : cd;
+  return m > q ? m : q;
+}
+// Every thread of the 256-thread workgroup calls this (no divergence around it).  One atomic per workgroup, and only
+// when it would raise the slot: thousands of atomics on one address serialise in L2 (measured: 8192 per launch = 25 us).
+// The slot is read right before the atomic: a value peeked when the kernel starts is 0 for every workgroup of the first
+// resident round, i.e. every one of them then pays the atomic (measured: update kernel 270 -> 890 us, fix-ups +40 %).
+__device__ __forceinline__ unsigned amax_peek(const unsigned*) { return 0u; }
+__device__ __forceinline__ void amax_block_commit(unsigned m, unsigned* slot, unsigned = 0) {
+  __shared__ unsigned wmax[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = m > t ? m : t;
+  }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    const unsigned q = a > b ? a : b;
+    if (q > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, q);
+  }
+}
+#endif
 
 // ---------------------------------------------------------------------------------
 // Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -52,6 +82,12 @@ struct ConvArgs {
   int deep;             // set by conv_plan: 1 / 2 = the 3-workgroups-per-CU kernel variants (K step 32 single stage / 16)
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
   int wg_budget;        // workgroups the launch may plan for (0: two per CU); engines that run beside others split less
+  // f16x3 mode: device words holding the bit pattern of max|x| over the gather source, over the weights as passed in `w`
+  // (all planes of a batched GEMM) and -- data gradient -- over `kscale`; see launch_absmax
+  const unsigned* amax_x;
+  const unsigned* amax_w;
+  const unsigned* amax_ks;
+  unsigned* amax_y;     // optional: atomicMax of the bit patterns of |y| as written (the absmax slot of the destination tensor)
 };
 // Parity-major row order of a stride-2 data gradient: rows [0, M) walk the (even,even) output pixels of all
 // images, then (even,odd), (odd,even), (odd,odd).  A pixel of parity (py,px) only receives the filter taps with
@@ -84,7 +120,11 @@ void conv_prof_enable(int on);
 int conv_prof_read(int max, const char** names, long* counts, double* ms, double* flops);
 double conv_exec_frac(const struct ConvArgs& a);
 double wgrad_exec_frac(const struct WgradArgs& a);
-int conv_mfma_mode();                // 1: bf16x6 split kernels (default), 0: fp32 MFMA kernels (EOSVOS_MFMA=f32)
+int conv_mfma_mode();                // 1: bf16x6 split kernels (default), 0: fp32 MFMA kernels (EOSVOS_MFMA=f32), 2: f16x3 (EOSVOS_MFMA=f16x3)
+// max|x| over rows x C floats (row pitch ld): atomicMax of the bit patterns into *slot (the caller zeroes the slot first)
+void launch_absmax(const float* x, long rows, int C, int ld, unsigned* slot, hipStream_t s);
+// many dense tensors in one launch: segment y = floats [dev_off[y], dev_off[y] + dev_n[y]) of base (dev_n % 4 == 0) -> slots[y]
+void launch_absmax_segments(const float* base, const long* dev_off, const int* dev_n, int nseg, unsigned* slots, hipStream_t s);
 // calibration: back-to-back fp32 MFMAs, returns the FLOPs the launch performs
 double launch_mfma_probe(float* scratch, int iters, hipStream_t s);
 int64_t conv_ws_floats();
@@ -104,6 +144,8 @@ struct WgradArgs {
   int KH, KW, stride, pad, dil;
   int splits;
   long g_tap_stride, x_tap_stride;   // != 0: tap t reads plane g + t*stride / x + t*stride (batched GEMMs, Winograd)
+  const unsigned* amax_g;            // f16x3 mode: bit pattern of max|g| / max|x| over the tensors (all planes), device words
+  const unsigned* amax_x;
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget = 0);
@@ -116,24 +158,24 @@ int conv_clamp_wg_budget(int n);     // the budgets the slab arenas are sized fo
 // Winograd F(2x2,3x3) weight gradient pieces (misc_kernels.hip): V = B^T d B, dM = A dY A^T, dW = G^T sum_z dU_z G
 // planes are [16][prow][C] with prow >= B*th*tw rows (padded to the GEMM tile so that a row tile never straddles planes)
 // dil: dilation of the 3x3 conv = dil*dil interleaved sub-grids; tiles are (image, sy, sx, ty, tx), th x tw per sub-grid
-void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V, hipStream_t s);
-void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M, hipStream_t s);
-void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s);   // U = G w G^T, Us = rowscale*U
+void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V, hipStream_t s, unsigned* amax = nullptr);
+void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M, hipStream_t s, unsigned* amax = nullptr);
+void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s, unsigned* amax_u = nullptr, unsigned* amax_us = nullptr);   // U = G w G^T, Us = rowscale*U
 // Winograd F(4x4,3x3): 36 planes, th x tw tiles of 4x4 outputs per sub-grid
 void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,
-                        hipStream_t s);
+                        hipStream_t s, unsigned* amax = nullptr);
 void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M,
-                       hipStream_t s);
-void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s);
+                       hipStream_t s, unsigned* amax = nullptr);
+void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s, unsigned* amax_u = nullptr, unsigned* amax_us = nullptr);
 void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                         const float* bias, int relu, float* y, int ldy, hipStream_t s);
+                         const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax = nullptr);
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
 void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // U = G (rowscale*w) G^T
+                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax = nullptr);   // U = G (rowscale*w) G^T
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s);   // dX = mask?(B dV B^T, overlapped)
+                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax = nullptr);   // dX = mask?(B dV B^T, overlapped)
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                        const float* bias, int relu, float* y, int ldy, hipStream_t s);        // y = epilogue(A^T M A)
+                        const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax = nullptr);        // y = epilogue(A^T M A)
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
 
 // ---------------------------------------------------------------------------------
@@ -229,10 +271,12 @@ struct UpdEntry {
   int lr_off;      // offset of its per-neuron learning rates
   int norm_off;    // offset of its frozen-norm scale, -1 if none
   int blk0;        // first workgroup of this entry (UPD_CHUNKS x 1024 elements per workgroup)
+  int amax_idx;    // f16x3 mode: index of the tensor's absmax word in `amax_w` (the conv index), -1: none
 };
 #define UPD_CHUNKS 1   // 1024-element chunks per workgroup of the update kernel (UpdEntry::blk0 counts those)
 void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
-                           const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s);
+                           const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s,
+                           unsigned* amax_w = nullptr);   // amax_w: max|w| of the updated weights, per UpdEntry::amax_idx
 // learning-rate hierarchy (meta_optim.py:27-67): stored lr state -> effective per-neuron lr, and back
 void launch_lr_expand(const float* store, const int* row_tensor, float* lr, int nlr, int level, int use_log,
                       hipStream_t s);

@@ -841,7 +841,8 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
                                                               float* __restrict__ W, const float* __restrict__ ws,
                                                               const float* __restrict__ na, const float* __restrict__ lr,
                                                               const float* __restrict__ lr_elem,
-                                                              float* __restrict__ gsum, float* __restrict__ gout) {
+                                                              float* __restrict__ gsum, float* __restrict__ gout,
+                                                              unsigned* __restrict__ amax_w) {
   // locate this workgroup's table entry: first-block offsets to LDS, then a binary search
   __shared__ int blk0s[256];
   for (int i = threadIdx.x; i < nent; i += 256) blk0s[i] = tab[i].blk0;
@@ -852,6 +853,9 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
     if ((int)blockIdx.x >= blk0s[mid]) lo = mid; else hi = mid - 1;
   }
   const UpdEntry t = tab[lo];
+  unsigned* const aslot = (amax_w && t.amax_idx >= 0) ? amax_w + t.amax_idx : nullptr;
+  const unsigned aseen = amax_peek(aslot);
+  unsigned am = 0;
   constexpr int CH = UPD_CHUNKS;        // 1024-element chunks per workgroup, all in flight together
   const int base = ((int)blockIdx.x - t.blk0) * (1024 * CH) + threadIdx.x * 4;
   const size_t zstride = (size_t)t.slab;
@@ -912,7 +916,9 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
         *reinterpret_cast<float4*>(gsum + t.w_off + e) = q;
       }
       if (gout) *reinterpret_cast<float4*>(gout + t.w_off + e) = g;
+      am = amax_f4(am, w4[c]);
     }
+    if (aslot) amax_block_commit(am, aslot, aseen);
     return;
   }
   // odd-sized tensors (the classifier's 256 weights + bias): element per thread, coalesced, the slab
@@ -941,9 +947,9 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
   }
 }
 void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
-                           const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s) {
+                           const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s, unsigned* amax_w) {
   hipLaunchKernelGGL(sgd_update_all_kernel, dim3(nblocks), dim3(256), 0, s, tab, nent, W, ws, na, lr, lr_elem, gsum,
-                     gout);
+                     gout, amax_w);
 }
 }  // namespace eosvos
 
@@ -1286,9 +1292,11 @@ void launch_warp_affine(const float* src, float* dst, int C, int H, int W, const
 namespace eosvos {
 // V[p][tile][c] from X (NHWC, ld ldx): 4x4 patch rows 2ty-1..2ty+2, cols 2tx-1..2tx+2, zero outside the image
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, int C, int B, int H, int W,
-                                                          int th, int tw, int dil, long prow, float* __restrict__ V) {
+                                                          int th, int tw, int dil, long prow, float* __restrict__ V, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
@@ -1321,18 +1329,22 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       F4OP(v0, t[i][0], -, t[i][2]); F4OP(v1, t[i][1], +, t[i][2]);
       F4OP(v2, t[i][2], -, t[i][1]); F4OP(v3, t[i][1], -, t[i][3]);
       float* o = V + ((long)(i * 4) * prow + tile) * C + c4 * 4;
+      am = amax_f4(amax_f4(amax_f4(amax_f4(am, v0), v1), v2), v3);
       *reinterpret_cast<float4*>(o) = v0;
       *reinterpret_cast<float4*>(o + prow * C) = v1;
       *reinterpret_cast<float4*>(o + 2 * prow * C) = v2;
       *reinterpret_cast<float4*>(o + 3 * prow * C) = v3;
     }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 // dM[p][tile][c] = A dY A^T from dY (NHWC, ld ldg): 2x2 outputs of the tile (zero outside), A = [[1,0],[1,1],[1,-1],[0,-1]]
 __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
-                                                         int th, int tw, int dil, long prow, float* __restrict__ M) {
+                                                         int th, int tw, int dil, long prow, float* __restrict__ M, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
@@ -1361,12 +1373,14 @@ __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict_
       F4OP(m1, t[i][0], +, t[i][1]); F4OP(m2, t[i][0], -, t[i][1]);
       const float4 m3 = make_float4(-t[i][1].x, -t[i][1].y, -t[i][1].z, -t[i][1].w);
       float* o = M + ((long)(i * 4) * prow + tile) * C + c4 * 4;
+      am = amax_f4(amax_f4(amax_f4(amax_f4(am, t[i][0]), m1), m2), m3);
       *reinterpret_cast<float4*>(o) = t[i][0];
       *reinterpret_cast<float4*>(o + prow * C) = m1;
       *reinterpret_cast<float4*>(o + 2 * prow * C) = m2;
       *reinterpret_cast<float4*>(o + 3 * prow * C) = m3;
     }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 // dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][4x4][cin]) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ ws, int splits, int Cout, int Cin,
@@ -1410,22 +1424,24 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 #undef F4OP
 }
 void launch_wino_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,
-                       hipStream_t s) {
+                       hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, dil, prow, V);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, dil, prow, V, amax);
 }
 void launch_wino_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M,
-                      hipStream_t s) {
+                      hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M);
+  hipLaunchKernelGGL(wino_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M, amax);
 }
 // U[p][cout][cin] = G w G^T from W[cout][3x3][cin]
 // U = G w G^T; Us (optional) = rowscale[cout] * U, the copy the data gradient multiplies with
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
                                                            const float* __restrict__ rowscale, float* __restrict__ U,
-                                                           float* __restrict__ Us) {
+                                                           float* __restrict__ Us, unsigned* __restrict__ amax_u, unsigned* __restrict__ amax_us) {
   const int C4 = Cin >> 2;
   const long n = (long)Cout * C4;
+  unsigned am = 0, ams = 0;
+  const unsigned seen = amax_peek(amax_u), seen_s = amax_peek(amax_us);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4), co = (int)(e / C4);
     const float rs = rowscale ? rowscale[co] : 1.f;      // data gradient: the frozen-norm scale a[cout] folded into Us
@@ -1450,6 +1466,9 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
       const float4 u1 = make_float4(0.5f * (a.x + b.x + c.x), 0.5f * (a.y + b.y + c.y), 0.5f * (a.z + b.z + c.z), 0.5f * (a.w + b.w + c.w));
       const float4 u2 = make_float4(0.5f * (a.x - b.x + c.x), 0.5f * (a.y - b.y + c.y), 0.5f * (a.z - b.z + c.z), 0.5f * (a.w - b.w + c.w));
       const float4 u3 = c;
+      am = amax_f4(amax_f4(amax_f4(amax_f4(am, u0), u1), u2), u3);
+      ams = amax_f4(amax_f4(ams, make_float4(rs * u0.x, rs * u0.y, rs * u0.z, rs * u0.w)), make_float4(rs * u1.x, rs * u1.y, rs * u1.z, rs * u1.w));
+      ams = amax_f4(amax_f4(ams, make_float4(rs * u2.x, rs * u2.y, rs * u2.z, rs * u2.w)), make_float4(rs * u3.x, rs * u3.y, rs * u3.z, rs * u3.w));
       *reinterpret_cast<float4*>(U + off) = u0;
       *reinterpret_cast<float4*>(U + off + ps) = u1;
       *reinterpret_cast<float4*>(U + off + 2 * ps) = u2;
@@ -1462,10 +1481,12 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
       }
     }
   }
+  if (amax_u) amax_block_commit(am, amax_u, seen);
+  if (amax_us) amax_block_commit(ams, amax_us, seen_s);
 }
-void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s) {
+void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s, unsigned* amax_u, unsigned* amax_us) {
   const long n = (long)Cout * (Cin / 4);
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U, Us);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U, Us, amax_u, amax_us);
 }
 // dX (NHWC, ld ldgx) = mask?( sum over the covering tiles of (B dV B^T)[i][j] ), one thread per 2x2 pixel block and 4
 // channels: the block (2k..2k+1, 2l..2l+1) takes rows i = 3 of tile k-1, i = 1, 2 of tile k and i = 0 of tile k+1
@@ -1473,9 +1494,11 @@ void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale
 __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
                                                                  int W, int th, int tw, int dil,
                                                                  const float* __restrict__ mask, int ldmask, int mask_c0,
-                                                                 int accum, float* __restrict__ gx, int ldgx) {
+                                                                 int accum, float* __restrict__ gx, int ldgx, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;      // one 2x2 block of a sub-grid per tile position
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long blk = e / C4;
@@ -1551,24 +1574,28 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
           const float4 m = *reinterpret_cast<const float4*>(mask + pix * ldmask + c4 * 4);
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
+        am = amax_f4(am, v);
         *reinterpret_cast<float4*>(gx + pix * ldgx + c4 * 4) = v;
       }
     }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s) {
+                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
-                     dil, mask, ldmask, mask_c0, accum, gx, ldgx);
+                     dil, mask, ldmask, mask_c0, accum, gx, ldgx, amax);
 }
 // y (NHWC, ld ldy) = relu?(scale * (A^T M A) + bias) from M[p][tile][c], A^T = [[1,1,1,0],[0,1,-1,-1]]
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
                                                            int th, int tw, int dil, const float* __restrict__ scale,
                                                            const float* __restrict__ bias, int relu, float* __restrict__ y,
-                                                           int ldy) {
+                                                           int ldy, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
@@ -1601,16 +1628,18 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         if (scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
         if (bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        am = amax_f4(am, v);
         *reinterpret_cast<float4*>(y + (((long)b * H + yy) * W + xx) * ldy + c4 * 4) = v;
       }
     }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                        const float* bias, int relu, float* y, int ldy, hipStream_t s) {
+                        const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, dil,
-                     scale, bias, relu, y, ldy);
+                     scale, bias, relu, y, ldy, amax);
 }
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
@@ -1647,9 +1676,11 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 
 // V[p][tile][c] = B^T d B, d = 6x6 patch rows 4ty-1..4ty+4, cols 4tx-1..4tx+4 (zero outside)
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ldx, int C, int B, int H, int W,
-                                                           int th, int tw, int dil, long prow, float* __restrict__ V) {
+                                                           int th, int tw, int dil, long prow, float* __restrict__ V, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 d[6][6];
@@ -1685,16 +1716,20 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
 #pragma unroll
         for (int bb = 0; bb < 6; ++bb)
           if (w4::BT[j][bb] != 0.f) w4::fma4(v, w4::BT[j][bb], d[i][bb]);
+        am = amax_f4(am, v);
         *reinterpret_cast<float4*>(V + ((long)(i * 6 + j) * prow + tile) * C + c4 * 4) = v;
       }
     }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 // dM[p][tile][c] = A dY A^T, dY = the tile's 4x4 outputs (zero outside), A = AT^T
 __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
-                                                          int th, int tw, int dil, long prow, float* __restrict__ M) {
+                                                          int th, int tw, int dil, long prow, float* __restrict__ M, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 d[4][4];
@@ -1724,16 +1759,20 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (w4::AT[r][bb] != 0.f) w4::fma4(v, w4::AT[r][bb], t[a][r]);
+        am = amax_f4(am, v);
         *reinterpret_cast<float4*>(M + ((long)(a * 6 + bb) * prow + tile) * C + c4 * 4) = v;
       }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 // U[p][cout][cin] = G (rowscale * w) G^T
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
                                                             const float* __restrict__ rowscale, float* __restrict__ U,
-                                                            float* __restrict__ Us) {
+                                                            float* __restrict__ Us, unsigned* __restrict__ amax_u, unsigned* __restrict__ amax_us) {
   const int C4 = Cin >> 2;
   const long n = (long)Cout * C4;
+  unsigned am = 0, ams = 0;
+  const unsigned seen = amax_peek(amax_u), seen_s = amax_peek(amax_us);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4), co = (int)(e / C4);
     const float rs = rowscale ? rowscale[co] : 1.f;
@@ -1759,20 +1798,26 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 3; ++r)
           if (w4::G[bb][r] != 0.f) w4::fma4(v, w4::G[bb][r], t[a][r]);
+        am = amax_f4(am, v);
+        ams = amax_f4(ams, make_float4(rs * v.x, rs * v.y, rs * v.z, rs * v.w));
         *reinterpret_cast<float4*>(U + (size_t)(a * 6 + bb) * ps + (size_t)co * Cin + c4 * 4) = v;
         if (Us)
           *reinterpret_cast<float4*>(Us + (size_t)(a * 6 + bb) * ps + (size_t)co * Cin + c4 * 4) =
               make_float4(rs * v.x, rs * v.y, rs * v.z, rs * v.w);
       }
   }
+  if (amax_u) amax_block_commit(am, amax_u, seen);
+  if (amax_us) amax_block_commit(ams, amax_us, seen_s);
 }
 // y = relu?(scale * (A^T M A) + bias), 4x4 outputs per tile
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
                                                             int th, int tw, int dil, const float* __restrict__ scale,
                                                             const float* __restrict__ bias, int relu, float* __restrict__ y,
-                                                            int ldy) {
+                                                            int ldy, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 t[4][6];                        // t = A^T m, streamed over the rows a of m
@@ -1807,10 +1852,12 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         if (scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
         if (bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        am = amax_f4(am, v);
         *reinterpret_cast<float4*>(y + (((long)b * H + yy) * W + xx) * ldy + c4 * 4) = v;
       }
     }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 // dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][6x6][cin]) G.  One thread per (cout, cin): the decoder convs have only
 // 256 x 304 of them, and a float4-per-thread version (64 workgroups of long dependent load chains) ran at 2 TB/s.
@@ -1860,9 +1907,11 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
 __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
                                                                   int W, int th, int tw, int dil,
                                                                   const float* __restrict__ mask, int ldmask, int mask_c0,
-                                                                  int accum, float* __restrict__ gx, int ldgx) {
+                                                                  int accum, float* __restrict__ gx, int ldgx, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long blk = e / C4;
@@ -1947,40 +1996,42 @@ __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __
           const float4 m = *reinterpret_cast<const float4*>(mask + pix * ldmask + c4 * 4);
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
+        am = amax_f4(am, v);
         *reinterpret_cast<float4*>(gx + pix * ldgx + c4 * 4) = v;
       }
     }
   }
+  if (amax) amax_block_commit(am, amax, seen);
 }
 #undef W4_TILE_DECODE
 void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,
-                        hipStream_t s) {
+                        hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, dil, prow, V);
+  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, ldx, C, B, H, W, th, tw, dil, prow, V, amax);
 }
 void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* M,
-                       hipStream_t s) {
+                       hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
-  hipLaunchKernelGGL(wino4_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M);
+  hipLaunchKernelGGL(wino4_grad_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, g, ldg, C, B, H, W, th, tw, dil, prow, M, amax);
 }
-void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s) {
+void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s, unsigned* amax_u, unsigned* amax_us) {
   const long n = (long)Cout * (Cin / 4);
-  hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U, Us);
+  hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U, Us, amax_u, amax_us);
 }
 void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                         const float* bias, int relu, float* y, int ldy, hipStream_t s) {
+                         const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, dil,
-                     scale, bias, relu, y, ldy);
+                     scale, bias, relu, y, ldy, amax);
 }
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
   const long n = (long)Cout * Cin;
   hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, ws, splits, Cout, Cin, dst);
 }
 void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s) {
+                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino4_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
-                     dil, mask, ldmask, mask_c0, accum, gx, ldgx);
+                     dil, mask, ldmask, mask_c0, accum, gx, ldgx, amax);
 }
 }  // namespace eosvos

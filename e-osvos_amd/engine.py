@@ -25,12 +25,12 @@ LOSS_KINDS = {'cross_entropy': 0, 'dice': 1, 'cross_entropy_and_dice': 2, 'class
 
 
 def set_matrix_mode(mode):
-    """'bf16x6' (default) or 'f32': how the convolutions' fp32 contractions use the matrix cores (process-wide)."""
-    _ffi.check(_ffi.load().eosvos_set_matrix_mode({'f32': 0, 'bf16x6': 1}[mode]))
+    """'bf16x6', 'f16x3' or 'f32': how the convolutions' fp32 contractions use the matrix cores (process-wide)."""
+    _ffi.check(_ffi.load().eosvos_set_matrix_mode({'f32': 0, 'bf16x6': 1, 'f16x3': 2}[mode]))
 
 
 def get_matrix_mode():
-    return 'bf16x6' if _ffi.load().eosvos_get_matrix_mode() == 1 else 'f32'
+    return {0: 'f32', 1: 'bf16x6', 2: 'f16x3'}[_ffi.load().eosvos_get_matrix_mode()]
 
 
 _POOL_WARMED = []

@@ -60,6 +60,7 @@ const char* eosvos_last_error(void);
  * loss; denormal operands contribute nothing in either mode; finite values up to FLT_MAX split exactly. */
 #define EOSVOS_MATRIX_F32 0
 #define EOSVOS_MATRIX_BF16X6 1
+#define EOSVOS_MATRIX_F16X3 2
 int eosvos_set_matrix_mode(int mode);
 int eosvos_get_matrix_mode(void);
 

@@ -12,8 +12,8 @@ from collections import defaultdict
 def main(trace_csv, log, steps=3):
     rows = [r for r in csv.DictReader(open(trace_csv))]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    is_conv = lambda n: 'conv_igemm_kernel' in n or 'conv_x6_kernel' in n
-    mf = [r for r in rows if is_conv(r['Kernel_Name']) or 'wgrad_kernel<' in r['Kernel_Name'] or 'wgrad_x6_kernel<' in r['Kernel_Name'] or 'wgrad_x6_group_kernel<' in r['Kernel_Name']]
+    is_conv = lambda n: 'conv_igemm_kernel' in n or 'conv_x6_kernel' in n or 'conv_h3_kernel' in n
+    mf = [r for r in rows if is_conv(r['Kernel_Name']) or 'wgrad_kernel<' in r['Kernel_Name'] or 'wgrad_x6_kernel<' in r['Kernel_Name'] or 'wgrad_x6_group_kernel<' in r['Kernel_Name'] or 'wgrad_h3_kernel<' in r['Kernel_Name'] or 'wgrad_h3_group_kernel<' in r['Kernel_Name']]
     # fix-up launch that follows a conv launch (same stream order)
     for i, r in enumerate(rows):
         if is_conv(r['Kernel_Name']):

@@ -1,0 +1,229 @@
+// Probe: fp32 GEMM on the matrix cores as a 2-way fp16 split with 3 partial products ("f16x3") against the adopted
+// 3-way bf16 split with 6 ("bf16x6").  Same loop (128x128x32 tile, 256 threads, 16x16x32 MFMA, one LDS stage, pitch 96).
+//   a*sa = h0 + h1 + e,  h0 = rn16(a*sa), h1 = rn16(a*sa - h0),  |e| <= 2^-24 |a*sa| while h1 is a normal fp16 number;
+//   sa, sb: per-tensor powers of two that put max|a| near 2^12 (fp16 overflows at 65504; below 2^-14 * 2^12 of the
+//   maximum the low piece goes subnormal: absolute error floor 2^-25 in scaled units = 2^-37 of the tensor's maximum)
+//   C = (h0a*h0b + h0a*h1b + h1a*h0b) / (sa*sb), fp32 accumulation; dropped h1a*h1b <= 2^-24 |ab|.
+// C[M][N] = A[M][K] * B[N][K]^T.   Build: hipcc -O3 --offload-arch=gfx950 tools/probes/f16x3_probe.cpp -o tools/probes/bin/f16x3
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+__device__ __forceinline__ unsigned pack_hi(float e0, float e1) {
+  return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_f16(float e0, float e1) {        // round to nearest even, e0 in the low half
+  f32x2 v = {e0, e1};
+  f16x2 h = __builtin_convertvector(v, f16x2);
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ f32x2 unpack_f16(unsigned w) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
+}
+
+// NP 3: bf16x6.  NP 2: f16x3.
+template <int NP>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ C, int M, int N, int K, float sa, float sb) {
+  constexpr int BM = 128, BN = 128, BK = 32, PITCH = 96;
+  constexpr int OP_BYTES = NP * BM * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP_BYTES];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + OP_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int c4 = tid & 7;
+  const int j = lane >> 3;
+  const int row = (wave << 3) + ((j & 1) << 1) + ((j >> 1) & 1) + (j & 4);
+  float4 ra[4], rb[4];
+  auto load = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+      rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + 32 * i) * K + ks * BK + c4 * 4);
+    }
+  };
+  auto store_op = [&](unsigned char* S, const float4* rv, float s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = row + 32 * i;
+      float4 v = rv[i];
+      if (NP == 3) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          uint2 w;
+          w.x = pack_hi(v.x, v.y);
+          w.y = pack_hi(v.z, v.w);
+          *reinterpret_cast<uint2*>(S + p * BM * PITCH + rr * PITCH + c4 * 8) = w;
+          if (p + 1 < 3) { v.x -= trunc_bf16(v.x); v.y -= trunc_bf16(v.y); v.z -= trunc_bf16(v.z); v.w -= trunc_bf16(v.w); }
+        }
+      } else {
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        uint2 w0, w1;
+        w0.x = pack_f16(v.x, v.y);
+        w0.y = pack_f16(v.z, v.w);
+        const f32x2 b0 = unpack_f16(w0.x), b1 = unpack_f16(w0.y);
+        w1.x = pack_f16(v.x - b0.x, v.y - b0.y);
+        w1.y = pack_f16(v.z - b1.x, v.w - b1.y);
+        *reinterpret_cast<uint2*>(S + rr * PITCH + c4 * 8) = w0;
+        *reinterpret_cast<uint2*>(S + BM * PITCH + rr * PITCH + c4 * 8) = w1;
+      }
+    }
+  };
+  const int nk = K / BK;
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+  load(0);
+  store_op(As, ra, sa); store_op(Bs, rb, sb);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) load(ks + 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn) {
+      uint4 fa[4][NP], fb[2][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t][p] = *reinterpret_cast<const uint4*>(As + p * BM * PITCH + (wm * 64 + t * 16 + r) * PITCH + q * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[t][p] = *reinterpret_cast<const uint4*>(Bs + p * BM * PITCH + (wn * 64 + (hn * 2 + t) * 16 + r) * PITCH + q * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x4 c = acc[tm][hn * 2 + tn];
+          if (NP == 3) {
+#define MB(a, b) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+            MB(fa[tm][NP - 1], fb[tn][0]); MB(fa[tm][0], fb[tn][NP - 1]); MB(fa[tm][1], fb[tn][1]);
+            MB(fa[tm][1], fb[tn][0]); MB(fa[tm][0], fb[tn][1]); MB(fa[tm][0], fb[tn][0]);
+          } else {
+#define MH(a, b) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+            MH(fa[tm][1], fb[tn][0]); MH(fa[tm][0], fb[tn][1]); MH(fa[tm][0], fb[tn][0]);
+          }
+          acc[tm][hn * 2 + tn] = c;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (more) { store_op(As, ra, sa); store_op(Bs, rb, sb); }
+    __syncthreads();
+  }
+  const float inv = NP == 3 ? 1.f : 1.f / (sa * sb);
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + tm * 16 + 4 * q + e;
+        const int n = n0 + wn * 64 + tn * 16 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e] * inv;
+      }
+}
+
+static float pow2_scale(const std::vector<float>& v) {           // power of two that puts the maximum in [2^11, 2^12)
+  float mx = 0;
+  for (float x : v) mx = fmaxf(mx, fabsf(x));
+  int e;
+  frexpf(mx, &e);                                                 // mx = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 12 - e);
+}
+
+template <int NP>
+static void run(const char* name, const float* dA, const float* dB, float* dC, int M, int N, int K, const std::vector<float>& hA,
+                const std::vector<float>& hB, float sa, float sb) {
+  const int tiles = (M / 128) * (N / 128);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto go = [&]() { hipLaunchKernelGGL((gemm_kernel<NP>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb); };
+  for (int i = 0; i < 3; ++i) go();
+  CK(hipDeviceSynchronize());
+  const int reps = 20;
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) go();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const int RM = 64, RN = 128;
+  std::vector<float> hC((size_t)RM * N);
+  CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+  double max_rel_sabs = 0, sum_sq = 0, sum_sq_ref = 0, sum_sq32 = 0;
+  for (int m = 0; m < RM; ++m)
+    for (int n = 0; n < RN; ++n) {
+      double s = 0, sa_ = 0;
+      float s32 = 0;
+      for (int k = 0; k < K; ++k) {
+        const double p = (double)hA[(size_t)m * K + k] * (double)hB[(size_t)n * K + k];
+        s += p; sa_ += fabs(p);
+        s32 = fmaf(hA[(size_t)m * K + k], hB[(size_t)n * K + k], s32);
+      }
+      const double err = fabs((double)hC[(size_t)m * N + n] - s);
+      max_rel_sabs = fmax(max_rel_sabs, err / sa_);
+      sum_sq += err * err; sum_sq_ref += s * s; sum_sq32 += ((double)s32 - s) * ((double)s32 - s);
+    }
+  printf("%-10s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TFLOP/s  rms_rel=%.3e (fp32 fma chain %.3e)  max err/sum|ab|=%.3e\n", name, M, N, K,
+         ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, sqrt(sum_sq / sum_sq_ref), sqrt(sum_sq32 / sum_sq_ref), max_rel_sabs);
+}
+
+int main(int argc, char** argv) {
+  const int shapes[][3] = {{16384, 4096, 2048}, {8192, 2048, 1024}, {8192, 2048, 256}, {65536, 256, 320}};
+  // data 0: uniform (-1,1) x 0.05 uniform; 1: heavy-tailed (normal * exp(3 * normal)) both sides; 2: tiny magnitudes (1e-6 .. 1e-9)
+  for (int data = 0; data < 3; ++data)
+  for (auto& s : shapes) {
+    if (data > 0 && s[0] != 8192) continue;
+    const int M = s[0], N = s[1], K = s[2];
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    std::mt19937 g(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::uniform_real_distribution<float> ud(-1.f, 1.f);
+    if (data == 0) { for (auto& v : hA) v = ud(g); for (auto& v : hB) v = ud(g) * 0.05f; }
+    else if (data == 1) { for (auto& v : hA) v = nd(g) * expf(3.f * nd(g)); for (auto& v : hB) v = nd(g) * expf(3.f * nd(g)) * 1e-3f; }
+    else { for (auto& v : hA) v = nd(g) * 1e-6f * expf(2.f * nd(g)); for (auto& v : hB) v = ud(g) * 0.05f; }
+    float *dA, *dB, *dC;
+    CK(hipMalloc(&dA, hA.size() * 4));
+    CK(hipMalloc(&dB, hB.size() * 4));
+    CK(hipMalloc(&dC, (size_t)M * N * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    const float sa = pow2_scale(hA), sb = pow2_scale(hB);
+    printf("data %d: scales 2^%d 2^%d\n", data, (int)log2f(sa), (int)log2f(sb));
+    run<3>("bf16x6", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
+    run<2>("f16x3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
+    if (data == 2) run<2>("f16x3 s=1", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
+  }
+  return 0;
+}
