@@ -431,7 +431,6 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
   constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
   const int c_c4 = threadIdx.x % CF4, c_r = threadIdx.x / CF4;
-  const unsigned yseen = amax_peek(p.amax_y);
   const bool act = n0 + c_c4 * 4 < p.N;          // threads past the last column only take part in the absmax reduction
   const int n = act ? n0 + c_c4 * 4 : n0;
   // blockIdx.y selects one eighth of the tile's rows (more, shorter workgroups: the sum is latency
@@ -490,7 +489,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
     *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
     ymax = amax_f4(ymax, v);
   }
-  if (p.amax_y) amax_block_commit(ymax, p.amax_y, yseen);
+  if (p.amax_y) amax_block_commit(ymax, p.amax_y);
 }
 
 static int env_int(const char* name, int dflt);
@@ -609,7 +608,8 @@ __device__ __forceinline__ void x6_split2(float a, float b, unsigned out[3]) {
 // Half the MFMAs, a third less LDS traffic than bf16x6; measured on the bare GEMM loop 238-276 TFLOP/s against 163-188 and
 // a smaller error than bf16x6 on well-scaled data (tools/probes/f16x3_probe.cpp, profiles/r03_f16x3_probe.txt).
 // The scale comes from the absmax slots the engine maintains (uint bit patterns of max|x|, atomicMax'ed by absmax_kernel
-// or by the kernel that produced the tensor); a NaN / inf slot yields NaN outputs, as in the other modes.
+// or by the kernel that produced the tensor; finite values only).  NaN / inf elements become fp16 NaN / inf pieces and
+// reach the outputs they contribute to as NaN, as in the bf16x6 mode.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -622,8 +622,8 @@ __device__ __forceinline__ f32x2v h3_unpack(unsigned w) { return __builtin_conve
 // scale 2^(141 - e) for a tensor whose absmax has the biased exponent e (largest magnitude -> [2^14, 2^15)), and 1 / scale.
 // `amax2`: optional second factor of the staged values (the per-channel norm scale of the data gradient).
 __device__ __forceinline__ float h3_scale(const unsigned* amax, const unsigned* amax2, float& inv) {
-  float m = __uint_as_float(*amax);
-  if (amax2) m *= __uint_as_float(*amax2);
+  float m = __uint_as_float(amax_read(amax));
+  if (amax2) m *= __uint_as_float(amax_read(amax2));
   const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
   int f = 268 - e;
   f = f < 1 ? 1 : (f > 254 ? 254 : f);
@@ -727,6 +727,9 @@ __device__ __forceinline__ void x6_mma_step(const unsigned char* As, const unsig
   }
 }
 
+#ifndef EOSVOS_H3_MB2
+#define EOSVOS_H3_MB2 0      // 1: the f16x3 conv kernel re-reads the B fragments per A pair like the bf16x6 one (fewer registers, 1.5x the LDS reads)
+#endif
 constexpr int xs_max(int a, int b) { return a > b ? a : b; }
 // LDS of a conv workgroup: NP operand planes, or the C tile that the epilogue stages through the same bytes
 template <int BN, int NP> constexpr int conv_xs_smem() { return xs_max(NP * (128 + BN) * X6_ROWB, 128 * (BN + 4) * 4); }
@@ -777,7 +780,6 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
   }
 
   unsigned ymax = 0;           // f16x3: absmax of what this workgroup writes (-> p.amax_y)
-  const unsigned yseen = NP == 2 ? amax_peek(p.amax_y) : 0u;
   for (long u = u_begin;;) {
     int tile, ks_begin, ks_end = ksteps;
     const bool dp = dp_i < p.dp_q;
@@ -942,7 +944,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
       const bool more = (ks + 1) < ks_end;
       if (more) load_tiles(ks + 1);          // global loads in flight behind the MFMAs below
       __builtin_amdgcn_s_setprio(1);
-      x6_mma_step<TM, TN, (BN == 128 ? 2 : TM), NP>(As, Bs, BM, BN, wm * 64, wn * (BN / 2), fr, fq, acc);
+      x6_mma_step<TM, TN, ((BN == 128 && (NP == 3 || EOSVOS_H3_MB2)) ? 2 : TM), NP>(As, Bs, BM, BN, wm * 64, wn * (BN / 2), fr, fq, acc);
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();                       // every wave is done reading the stage
       if (more) store_tiles();
@@ -1027,7 +1029,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
     }
     if (!dp) u += ks_end - ks_begin;
   }
-  if (NP == 2 && p.amax_y) amax_block_commit(ymax, p.amax_y, yseen);
+  if (NP == 2 && p.amax_y) amax_block_commit(ymax, p.amax_y);
 }
 
 template <int BN, bool KMAJOR>
@@ -1254,8 +1256,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_group_kernel(const WgradArgs*
   wgrad_x6_body<BMO, BNI, 2>(p, bid, smem);
 }
 
-// max|x| of a [rows x C] view (row pitch ld floats) -> atomicMax of the bit pattern (|x| compares like an unsigned
-// integer; a NaN compares above every number and so survives).  HBM-bound: one read of the view.
+// max over the finite |x| of a [rows x C] view (row pitch ld floats) -> atomicMax of the bit pattern (|x| compares like
+// an unsigned integer).  HBM-bound: one read of the view.
 __device__ __forceinline__ unsigned absmax4(const float4& v, unsigned m) { return amax_f4(m, v); }
 __device__ __forceinline__ void absmax_finish(unsigned m, unsigned* slot) { amax_block_commit(m, slot); }
 // dense view: n4 float4 in a row
@@ -1306,7 +1308,7 @@ __global__ __launch_bounds__(256) void absmax_segments_kernel(const float* __res
   const float4* x = reinterpret_cast<const float4*>(base + off[y]);
   unsigned m = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) m = absmax4(x[i], m);
-  absmax_finish(m, slots + y);
+  absmax_finish(m, slots + y);   // (blockIdx.x + blockIdx.y) spreads the words
 }
 void launch_absmax_segments(const float* base, const long* dev_off, const int* dev_n, int nseg, unsigned* slots, hipStream_t s) {
   hipLaunchKernelGGL(absmax_segments_kernel, dim3(64, (unsigned)nseg), dim3(256), 0, s, base, dev_off, dev_n, slots);

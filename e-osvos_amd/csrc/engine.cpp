@@ -314,18 +314,37 @@ void wino_weights_changed(eosvos_engine* e) {
 // epoch; W / U / US / KS until the weights / norm change.
 bool trace_on();
 enum { AM_X = 0, AM_V = 1, AM_G = 2, AM_DM = 3, AM_W = 4, AM_U = 5, AM_US = 6, AM_KS = 7, AM_KINDS = 8 };
+// Arena: AMAX_SUB rows of AMAX_ROW words; slot s = column s of every row (kernels.h, amax_block_commit / amax_read).
+// Columns: [X | V | forward tensors][G | DM | backward tensors][W | U | US | KS] -- each phase's slots are one column
+// range, zeroed by one 2-D memset when the phase begins.
+inline size_t amax_col(const eosvos_engine* e, int kind, int ci) {
+  const size_t nc = e->t.convs.size(), T = eosvos_engine::TSLOTS;
+  if (kind <= AM_V) return (size_t)kind * nc + ci;
+  if (kind <= AM_DM) return 2 * nc + T + (size_t)(kind - AM_G) * nc + ci;
+  return 4 * nc + 2 * T + (size_t)(kind - AM_W) * nc + ci;
+}
+inline size_t amax_tcol(const eosvos_engine* e, int phase, int idx) {
+  return (phase == 0 ? 2 : 4) * e->t.convs.size() + (size_t)phase * eosvos_engine::TSLOTS + idx;
+}
+// zero the slots [first, first + count) (all their words)
+inline void amax_zero(unsigned* first, size_t count, hipStream_t st) {
+  (void)hipMemset2DAsync(first, (size_t)AMAX_ROW * 4, 0, count * 4, AMAX_SUB, st);
+}
 inline bool h3_mode() { return conv_mfma_mode() == 2; }
 int amax_init(eosvos_engine* e) {
   if (e->amax) return 0;
   const size_t n = (size_t)AM_KINDS * e->t.convs.size() + 2 * eosvos_engine::TSLOTS;
-  e->amax = (unsigned*)e->falloc((int64_t)n);
+  if (n > AMAX_ROW) return 1;
+  e->amax = (unsigned*)e->falloc((int64_t)AMAX_SUB * AMAX_ROW);
   if (!e->amax) return 1;
-  (void)hipMemsetAsync(e->amax, 0, n * 4, e->s);
+  (void)hipMemsetAsync(e->amax, 0, (size_t)AMAX_SUB * AMAX_ROW * 4, e->s);
   e->amax_rec.assign((size_t)AM_KINDS * e->t.convs.size(), eosvos_engine::AmaxRec());
   e->ks_amax_valid.assign(e->t.convs.size(), 0);
   return 0;
 }
-inline unsigned* amax_slot(eosvos_engine* e, int kind, int ci) { return e->amax + (size_t)kind * e->t.convs.size() + ci; }
+inline unsigned* amax_slot(eosvos_engine* e, int kind, int ci) { return e->amax + amax_col(e, kind, ci); }
+// host-side record of slot (kind, ci)
+inline eosvos_engine::AmaxRec& amax_rec_of(eosvos_engine* e, int kind, int ci) { return e->amax_rec[(size_t)kind * e->t.convs.size() + ci]; }
 // slot of the tensor that starts at `key` (phase 0: activation, 1: gradient); nullptr when the table is full
 unsigned* tslot(eosvos_engine* e, int phase, const float* key) {
   auto& reg = e->treg[phase];
@@ -334,11 +353,12 @@ unsigned* tslot(eosvos_engine* e, int phase, const float* key) {
     if ((int)reg.size() >= eosvos_engine::TSLOTS) return nullptr;
     it = reg.emplace(key, eosvos_engine::TRec{(int)reg.size(), false}).first;
   }
-  return e->amax + (size_t)AM_KINDS * e->t.convs.size() + (size_t)phase * eosvos_engine::TSLOTS + it->second.idx;
+  return e->amax + amax_tcol(e, phase, it->second.idx);
 }
 // a kernel with the fused absmax is about to write the tensor at `key` (full = every element): returns the slot to pass
 unsigned* twrite_fused(eosvos_engine* e, int phase, const float* key, bool full) {
-  if (!h3_mode() || amax_init(e)) return nullptr;
+  static const bool off = getenv("EOSVOS_TUNE_NO_FUSED_AMAX") != nullptr;      // A/B: every consumer runs its own absmax pass
+  if (off || !h3_mode() || amax_init(e)) return nullptr;
   unsigned* sl = tslot(e, phase, key);
   if (sl && full) e->treg[phase][key].valid = true;
   return sl;
@@ -358,7 +378,7 @@ void tmark_valid(eosvos_engine* e, int phase, const float* key) {
 const unsigned* tlookup(eosvos_engine* e, int phase, const float* key) {
   auto it = e->treg[phase].find(key);
   if (it == e->treg[phase].end() || !it->second.valid) return nullptr;
-  return e->amax + (size_t)AM_KINDS * e->t.convs.size() + (size_t)phase * eosvos_engine::TSLOTS + it->second.idx;
+  return e->amax + amax_tcol(e, phase, it->second.idx);
 }
 // a new forward (phase 0) / backward (phase 1) epoch: its slots are zeroed in one memset
 void amax_new_phase(eosvos_engine* e, int phase) {
@@ -367,9 +387,8 @@ void amax_new_phase(eosvos_engine* e, int phase) {
   long& ep = phase == 0 ? e->fwd_epoch : e->bwd_epoch;
   ++ep;
   const int k0 = phase == 0 ? AM_X : AM_G;
-  (void)hipMemsetAsync(e->amax + k0 * nc, 0, 2 * nc * 4, e->s);
+  amax_zero(amax_slot(e, k0, 0), 2 * nc + eosvos_engine::TSLOTS, e->s);     // the two kinds + the phase's tensor slots
   for (size_t i = k0 * nc; i < (k0 + 2) * nc; ++i) e->amax_rec[i].zero_epoch = ep;
-  (void)hipMemsetAsync(e->amax + AM_KINDS * nc + (size_t)phase * eosvos_engine::TSLOTS, 0, eosvos_engine::TSLOTS * 4, e->s);
   for (auto& kv : e->treg[phase]) kv.second.valid = false;
 }
 // absmax of the [rows x C] view at `ptr` into slot (kind, ci) -- computed once per epoch and view
@@ -377,10 +396,10 @@ const unsigned* amax_get(eosvos_engine* e, int kind, int ci, const float* ptr, l
   if (amax_init(e)) return nullptr;
   const long ep = (kind == AM_X || kind == AM_V) ? e->fwd_epoch : e->bwd_epoch;
   unsigned* slot = amax_slot(e, kind, ci);
-  auto& r = e->amax_rec[slot - e->amax];
+  auto& r = amax_rec_of(e, kind, ci);
   if (r.epoch == ep && r.ptr == ptr) return slot;
   if (trace_on()) fprintf(stderr, "EOSVOS_AMAX kind=%d conv=%d rows=%ld C=%d ld=%d memset=%d\n", kind, ci, rows, C, ld, (int)(r.zero_epoch != ep));
-  if (r.zero_epoch != ep) (void)hipMemsetAsync(slot, 0, 4, st);      // not covered by the epoch's bulk zeroing, or used since
+  if (r.zero_epoch != ep) amax_zero(slot, 1, st);      // not covered by the epoch's bulk zeroing, or used since
   launch_absmax(ptr, rows, C, ld, slot, st);
   r.epoch = ep; r.zero_epoch = -1; r.ptr = ptr;
   return slot;
@@ -390,8 +409,8 @@ unsigned* amax_fused_slot(eosvos_engine* e, int kind, int ci, const float* ptr, 
   if (!h3_mode() || amax_init(e)) return nullptr;
   const long ep = (kind == AM_X || kind == AM_V) ? e->fwd_epoch : e->bwd_epoch;
   unsigned* slot = amax_slot(e, kind, ci);
-  auto& r = e->amax_rec[slot - e->amax];
-  if (r.zero_epoch != ep) (void)hipMemsetAsync(slot, 0, 4, st);
+  auto& r = amax_rec_of(e, kind, ci);
+  if (r.zero_epoch != ep) amax_zero(slot, 1, st);
   r.epoch = ep; r.zero_epoch = -1; r.ptr = ptr;
   return slot;
 }
@@ -399,7 +418,7 @@ unsigned* amax_fused_slot(eosvos_engine* e, int kind, int ci, const float* ptr, 
 const unsigned* amax_make(eosvos_engine* e, int kind, int ci, const float* ptr, long rows, int C, int ld, hipStream_t st) {
   if (amax_init(e)) return nullptr;
   unsigned* slot = amax_slot(e, kind, ci);
-  (void)hipMemsetAsync(slot, 0, 4, st);
+  amax_zero(slot, 1, st);
   launch_absmax(ptr, rows, C, ld, slot, st);
   return slot;
 }
@@ -421,8 +440,8 @@ void amax_weights(eosvos_engine* e, hipStream_t st) {
     (void)hipMemcpy(e->amax_w_off, off.data(), nc * sizeof(long), hipMemcpyHostToDevice);
     (void)hipMemcpy(e->amax_w_n, n.data(), nc * sizeof(int), hipMemcpyHostToDevice);
   }
-  (void)hipMemsetAsync(e->amax + AM_W * nc, 0, nc * 4, st);
-  launch_absmax_segments(e->Wp, e->amax_w_off, e->amax_w_n, (int)nc, e->amax + AM_W * nc, st);
+  amax_zero(amax_slot(e, AM_W, 0), nc, st);
+  launch_absmax_segments(e->Wp, e->amax_w_off, e->amax_w_n, (int)nc, amax_slot(e, AM_W, 0), st);
   e->w_amax_valid = true;
 }
 const unsigned* amax_ks(eosvos_engine* e, int ci, hipStream_t st) {
@@ -439,8 +458,8 @@ unsigned* amax_wino_weights(eosvos_engine* e, int ci, hipStream_t st) {
   if (!h3_mode() || amax_init(e)) return nullptr;
   unsigned* u = amax_slot(e, AM_U, ci);
   if (e->us_zero_epoch != e->fwd_epoch) {          // else: forward_impl zeroed every U / US slot of this epoch at once
-    (void)hipMemsetAsync(u, 0, 4, st);
-    (void)hipMemsetAsync(amax_slot(e, AM_US, ci), 0, 4, st);
+    amax_zero(u, 1, st);
+    amax_zero(amax_slot(e, AM_US, ci), 1, st);
   }
   return u;
 }
@@ -938,13 +957,13 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     if (h3) {
       a.amax_g = amax_get(e, AM_DM, ci, e->wino_dM[ci], (long)wg.np * prow, c.cout, c.cout, e->s);
       a.amax_x = amax_slot(e, AM_V, ci);
-      if (!need_v && (e->amax_rec[a.amax_x - e->amax].epoch != e->fwd_epoch))      // V of a forward in another mode
+      if (!need_v && amax_rec_of(e, AM_V, ci).epoch != e->fwd_epoch)      // V of a forward in another mode
         a.amax_x = amax_get(e, AM_V, ci, V, (long)wg.np * prow, c.cin, c.cin, e->s);
     }
     unsigned* vslot = h3 ? amax_slot(e, AM_V, ci) : nullptr;
     go = [=](hipStream_t ws) {
       if (need_v) {
-        if (h3) (void)hipMemsetAsync(vslot, 0, 4, ws);
+        if (h3) amax_zero(vslot, 1, ws);
         if (wg.tm == 4) launch_wino4_input(x, ldx, cin, B, Hin, Win, wg.th, wg.tw, wg.d, prow, V, ws, vslot);
         else launch_wino_input(x, ldx, cin, B, Hin, Win, wg.th, wg.tw, wg.d, prow, V, ws, vslot);
       }
@@ -965,7 +984,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
       a.amax_x = tlookup(e, 0, xkey);
       if (!a.amax_x) {
         unsigned* xs = amax_slot(e, AM_X, ci);
-        auto& r = e->amax_rec[xs - e->amax];
+        auto& r = amax_rec_of(e, AM_X, ci);
         a.amax_x = (r.epoch == e->fwd_epoch && r.ptr == x) ? xs : amax_get(e, AM_X, ci, x, (long)B * Hin * Win, c.cin, ldx, e->s);
       }
     }
@@ -1030,8 +1049,8 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
   if (update) {
     for (auto& kv : e->wino_us_valid) kv.second = 0;
     if (h3_mode() && !amax_init(e) && e->w_amax_valid) {
-      amax_w = e->amax + AM_W * t.convs.size();
-      (void)hipMemsetAsync(amax_w + lo, 0, (size_t)(hi - lo) * 4, stream);
+      amax_w = amax_slot(e, AM_W, 0);
+      amax_zero(amax_w + lo, (size_t)(hi - lo), stream);
     } else {
       e->w_amax_valid = false;
     }
@@ -1519,7 +1538,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
     bool stale = false, fresh = false;
     for (auto& kv : e->wino_us_valid) { stale |= !kv.second; fresh |= kv.second != 0; }
     if (stale && !fresh) {                          // every Winograd-domain weight is remade by this forward
-      (void)hipMemsetAsync(e->amax + AM_U * t.convs.size(), 0, 2 * t.convs.size() * 4, s);
+      amax_zero(amax_slot(e, AM_U, 0), 2 * t.convs.size(), s);
       e->us_zero_epoch = e->fwd_epoch;
     }
   }

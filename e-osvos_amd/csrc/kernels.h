@@ -6,21 +6,29 @@
 #include <stdint.h>
 
 namespace eosvos {
+#define AMAX_SUB 32        // words per absmax slot
+#define AMAX_ROW 2048      // distance (in words) between the words of a slot = slots per arena
 #if defined(__HIPCC__)
-// absmax bookkeeping of the f16x3 matrix mode: |x| bit patterns compare like unsigned integers (NaN above everything)
+// absmax bookkeeping of the f16x3 matrix mode: |x| bit patterns compare like unsigned integers
+// Only finite values count: a NaN / inf element must not set the scale of the whole tensor (it still propagates as NaN
+// through the split of its own products).
+__device__ __forceinline__ unsigned amax_f1(float x) {
+  const unsigned a = __float_as_uint(x) & 0x7fffffffu;
+  return a < 0x7f800000u ? a : 0u;
+}
 __device__ __forceinline__ unsigned amax_f4(unsigned m, const float4& v) {
-  const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
-  const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+  const unsigned a = amax_f1(v.x), b = amax_f1(v.y), c = amax_f1(v.z), d = amax_f1(v.w);
   const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
   const unsigned q = ab > cd ? ab : cd;
   return m > q ? m : q;
 }
-// Every thread of the 256-thread workgroup calls this (no divergence around it).  One atomic per workgroup, and only
-// when it would raise the slot: thousands of atomics on one address serialise in L2 (measured: 8192 per launch = 25 us).
-// The slot is read right before the atomic: a value peeked when the kernel starts is 0 for every workgroup of the first
-// resident round, i.e. every one of them then pays the atomic (measured: update kernel 270 -> 890 us, fix-ups +40 %).
-__device__ __forceinline__ unsigned amax_peek(const unsigned*) { return 0u; }
-__device__ __forceinline__ void amax_block_commit(unsigned m, unsigned* slot, unsigned = 0) {
+// An absmax slot is AMAX_SUB words, AMAX_ROW words apart (word j of slot s = base[j * AMAX_ROW + s]): a workgroup
+// raises word (its index % AMAX_SUB) with one fire-and-forget atomic, the consumer takes the maximum of the AMAX_SUB
+// words.  Measured (tools/probes/atomic_probe.cpp, 2048 workgroups): all on ONE word 25 us (11 ns per atomic, they
+// serialise in L2), on 32 words of one 128-byte line 13 us, on 32 words >= 256 bytes apart 0 us over the kernel
+// without atomics; reading the word first and skipping the atomic unless it raises it costs nothing there either, but a
+// fix-up workgroup that lives 5 us paid 2.5-9 us per launch for that dependent load.
+__device__ __forceinline__ void amax_block_commit(unsigned m, unsigned* slot) {
   __shared__ unsigned wmax[4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -32,8 +40,19 @@ __device__ __forceinline__ void amax_block_commit(unsigned m, unsigned* slot, un
   if (threadIdx.x == 0) {
     const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
     const unsigned q = a > b ? a : b;
-    if (q > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, q);
+    if (q) atomicMax(slot + (size_t)((blockIdx.x + blockIdx.y) & (AMAX_SUB - 1)) * AMAX_ROW, q);
   }
+}
+// the value of a slot: every lane returns the maximum of its AMAX_SUB words (call with the whole wave active)
+__device__ __forceinline__ unsigned amax_read(const unsigned* slot) {
+  const int lane = threadIdx.x & 63;
+  unsigned m = lane < AMAX_SUB ? slot[(size_t)lane * AMAX_ROW] : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = m > t ? m : t;
+  }
+  return m;
 }
 #endif
 

@@ -854,7 +854,6 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
   }
   const UpdEntry t = tab[lo];
   unsigned* const aslot = (amax_w && t.amax_idx >= 0) ? amax_w + t.amax_idx : nullptr;
-  const unsigned aseen = amax_peek(aslot);
   unsigned am = 0;
   constexpr int CH = UPD_CHUNKS;        // 1024-element chunks per workgroup, all in flight together
   const int base = ((int)blockIdx.x - t.blk0) * (1024 * CH) + threadIdx.x * 4;
@@ -918,7 +917,7 @@ __global__ __launch_bounds__(256) void sgd_update_all_kernel(const UpdEntry* __r
       if (gout) *reinterpret_cast<float4*>(gout + t.w_off + e) = g;
       am = amax_f4(am, w4[c]);
     }
-    if (aslot) amax_block_commit(am, aslot, aseen);
+    if (aslot) amax_block_commit(am, aslot);
     return;
   }
   // odd-sized tensors (the classifier's 256 weights + bias): element per thread, coalesced, the slab
@@ -1296,7 +1295,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   const int C4 = C >> 2;
   const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
@@ -1336,7 +1334,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       *reinterpret_cast<float4*>(o + 3 * prow * C) = v3;
     }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 // dM[p][tile][c] = A dY A^T from dY (NHWC, ld ldg): 2x2 outputs of the tile (zero outside), A = [[1,0],[1,1],[1,-1],[0,-1]]
 __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
@@ -1344,7 +1342,6 @@ __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict_
   const int C4 = C >> 2;
   const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
@@ -1380,7 +1377,7 @@ __global__ __launch_bounds__(256) void wino_grad_kernel(const float* __restrict_
       *reinterpret_cast<float4*>(o + 3 * prow * C) = m3;
     }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 // dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][4x4][cin]) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ ws, int splits, int Cout, int Cin,
@@ -1441,7 +1438,6 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   const int C4 = Cin >> 2;
   const long n = (long)Cout * C4;
   unsigned am = 0, ams = 0;
-  const unsigned seen = amax_peek(amax_u), seen_s = amax_peek(amax_us);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4), co = (int)(e / C4);
     const float rs = rowscale ? rowscale[co] : 1.f;      // data gradient: the frozen-norm scale a[cout] folded into Us
@@ -1481,8 +1477,8 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
       }
     }
   }
-  if (amax_u) amax_block_commit(am, amax_u, seen);
-  if (amax_us) amax_block_commit(ams, amax_us, seen_s);
+  if (amax_u) amax_block_commit(am, amax_u);
+  if (amax_us) amax_block_commit(ams, amax_us);
 }
 void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s, unsigned* amax_u, unsigned* amax_us) {
   const long n = (long)Cout * (Cin / 4);
@@ -1498,7 +1494,6 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;      // one 2x2 block of a sub-grid per tile position
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long blk = e / C4;
@@ -1579,7 +1574,7 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
       }
     }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax) {
@@ -1595,7 +1590,6 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   const int C4 = C >> 2;
   const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long tile = e / C4;
@@ -1633,7 +1627,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       }
     }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
                         const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax) {
@@ -1680,7 +1674,6 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 d[6][6];
@@ -1721,7 +1714,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       }
     }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 // dM[p][tile][c] = A dY A^T, dY = the tile's 4x4 outputs (zero outside), A = AT^T
 __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict__ g, int ldg, int C, int B, int H, int W,
@@ -1729,7 +1722,6 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 d[4][4];
@@ -1763,7 +1755,7 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
         *reinterpret_cast<float4*>(M + ((long)(a * 6 + bb) * prow + tile) * C + c4 * 4) = v;
       }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 // U[p][cout][cin] = G (rowscale * w) G^T
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
@@ -1772,7 +1764,6 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
   const int C4 = Cin >> 2;
   const long n = (long)Cout * C4;
   unsigned am = 0, ams = 0;
-  const unsigned seen = amax_peek(amax_u), seen_s = amax_peek(amax_us);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4), co = (int)(e / C4);
     const float rs = rowscale ? rowscale[co] : 1.f;
@@ -1806,8 +1797,8 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
               make_float4(rs * v.x, rs * v.y, rs * v.z, rs * v.w);
       }
   }
-  if (amax_u) amax_block_commit(am, amax_u, seen);
-  if (amax_us) amax_block_commit(ams, amax_us, seen_s);
+  if (amax_u) amax_block_commit(am, amax_u);
+  if (amax_us) amax_block_commit(ams, amax_us);
 }
 // y = relu?(scale * (A^T M A) + bias), 4x4 outputs per tile
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
@@ -1817,7 +1808,6 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     W4_TILE_DECODE
     float4 t[4][6];                        // t = A^T m, streamed over the rows a of m
@@ -1857,7 +1847,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       }
     }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 // dW[cout][3x3][cin] = G^T (sum_z dU_z[cout][6x6][cin]) G.  One thread per (cout, cin): the decoder convs have only
 // 256 x 304 of them, and a float4-per-thread version (64 workgroups of long dependent load chains) ran at 2 TB/s.
@@ -1911,7 +1901,6 @@ __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
   unsigned am = 0;
-  const unsigned seen = amax_peek(amax);
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long blk = e / C4;
@@ -2001,7 +1990,7 @@ __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __
       }
     }
   }
-  if (amax) amax_block_commit(am, amax, seen);
+  if (amax) amax_block_commit(am, amax);
 }
 #undef W4_TILE_DECODE
 void launch_wino4_input(const float* x, int ldx, int C, int B, int H, int W, int th, int tw, int dil, long prow, float* V,

@@ -141,8 +141,9 @@ def test_bf16x6_is_at_least_as_accurate_as_the_fp32_mfma(eng):
     xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
     F.conv2d(xd, wd).backward(gy.double())
     res = {}
+    prev = engine_mod.get_matrix_mode()
     try:
-        for mode in ('f32', 'bf16x6'):
+        for mode in ('f32', 'bf16x6', 'f16x3'):
             engine_mod.set_matrix_mode(mode)
             assert engine_mod.get_matrix_mode() == mode
             out = eng.test_conv_algo('direct', nhwc(x), w.to(DEV), None, None, None, False, 1, 1, 0).permute(0, 3, 1, 2)
@@ -150,11 +151,12 @@ def test_bf16x6_is_at_least_as_accurate_as_the_fp32_mfma(eng):
             res[mode] = (float(((out.double().cpu() - ref).abs() / sabs).max()), _rmsrel(out, ref),
                          _rmsrel(dx.permute(0, 3, 1, 2), xd.grad), _rmsrel(dw, wd.grad))
     finally:
-        engine_mod.set_matrix_mode('bf16x6')
+        engine_mod.set_matrix_mode(prev)
     print('MARGIN matrix modes (max err/sum|ab|, rms rel fwd, dx, dw):', res)
-    for i in range(4):
-        assert res['bf16x6'][i] <= 1.25 * res['f32'][i] + 1e-9, res
-    assert res['bf16x6'][0] < 3e-7 and res['bf16x6'][1] < 1e-6
+    for mode in ('bf16x6', 'f16x3'):          # both split modes: no worse than the fp32 MFMA
+        for i in range(4):
+            assert res[mode][i] <= 1.25 * res['f32'][i] + 1e-9, res
+        assert res[mode][0] < 3e-7 and res[mode][1] < 1e-6
 
 
 def test_bf16x6_special_values_propagate(eng):
@@ -177,12 +179,13 @@ def test_bf16x6_special_values_propagate(eng):
     x[0, 15, 5, 6] = 3.0e38                      # near FLT_MAX, times a small weight: stays finite
     w[:, 15] = w[:, 15] * 1e-3
     res = {}
+    prev = engine_mod.get_matrix_mode()
     try:
         for mode in ('f32', 'bf16x6'):
             engine_mod.set_matrix_mode(mode)
             res[mode] = eng.test_conv_algo('direct', nhwc(x), w.to(DEV), None, None, None, False, 1, 1, 0).permute(0, 3, 1, 2).cpu()
     finally:
-        engine_mod.set_matrix_mode('bf16x6')
+        engine_mod.set_matrix_mode(prev)
     a, b = res['f32'], res['bf16x6']
     assert bool(torch.isnan(a[0, :, 1, 2]).all()) and bool(torch.isnan(b[0, :, 1, 2]).all())
     for (py, px) in ((2, 3), (3, 4)):
@@ -201,3 +204,46 @@ def test_bf16x6_special_values_propagate(eng):
     assert float((b[0][:, clean].double() - ref[0][:, clean]).abs().max()) <= 2e-6 * scale       # denormals contribute nothing
     assert float((a[0][:, clean].double() - ref[0][:, clean]).abs().max()) <= 2e-6 * scale
     assert abs(float(b[0, 0, 5, 6]) - float(ref[0, 0, 5, 6])) <= 2e-6 * abs(float(ref[0, 0, 5, 6]))   # 3e38 * 1e-3 * w: exact split
+
+
+def test_f16x3_special_values_and_dynamic_range(eng):
+    """The fp16 split mode scales every operand tensor by a power of two taken from its largest FINITE magnitude
+    (include/eosvos.h):
+      NaN / +-inf -> NaN in every output the element reaches; they do not set the scale, so every other output keeps
+                     fp32 accuracy;
+      elements down to 2^-16 of the tensor's largest magnitude keep fp32 relative accuracy; smaller ones lose it
+      gradually (absolute error <= 2^-40 of that maximum per element) -- the error stays far below fp32 rounding of the
+      outputs the large elements dominate."""
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Ci, Co = 1, 8, 16, 64, 64
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    x[0, 3, 1, 2] = float('nan')
+    x[0, 5, 2, 3] = float('inf')
+    x[0, 7, 3, 4] = float('-inf')
+    x[0, :, 5, 6] *= 2.0 ** -14                  # a pixel whose activations are 16 000 x smaller than the rest
+    x[0, :, 6, 7] *= 2.0 ** -30                  # ... and one a billion times smaller
+    prev = engine_mod.get_matrix_mode()
+    try:
+        engine_mod.set_matrix_mode('f16x3')
+        out = eng.test_conv_algo('direct', nhwc(x), w.to(DEV), None, None, None, False, 1, 1, 0).permute(0, 3, 1, 2).cpu()
+    finally:
+        engine_mod.set_matrix_mode(prev)
+    assert bool(torch.isnan(out[0, :, 1, 2]).all())
+    for (py, px) in ((2, 3), (3, 4)):
+        assert not bool(torch.isfinite(out[0, :, py, px]).any())
+    clean = torch.ones(H, W, dtype=torch.bool)
+    for (py, px) in ((1, 2), (2, 3), (3, 4)):
+        clean[py, px] = False
+    ref = F.conv2d(torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0).double(), w.double())
+    sabs = F.conv2d(torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0).double().abs(), w.double().abs())
+    assert bool(torch.isfinite(out[0][:, clean]).all())
+    rel = ((out.double() - ref).abs() / sabs)[0]
+    normal = clean.clone()
+    normal[5, 6] = normal[6, 7] = False
+    assert float(rel[:, normal].max()) < 3e-7, float(rel[:, normal].max())          # fp32 accuracy
+    assert float(rel[:, 5, 6].max()) < 3e-7, float(rel[:, 5, 6].max())               # 2^-14 of the maximum: still fp32 accuracy
+    # 2^-30 of the maximum: absolute error <= 2^-40 of the tensor's maximum per element, i.e. tiny against the output scale
+    big = float(x[torch.isfinite(x)].abs().max())
+    err = (out.double() - ref).abs()[0, :, 6, 7]
+    assert float(err.max()) < 64 * 2.0 ** -40 * big * float(w.abs().max()), float(err.max())

@@ -10,7 +10,7 @@ e = Engine('resnet50', 480, 854, max_batch=B)
 e.load_model_state(synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50'))
 x, y = synthetic.synthetic_frames(B, 480, 854)
 e.finetune_step(x.cuda(), y.cuda())
-budgets = [0, 448, 384, 320, 256]
+budgets = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 448, 384, 320, 256]
 from eosvos_amd.topology import conv_infos
 n = len(conv_infos('resnet50'))
 tot = {b: [0.0, 0.0, 0.0] for b in budgets}

@@ -1,12 +1,12 @@
 #!/bin/bash
-# tools/build_variant.sh NAME "-DFLAG ..."  ->  e-osvos_amd/variants/libeosvos_NAME.so  (A/B tuning builds)
+# tools/build_variant.sh NAME "-DFLAG=1 ..."  ->  e-osvos_amd/variants/libeosvos_NAME.so (A/B builds for tools/ab_libs.sh)
 set -e
-cd "$(dirname "$0")/../e-osvos_amd/csrc"
-mkdir -p ../variants /tmp/var_$1
-for f in conv_kernels.hip misc_kernels.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $2 -c $f -o /tmp/var_$1/${f%.hip}.o &
-done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $2 -x hip -c engine.cpp -o /tmp/var_$1/engine.o 2>/dev/null &
+N=$1; F=$2; D=$(mktemp -d); S=$PWD/e-osvos_amd/csrc
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize $F -I$S"
+/opt/rocm/bin/hipcc $FL -c $S/conv_kernels.hip -o $D/conv.o &
+/opt/rocm/bin/hipcc $FL -c $S/misc_kernels.hip -o $D/misc.o &
+/opt/rocm/bin/hipcc $FL -x hip -c $S/engine.cpp -o $D/engine.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libeosvos_$1.so /tmp/var_$1/*.o
-echo built ../variants/libeosvos_$1.so
+mkdir -p e-osvos_amd/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o e-osvos_amd/variants/libeosvos_$N.so $D/conv.o $D/misc.o $D/engine.o
+rm -rf $D; ls -la e-osvos_amd/variants/libeosvos_$N.so

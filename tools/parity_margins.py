@@ -19,7 +19,8 @@ def bits(a, b):
     return int(np.unpackbits(a ^ b).sum())
 
 
-for mode in ('bf16x6', 'f32'):
+PREV = engine_mod.get_matrix_mode()
+for mode in ('f16x3', 'bf16x6', 'f32'):
     engine_mod.set_matrix_mode(mode)
     print('== matrix mode', mode)
     eng = Engine('resnet50', 480, 854, max_batch=3)
@@ -95,4 +96,4 @@ for mode in ('bf16x6', 'f32'):
         max(abs(float(flat[o2[i]:o2[i + 1]].double().norm()) - g7[f'k{K}_init_grad_fp'][i][1]) / (g7[f'k{K}_init_grad_fp'][i][1] + 1e-12) for i in range(len(tr))),
         np.abs(flat[o2[-3]:o2[-2]].view(*g7[f'k{K}_init_grad_last'].shape).numpy() - g7[f'k{K}_init_grad_last']).max() / np.abs(g7[f'k{K}_init_grad_last']).max()))
     eng.close()
-engine_mod.set_matrix_mode('bf16x6')
+engine_mod.set_matrix_mode(PREV)
