@@ -44,9 +44,13 @@ BF16_DENSE_PEAK = 2500.0            # TFLOP/s, MI355X_MICROARCH.md "Peak BF16/FP
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant_kernel.json')
 
 
+MFMAS_PER_FMA = {'f16x3': 3, 'bf16x6': 6}      # 16-bit MFMA issues per fp32 multiply-accumulate
+
+
 def matrix_peak(mode):
-    """fp32-equivalent TFLOP/s roof of the matrix mode: bf16x6 issues 6 bf16 MFMAs per fp32 multiply-accumulate."""
-    return BF16_DENSE_PEAK / 6.0 if mode == 'bf16x6' else FP32_MATRIX_PEAK
+    """fp32-equivalent TFLOP/s roof of the matrix mode = the dense 16-bit MFMA peak / the MFMAs it issues per fp32
+    multiply-accumulate (f16x3: 3, bf16x6: 6); the fp32 MFMA peak in the f32 mode."""
+    return BF16_DENSE_PEAK / MFMAS_PER_FMA[mode] if mode in MFMAS_PER_FMA else FP32_MATRIX_PEAK
 
 
 def cpu_threads():
@@ -136,13 +140,14 @@ def roofline_from(rows, steps, mode, lib_version, batch, ms_per_step):
     traffic, note = pmc_traffic(kernel, lib_version, batch)
     return {
         'bound': 'mfma', 'kernel': kernel, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-        'peak_basis': ('dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per fp32 multiply-accumulate (fp32-equivalent)'
-                       if mode == 'bf16x6' else 'fp32 MFMA peak'),
+        'peak_basis': (f'dense 16-bit MFMA peak 2500 TFLOP/s / {MFMAS_PER_FMA[mode]} MFMAs per fp32 multiply-accumulate in the '
+                       f'{mode} mode (fp32-equivalent)' if mode in MFMAS_PER_FMA else 'fp32 MFMA peak'),
+        'frac_of_bf16x6_roof': achieved / (BF16_DENSE_PEAK / 6.0),      # the yardstick of rounds 2-3 (416.7 TFLOP/s)
         'achieved_is': 'executed fp32-equivalent FLOPs of all launches of this kernel symbol in the profiled steps / their '
                        'summed HIP-event durations (padding taps skipped by the tap tables are not counted)',
         'launches_per_step': launches / steps, 'avg_launch_us': 1e3 * ms / launches,
         'flops_per_launch': flops / launches, 'share_of_step_kernel_time': ms / sum(v[1] for v in rows.values()),
-        'executed_bf16_tflops': 6 * achieved if mode == 'bf16x6' else None,
+        'executed_16bit_mfma_tflops': MFMAS_PER_FMA[mode] * achieved if mode in MFMAS_PER_FMA else None,
         'frac_of_fp32_matrix_peak': achieved / FP32_MATRIX_PEAK,
         'traffic': traffic, 'traffic_note': note,
         'whole_step_executed_gflop': total_flops / 1e9,
@@ -358,10 +363,11 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
     extra = {'last_loss': last_loss, 'matrix_mode': mode, 'lib_version': lib_version, 'timed_region_samples_s': samples,
              'mfma_probe_fp32_tflops': eng.mfma_probe(),
              'direct_conv_equivalent_tflops': BATCH * FLOPS_PER_FRAME_ITER / (ms_per_step * 1e-3) / 1e12,
-             'conv_algorithms': 'fp32 arithmetic throughout; contractions on the bf16 matrix cores by exact 3-way operand '
-                                'split + 6 partial products (bf16x6); 6 of the 63 convs (decoder 3x3 x2, layer4 conv2 x3: '
-                                'Winograd F(4x4,3x3); ASPP d=6: F(2x2,3x3)) run all three passes in the Winograd domain; '
-                                'direct_conv_equivalent_tflops counts 9-tap-equivalent FLOPs, roofline.* executed FLOPs'}
+             'conv_algorithms': 'fp32 tensors throughout; contractions on the 16-bit matrix cores: f16x3 = per-tensor power-of-two '
+                                'scale, 2-way fp16 split, 3 partial products (default); bf16x6 = exact 3-way bf16 split, 6 partial '
+                                'products; 6 of the 63 convs (decoder 3x3 x2, layer4 conv2 x3: Winograd F(4x4,3x3); ASPP d=6: '
+                                'F(2x2,3x3)) run all three passes in the Winograd domain; direct_conv_equivalent_tflops counts '
+                                '9-tap-equivalent FLOPs, roofline.* executed FLOPs'}
     # fine-tune iterations/s for the C1 / C3 shapes as well (C2 is the headline).
     n1 = min(a.steps, 60)
     step_b1 = lambda: eng.finetune_step(xg[:1], yg[:1], sync_loss=False)
@@ -431,13 +437,16 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
 
     if not a.no_ab and world == 1:
         # same engine, same buffers, fp32-MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split kernels
-        engine_mod.set_matrix_mode('f32')
-        for _ in range(3):
-            step()
-        dt32 = timed(step, min(a.steps, 30), barrier, dist, dev)
-        engine_mod.set_matrix_mode(mode)
-        eng.reset()
-        extra['fp32_mfma_mode_ms_per_step'] = 1e3 * dt32 / min(a.steps, 30)
+        for other, key in (('bf16x6', 'bf16x6_mode_ms_per_step'), ('f32', 'fp32_mfma_mode_ms_per_step')):
+            if other == mode:
+                continue
+            engine_mod.set_matrix_mode(other)
+            for _ in range(3):
+                step()
+            dto = timed(step, min(a.steps, 30), barrier, dist, dev)
+            engine_mod.set_matrix_mode(mode)
+            eng.reset()
+            extra[key] = 1e3 * dto / min(a.steps, 30)
     if not a.no_ab and world == 1 and torch.cuda.is_available():
         # the objects of a multi-object sequence are independent fine-tunes (evaluate.py:132): three of them in flight, one
         # engine and ONE queue each (no side stream, each launch planned for half the chip, fresh consecutive streams:

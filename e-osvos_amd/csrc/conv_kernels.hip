@@ -1314,7 +1314,7 @@ void launch_absmax_segments(const float* base, const long* dev_off, const int* d
   hipLaunchKernelGGL(absmax_segments_kernel, dim3(64, (unsigned)nseg), dim3(256), 0, s, base, dev_off, dev_n, slots);
 }
 
-// EOSVOS_MFMA=f32 selects the fp32-MFMA kernels (A/B and fallback); default: bf16x6
+// Matrix mode: 2 = f16x3 (default), 1 = bf16x6, 0 = fp32 MFMA; EOSVOS_MFMA=f16x3|bf16x6|f32 picks the initial one
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && v[0]) ? atoi(v) : dflt;
@@ -1323,7 +1323,7 @@ static int g_mfma_mode = -1;
 int conv_mfma_mode() {
   if (g_mfma_mode < 0) {
     const char* v = getenv("EOSVOS_MFMA");
-    g_mfma_mode = (v && !strcmp(v, "f32")) ? 0 : (v && !strcmp(v, "f16x3")) ? 2 : 1;
+    g_mfma_mode = (v && !strcmp(v, "f32")) ? 0 : (v && !strcmp(v, "bf16x6")) ? 1 : 2;
   }
   return g_mfma_mode;
 }

@@ -1067,7 +1067,7 @@ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 
 extern "C" {
 
-const char* eosvos_version(void) { return "eosvos-mi355x 0.4 (gfx950, fp32 implicit GEMM on the bf16 matrix cores: exact 3-way split, 6 partial products on v_mfma_f32_16x16x32_bf16)"; }
+const char* eosvos_version(void) { return "eosvos-mi355x 0.5 (gfx950, fp32 implicit GEMM on the fp16 matrix cores: 2-way split, 3 partial products on v_mfma_f32_16x16x32_f16; bf16x6 and fp32-MFMA modes selectable)"; }
 const char* eosvos_last_error(void) { return g_err.c_str(); }
 
 int eosvos_set_matrix_mode(int mode) {
@@ -1533,7 +1533,8 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   const Topo& t = e->t;
   hipStream_t s = e->s;
   amax_new_phase(e, 0);
-  if (h3_mode() && !amax_init(e)) {
+  if (h3_mode() && amax_init(e)) return fail("f16x3 matrix mode: no room for the absmax slots of this topology");
+  if (h3_mode()) {
     amax_weights(e, s);
     bool stale = false, fresh = false;
     for (auto& kv : e->wino_us_valid) { stale |= !kv.second; fresh |= kv.second != 0; }

@@ -25,7 +25,7 @@ LOSS_KINDS = {'cross_entropy': 0, 'dice': 1, 'cross_entropy_and_dice': 2, 'class
 
 
 def set_matrix_mode(mode):
-    """'bf16x6', 'f16x3' or 'f32': how the convolutions' fp32 contractions use the matrix cores (process-wide)."""
+    """'f16x3' (default), 'bf16x6' or 'f32': how the convolutions' fp32 contractions use the matrix cores (process-wide; include/eosvos.h)."""
     _ffi.check(_ffi.load().eosvos_set_matrix_mode({'f32': 0, 'bf16x6': 1, 'f16x3': 2}[mode]))
 
 

@@ -51,13 +51,22 @@ const char* eosvos_last_error(void);
 
 /* How the fp32 contractions of the convolutions run on the matrix cores (process-wide; results agree to fp32
  * rounding):
- *   BF16X6 (default): every fp32 operand is split exactly into three bf16 pieces and the product is accumulated
- *          in fp32 from the six leading partial products on v_mfma_f32_16x16x32_bf16 (error <= fp32 MFMA's);
- *   F32:   v_mfma_f32_32x32x2_f32 (1/16 of the bf16 rate on CDNA4).  Also selected by EOSVOS_MFMA=f32.
- * Special values (tests/test_gpu_conv_algos.py::test_bf16x6_special_values_propagate): a NaN operand gives NaN in both
- * modes; a +-inf operand gives +-inf in F32 and NaN in BF16X6 (the remainder inf - top16(inf) is NaN) -- non-finite
- * either way, which is what the meta loop's NaN-skip (meta_run.py:209-211) needs: an overflowed task shows up as a NaN
- * loss; denormal operands contribute nothing in either mode; finite values up to FLT_MAX split exactly. */
+ *   F16X3 (default): every operand TENSOR is scaled by a power of two taken from its largest finite magnitude (kept on the
+ *          device by the kernels that write the tensor), every scaled fp32 value is split into two fp16 pieces
+ *          (round to nearest: together they hold the value to <= 1 fp32 ulp) and the product is accumulated in fp32 from
+ *          the three leading partial products on v_mfma_f32_16x16x32_f16.  Error <= the fp32 MFMA's on tensors whose
+ *          elements lie within 2^16 of the largest; smaller elements lose relative precision gradually (absolute
+ *          error <= 2^-40 of the tensor's maximum each), which only shows in outputs that no large element reaches.
+ *   BF16X6: every fp32 operand is split exactly into three bf16 pieces and the product is accumulated in fp32 from the six
+ *          leading partial products on v_mfma_f32_16x16x32_bf16 (error <= fp32 MFMA's, no scaling, any dynamic range);
+ *          1.5x the LDS traffic and 2x the MFMAs of F16X3.  EOSVOS_MFMA=bf16x6.
+ *   F32:   v_mfma_f32_32x32x2_f32 (1/16 of the bf16 rate on CDNA4).  EOSVOS_MFMA=f32.
+ * Special values (tests/test_gpu_conv_algos.py::test_bf16x6_special_values_propagate, ::test_f16x3_special_values_and_
+ * dynamic_range): a NaN operand gives NaN in every mode; a +-inf operand gives +-inf in F32 and NaN in the split modes
+ * (inf - piece(inf) is NaN) -- non-finite either way, which is what the meta loop's NaN-skip (meta_run.py:209-211)
+ * needs: an overflowed task shows up as a NaN loss.  NaN / inf never set an F16X3 scale (finite values only), so the
+ * outputs they do not reach keep their accuracy.  Denormal operands contribute nothing in any mode; BF16X6 splits
+ * finite values up to FLT_MAX exactly. */
 #define EOSVOS_MATRIX_F32 0
 #define EOSVOS_MATRIX_BF16X6 1
 #define EOSVOS_MATRIX_F16X3 2

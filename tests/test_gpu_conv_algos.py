@@ -247,3 +247,29 @@ def test_f16x3_special_values_and_dynamic_range(eng):
     big = float(x[torch.isfinite(x)].abs().max())
     err = (out.double() - ref).abs()[0, :, 6, 7]
     assert float(err.max()) < 64 * 2.0 ** -40 * big * float(w.abs().max()), float(err.max())
+
+
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6', 'f32'])
+def test_finetune_trajectory_in_every_matrix_mode(mode):
+    """Three fine-tune iterations + inference at 96x160, batch 2, against the CPU oracle in each matrix mode (the other
+    GPU tests run in the default mode only): losses to 1e-4 relative, probabilities to 1e-4 absolute."""
+    from eosvos_amd import synthetic
+    from oracle import meta
+    H, W, B = 96, 160, 2
+    sd = synthetic.synthetic_state('resnet50')
+    lrs = synthetic.synthetic_lrs('resnet50')
+    x, y = synthetic.synthetic_frames(B, H, W, seed=7)
+    ref_losses, ref_state = meta.finetune(sd, lrs, [(x, y)] * 3)
+    prev = engine_mod.get_matrix_mode()
+    try:
+        engine_mod.set_matrix_mode(mode)
+        e = Engine('resnet50', H, W, max_batch=B, device=DEV)
+        e.load_model_state(sd, lrs)
+        losses = [e.finetune_step(x.to(DEV), y.to(DEV)) for _ in range(3)]
+        params = e.get_params().cpu()
+        e.close()
+    finally:
+        engine_mod.set_matrix_mode(prev)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * abs(b), (mode, losses, ref_losses)
+    assert bool(torch.isfinite(params).all())
