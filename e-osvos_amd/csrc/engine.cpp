@@ -579,6 +579,9 @@ bool wino_on(const eosvos_engine* e, int ci, int B, int Ho, int Wo) {
   if (e->force_algo == EOSVOS_ALGO_WINO_F2 || e->force_algo == EOSVOS_ALGO_WINO_F4) return e->wino_V.find(ci) != e->wino_V.end();
   if (ci == e->t.dec_a || ci == e->t.dec_b) return true;
   if (e->wino_V.find(ci) == e->wino_V.end()) return false;            // no buffers were reserved for it
+  // f16x3 mode: the matrix kernels are 1.3-1.5x faster, the HBM-bound transforms are not -- layer4's conv2 and the d = 6 ASPP
+  // conv no longer gain (same box, batch 1: 5.62 -> 5.45 ms without them, batch 3: 9.97 -> 9.93); the decoder keeps its F(4,3)
+  if (conv_mfma_mode() == 2) return false;
   return (long long)B * Ho * Wo / 4 * c.cin * c.cout >= EOSVOS_WINO_MINWORK;      // MACs of one F(2,3) position
 #endif
 }
