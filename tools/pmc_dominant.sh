@@ -47,7 +47,7 @@ with open(f'{O}/pmc_dominant_kernel.txt', 'w') as f:
     f.write(f'  corrected HBM-side traffic per launch = 2*FETCH_SIZE + WRITE_SIZE = {traffic / 1e6:.1f} MB\n')
     if 'SQ_INSTS_MFMA' in avg and 'GRBM_GUI_ACTIVE' in avg and dur:
         cyc = avg['GRBM_GUI_ACTIVE'] / 8
-        f.write(f'  MFMA-busy: {avg["SQ_INSTS_MFMA"] * 16 / 1024 / cyc * 100:.1f} % of {cyc:.0f} cycles per launch (16 cycles per v_mfma_f32_16x16x32_bf16, 1024 SIMDs) '
+        f.write(f'  MFMA-busy: {avg["SQ_INSTS_MFMA"] * 16 / 1024 / cyc * 100:.1f} % of {cyc:.0f} cycles per launch (16 cycles per v_mfma_f32_16x16x32_f16 or _bf16, 1024 SIMDs) '
                 f'(effective clock {cyc / (sum(dur) / len(dur)) :.2f} GHz)\n')
 print(open(f'{O}/pmc_dominant_kernel.txt').read())
 PY
