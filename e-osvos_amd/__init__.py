@@ -21,4 +21,4 @@ import os as _os_env
 _os_env.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 del _os_env
 
-__version__ = '0.3.0'
+__version__ = '0.5.0'

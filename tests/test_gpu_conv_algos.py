@@ -273,3 +273,33 @@ def test_finetune_trajectory_in_every_matrix_mode(mode):
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) <= 1e-4 * abs(b), (mode, losses, ref_losses)
     assert bool(torch.isfinite(params).all())
+
+
+def test_f16x3_is_invariant_under_power_of_two_reparametrisation():
+    """Scaling a conv's weights by 2^-30 and its frozen-norm scale by 2^30 leaves the network unchanged in exact arithmetic;
+    in the f16x3 mode the per-tensor scales absorb the factor exactly (same fp16 pieces), so the logits are bit-identical
+    -- tensors of any magnitude use the full precision of the split (bf16x6 / fp32 have this property trivially)."""
+    from eosvos_amd import synthetic
+    H, W = 96, 160
+    sd = synthetic.synthetic_state('resnet50')
+    lrs = synthetic.synthetic_lrs('resnet50')
+    x, _ = synthetic.synthetic_frames(1, H, W, seed=3)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for conv, bn, f in (('backbone.layer1.0.conv1', 'backbone.layer1.0.bn1', 2.0 ** -30), ('backbone.layer3.2.conv2', 'backbone.layer3.2.bn2', 2.0 ** 24)):
+        assert conv + '.weight' in sd2 and bn + '.weight' in sd2, [k for k in sd2 if 'layer1.0' in k][:8]
+        sd2[conv + '.weight'] *= f
+        # y = gamma * (conv(x) - mean) / sqrt(var + eps) + beta: scale the mean by f and gamma by 1 / f (exact: powers of two)
+        sd2[bn + '.running_mean'] *= f
+        sd2[bn + '.weight'] /= f
+    prev = engine_mod.get_matrix_mode()
+    outs = []
+    try:
+        engine_mod.set_matrix_mode('f16x3')
+        for state in (sd, sd2):
+            e = Engine('resnet50', H, W, max_batch=1, device=DEV)
+            e.load_model_state(state, lrs)
+            outs.append(e.forward(x.to(DEV)).cpu())
+            e.close()
+    finally:
+        engine_mod.set_matrix_mode(prev)
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())

@@ -40,8 +40,8 @@ __device__ __forceinline__ f32x2 unpack_f16(unsigned w) {
 }
 
 // NP 3: bf16x6.  NP 2: f16x3.
-template <int NP>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+template <int NP, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ C, int M, int N, int K, float sa, float sb) {
   constexpr int BM = 128, BN = 128, BK = 32, PITCH = 96;
   constexpr int OP_BYTES = NP * BM * PITCH;
@@ -159,14 +159,14 @@ static float pow2_scale(const std::vector<float>& v) {           // power of two
   return ldexpf(1.f, 12 - e);
 }
 
-template <int NP>
+template <int NP, int OCC = 2>
 static void run(const char* name, const float* dA, const float* dB, float* dC, int M, int N, int K, const std::vector<float>& hA,
                 const std::vector<float>& hB, float sa, float sb) {
   const int tiles = (M / 128) * (N / 128);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  auto go = [&]() { hipLaunchKernelGGL((gemm_kernel<NP>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb); };
+  auto go = [&]() { hipLaunchKernelGGL((gemm_kernel<NP, OCC>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb); };
   for (int i = 0; i < 3; ++i) go();
   CK(hipDeviceSynchronize());
   const int reps = 20;
@@ -222,6 +222,7 @@ int main(int argc, char** argv) {
     printf("data %d: scales 2^%d 2^%d\n", data, (int)log2f(sa), (int)log2f(sb));
     run<3>("bf16x6", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
     run<2>("f16x3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
+    run<2, 3>("f16x3 occ3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
     if (data == 2) run<2>("f16x3 s=1", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
   }
