@@ -493,12 +493,20 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
 }
 
 static int env_int(const char* name, int dflt);
-// Tile width in N.  EOSVOS_TUNE_BN64_TILES=t (experiment): launches with fewer than t 128x128 tiles use 128x64 tiles,
-// halving the bytes of every parked partial tile at the price of more operand staging per MFMA.
+// Tile width in N.  128 x 64 tiles (half the bytes of every parked partial tile, twice the tiles, 1.5x the LDS reads per
+// MFMA) pay for launches that have few tiles AND a short K: per-layer A/B in the f16x3 mode (tools/layer_times.py,
+// profiles/r03_bn64_layer_times.txt) -- the 1x1 convs of layer2-4 / ASPP at batch 1 gain 5-30 %, long-K 3x3 convs and
+// everything with >= 256 tiles lose.  Batch 1 only: at batch 3 the same rule makes the two-stream iteration 1.4 % slower
+// (9.97 -> 10.12 ms) although the single-stream per-layer times predict a small gain; batch 1: 5.46 -> 5.33 ms.
+// EOSVOS_TUNE_BN64_TILES / _KSTEPS move the two thresholds (0 tiles: never).
 int conv_bn(const ConvArgs& a) {
   if (a.N <= 64) return 64;
-  static const int thr = env_int("EOSVOS_TUNE_BN64_TILES", 0);
-  if (thr > 0 && conv_mfma_mode() == 1 && (long)((a.M + 127) / 128) * ((a.N + 127) / 128) < thr) return 64;
+  static const int thr = env_int("EOSVOS_TUNE_BN64_TILES", 256), kthr = env_int("EOSVOS_TUNE_BN64_KSTEPS", 40);
+  if (thr > 0 && conv_mfma_mode() == 2 && !a.plane_rows && a.B == 1) {
+    const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const long ksteps = (long)a.KH * a.KW * ((a.Kc + 31) / 32);
+    if (tiles < thr && ksteps <= kthr) return 64;
+  }
   return 128;
 }
 
@@ -1720,7 +1728,7 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget) {
   const int RES = conv_wg_budget(wg_budget) * EOSVOS_WG_OCC / EOSVOS_OCC;
   int best = 1;
   double best_eff = 0.0;
-  static const int minsteps = env_int("EOSVOS_TUNE_WG_MINSTEPS", 128 / EOSVOS_WG_BKP);
+  static const int minsteps = env_int("EOSVOS_TUNE_WG_MINSTEPS", 256 / EOSVOS_WG_BKP);   // 8 steps = 256 pixels per split (4: batch 1 +1.3 %)
   for (int s = 1; s <= 512 && steps / s >= minsteps; ++s) {
     const long wgs = (long)tiles * s;
     const long rounds = (wgs + RES - 1) / RES;

@@ -614,7 +614,8 @@ def test_groupnorm_full_size_forward_vs_oracle(weights):
 def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weights, monkeypatch):
     """MetaTrainer with extra engines (each on its own stream): three tasks in flight together give bit for bit the
     meta-gradient, losses and updated state of the same three tasks run one after the other on one engine (at the same
-    workgroup budget: the budget changes the order of split reductions)."""
+    workgroup budget and, like the engines that run side by side, on one queue: both change the K splits of the weight
+    gradients and with them the order of the split reductions)."""
     from eosvos_amd.engine import Engine
     from eosvos_amd.meta_run import CONCURRENT_WG_BUDGET, MetaTrainer
     monkeypatch.setenv('EOSVOS_META_WG_BUDGET', str(CONCURRENT_WG_BUDGET[3]))
@@ -623,6 +624,7 @@ def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weight
         x, y = synthetic.synthetic_frames(1, *SMALL, seed=2000 + t)
         xg, yg = x.to(DEV), y.to(DEV)
         tasks.append((xg, yg, torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()))
+    small_engine.set_side_stream(False)
     seq = MetaTrainer(small_engine, meta_batch_size=3)
     seq.load_state(*weights)
     l_seq = seq.meta_iteration(tasks, inner_steps=3)
@@ -643,6 +645,7 @@ def test_concurrent_tasks_on_three_engines_equal_sequential(small_engine, weight
     for e in extra:
         e.close()
     small_engine.set_wg_budget(0)
+    small_engine.set_side_stream(True)
     small_engine.load_model_state(*weights)
 
 
