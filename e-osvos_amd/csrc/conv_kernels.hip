@@ -1714,13 +1714,16 @@ static int wg_tile(int c) {
 #define EOSVOS_WG_SMALLP 2500        // pixel count below which 64x64 tiles are used (more tiles, fewer K splits)
 #endif
 // few pixels AND few tiles (stride-16 layers at batch 1): 64x64 tiles give more tiles and fewer K splits
-static bool wg_small(int P, int Cout, int Cin, int T) {
+// (f16x3 mode: never -- with the faster K loop the 64x64 tiles' extra operand staging costs more than their fewer K
+// splits save: batch 1 5.31 -> 5.23 ms without them, batch 3 unchanged)
+static bool wg_small(int P, int Cout, int Cin, int T, int mode = -1) {
   const int t128 = ((Cout + wg_tile(Cout) - 1) / wg_tile(Cout)) * ((Cin + wg_tile(Cin) - 1) / wg_tile(Cin)) * T;
-  static const int smallp = env_int("EOSVOS_TUNE_WG_SMALLP", EOSVOS_WG_SMALLP), smallt = env_int("EOSVOS_TUNE_WG_SMALLT", 256);
+  static const int smallp_env = env_int("EOSVOS_TUNE_WG_SMALLP", -1), smallt = env_int("EOSVOS_TUNE_WG_SMALLT", 256);
+  const int smallp = smallp_env >= 0 ? smallp_env : ((mode < 0 ? conv_mfma_mode() : mode) == 2 ? 0 : EOSVOS_WG_SMALLP);
   return P < smallp && t128 < (P < EOSVOS_WG_SMALLP ? 256 : smallt);
 }
-int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget) {
-  const bool small = wg_small(P, Cout, Cin, T);
+int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget, int mode) {
+  const bool small = wg_small(P, Cout, Cin, T, mode);
   const int bm = small ? 64 : wg_tile(Cout), bn = small ? 64 : wg_tile(Cin);
   const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * T;
   const int steps = (P + EOSVOS_WG_BKP - 1) / EOSVOS_WG_BKP;

@@ -1065,6 +1065,12 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
 }
 
 int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+// slab sizing: the K splits of a weight gradient depend on the matrix mode (tile rules), which may change after create
+int wgrad_max_splits(int P, int Cout, int Cin, int T, int wg_budget) {
+  int m = 1;
+  for (int mode = 0; mode <= 2; ++mode) m = std::max(m, wgrad_pick_splits(P, Cout, Cin, T, wg_budget, mode));
+  return m;
+}
 
 }  // namespace
 
@@ -1209,7 +1215,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
     (void)Md;
     for (int b = 1; b <= B; ++b)
       for (int wb = 0; wb <= 512; wb += 64)          // every budget eosvos_set_wg_budget accepts
-        slabs[ci] = max64(slabs[ci], (int64_t)wgrad_pick_splits(b * Ho * Wo, c.cout, c.cin, c.T(), wb) * c.wsize());
+        slabs[ci] = max64(slabs[ci], (int64_t)wgrad_max_splits(b * Ho * Wo, c.cout, c.cin, c.T(), wb) * c.wsize());
     bool reserve = false;
 #ifndef EOSVOS_NO_WINO
     reserve = wino_shape(c) && (ci == t.dec_a || ci == t.dec_b ||
@@ -1219,7 +1225,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
       for (int b = 1; b <= B; ++b) {
         const WinoGeom gb = wino_geom(e, c, b, Ho, Wo);
         for (int wb = 0; wb <= 512; wb += 64)
-          slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_pick_splits((int)gb.ntile, c.cout, c.cin, gb.np, wb) * c.cout * gb.np * c.cin);
+          slabs[ci] = max64(slabs[ci], c.wsize() + (int64_t)wgrad_max_splits((int)gb.ntile, c.cout, c.cin, gb.np, wb) * c.cout * gb.np * c.cin);
       }
       const WinoGeom gm = wino_geom(e, c, B, Ho, Wo);
       const int64_t prow = gm.prow, np = gm.np;
@@ -2249,12 +2255,12 @@ struct ScratchEngine {
     t.Wp = t.falloc(c.wsize()); t.na = t.falloc(Cout); t.nb = t.falloc(Cout);
     t.ws_conv = t.falloc(conv_ws_floats());
     int64_t slab = 0;
-    for (int b = 1; b <= B; ++b) slab = max64(slab, (int64_t)wgrad_pick_splits(b * Ho * Wo, Cout, Cin, k * k) * c.wsize());
+    for (int b = 1; b <= B; ++b) slab = max64(slab, (int64_t)wgrad_max_splits(b * Ho * Wo, Cout, Cin, k * k, 0) * c.wsize());
     const bool wino = algo == EOSVOS_ALGO_WINO_F2 || algo == EOSVOS_ALGO_WINO_F4;
     if (wino) {
       if (!wino_shape(c)) return;
       const WinoGeom g = wino_geom(&t, c, B, Ho, Wo);
-      slab = max64(slab, c.wsize() + (int64_t)wgrad_pick_splits((int)g.ntile, Cout, Cin, g.np) * Cout * g.np * Cin);
+      slab = max64(slab, c.wsize() + (int64_t)wgrad_max_splits((int)g.ntile, Cout, Cin, g.np, 0) * Cout * g.np * Cin);
       t.wino_V[0] = t.falloc(g.np * g.prow * Cin);
       t.wino_U[0] = t.falloc((int64_t)g.np * Cout * Cin);
       t.wino_Us[0] = t.falloc((int64_t)g.np * Cout * Cin);

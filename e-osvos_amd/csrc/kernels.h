@@ -167,7 +167,7 @@ struct WgradArgs {
   const unsigned* amax_x;
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
-int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget = 0);
+int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget = 0, int mode = -1);   // mode -1: the current matrix mode
 // grouped launch (bf16x6 mode): entries of one tile shape bm x bn = wgrad_group_tile(Cout) x wgrad_group_tile(Cin);
 // dev_map holds (entry, workgroup-of-entry) pairs, workgroup-of-entry = split * tiles + tile as in launch_wgrad
 int wgrad_group_tile(int channels);
