@@ -1473,7 +1473,13 @@ int conv_plan(ConvArgs& a) {
 #endif
     // short K, or at least one tile per CU and a K so short that the fix-up pass (a second launch, >= 10 us)
     // costs more than the idle second slot of some CUs: one whole tile per workgroup
-    const bool dp_small = tiles >= conv_wg_budget(a.wg_budget) / 2 && ksteps * EOSVOS_BK <= 256;
+    // (f16x3 mode, where a K step costs less against the fix-up pass: from a quarter of the budget in tiles and up to K = 512
+    // -- batch 1 5.23 -> 5.12 ms, batch 3 9.89 -> 9.79; tools/budget_sweep.py showed layer3's 208-tile K = 256 launches at 22 us
+    // streamed against 16 us as whole tiles)
+    static const int dps_div_env = env_int("EOSVOS_TUNE_DPSMALL_DIV", 0), dps_k_env = env_int("EOSVOS_TUNE_DPSMALL_K", 0);
+    const int dps_div = dps_div_env > 0 ? dps_div_env : (conv_mfma_mode() == 2 ? 4 : 2);
+    const int dps_k = dps_k_env > 0 ? dps_k_env : (conv_mfma_mode() == 2 ? 512 : 256);
+    const bool dp_small = tiles >= conv_wg_budget(a.wg_budget) / dps_div && ksteps * EOSVOS_BK <= dps_k;
     if ((ksteps <= EOSVOS_MINK + 1 || dp_small) && a.total_units <= 0) {
       per = ksteps; nwg = tiles;                       // no fix-up
     } else {
