@@ -953,7 +953,12 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     a.B = 1; a.Ho = 1; a.Wo = (int)ntile; a.ldg = c.cout; a.Cout = c.cout; a.Hi = 1; a.Wi = (int)ntile; a.ldx = c.cin; a.Cin = c.cin;
     a.KH = a.KW = wg.tm + 2; a.stride = 1; a.pad = 0; a.dil = 0;  // the "taps" are the Winograd positions, no pixel shift
     a.g_tap_stride = prow * c.cout; a.x_tap_stride = prow * c.cin;
-    a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, wg.np, e->wg_budget);
+    // the 16 / 36 planes already give hundreds of tiles, and every K split parks a full Winograd-domain slab that the finish
+    // kernel re-reads: plan the splits for half the workgroup budget (tools/budget_sweep.py: decoder conv at batch 3 247 -> 198 us,
+    // batch 1 90 -> 72 us)
+    static const bool wino_half = getenv("EOSVOS_TUNE_WINO_WGRAD_FULL_BUDGET") == nullptr;
+    const int wbud = wino_half ? conv_wg_budget_of(e->wg_budget) / 2 : e->wg_budget;
+    a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, wg.np, wbud);
     trace("wgrad", ci, c.cout, (long)c.cin * wg.np, ntile, a.splits);
     const int cin = c.cin, cout = c.cout;
     const bool h3 = h3_mode() && !amax_init(e);
