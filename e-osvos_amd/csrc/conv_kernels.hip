@@ -502,10 +502,11 @@ static int env_int(const char* name, int dflt);
 int conv_bn(const ConvArgs& a) {
   if (a.N <= 64) return 64;
   static const int thr = env_int("EOSVOS_TUNE_BN64_TILES", 256), kthr = env_int("EOSVOS_TUNE_BN64_KSTEPS", 40);
-  if (thr > 0 && conv_mfma_mode() == 2 && !a.plane_rows && a.B == 1) {
+  static const int kthr_anyb = env_int("EOSVOS_TUNE_BN64_ANYB_KSTEPS", 0);     // experiment: the rule at any batch for K steps <= this
+  if (thr > 0 && conv_mfma_mode() == 2 && !a.plane_rows) {
     const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long ksteps = (long)a.KH * a.KW * ((a.Kc + 31) / 32);
-    if (tiles < thr && ksteps <= kthr) return 64;
+    if (tiles < thr && ksteps <= (a.B == 1 ? kthr : kthr_anyb)) return 64;
   }
   return 128;
 }
