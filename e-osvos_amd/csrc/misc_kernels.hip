@@ -105,6 +105,10 @@ void launch_fold_norm(const float* gamma, const float* beta, const float* mean, 
 // ---- stem: 7x7 stride-2 conv, 3 -> 64, on the 3-pixel zero-padded NHWC3 frame ------------
 // One thread per output pixel, 64 accumulators; the 147x64 weight panel sits in LDS as
 // [k][cout] and is read with broadcast ds_read_b128 (every lane the same address).
+// One thread = 4 consecutive output pixels of a row x 16 output channels (64 accumulators): a weight float4 read from LDS
+// feeds 16 FMAs (the one-pixel-per-thread form read one per 4 FMAs and was LDS-bound: 125 us at batch 3), and the 39
+// contiguous input floats the 4 pixels share per filter row come in as 20 float2 loads instead of 84 scalar ones.  Same (ky, kx, c) order per output as before:
+// bit-identical results.
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ xpad,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ a,
@@ -116,49 +120,83 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     wl[i] = w[co * 147 + k];
   }
   __syncthreads();
-  const long P = (long)B * Ho * Wo;
-  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= P) return;
-  const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+  const int cg = threadIdx.x & 3;                               // channels [16 cg, 16 cg + 16)
+  const int qrow = (Wo + 3) >> 2;                               // pixel quads per output row (the last may be partial)
+  const long quad = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (quad >= (long)B * Ho * qrow) return;
+  const int qx = (int)(quad % qrow), oy = (int)((quad / qrow) % Ho), b = (int)(quad / ((long)qrow * Ho));
+  const int ox0 = qx * 4;
   const int Wp = W + 6, Hp = H + 6;
-  float acc[64];
+  const long p0 = ((long)b * Ho + oy) * Wo + ox0;
+  bool ok[4];
 #pragma unroll
-  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  for (int i = 0; i < 4; ++i) ok[i] = ox0 + i < Wo;
+  // the 4 pixels read floats [6 i, 6 i + 21) of each of their 7 input rows: 39 contiguous floats, 8-byte aligned
+  const float* xrow = xpad + (((long)b * Hp + oy * 2) * Wp + ox0 * 2) * 3;
+  const int avail = (Wp - ox0 * 2) * 3;                         // floats left in the padded row (>= 21)
+  float acc[4][16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[i][c] = 0.f;
   for (int ky = 0; ky < 7; ++ky) {
-    const float* xr = xpad + (((long)b * Hp + oy * 2 + ky) * Wp + ox * 2) * 3;
+    const float* xr = xrow + (long)ky * Wp * 3;
+    float xin[40];
+#pragma unroll
+    for (int t = 0; t < 20; ++t) {
+      float2 v = make_float2(0.f, 0.f);
+      if (2 * t + 1 < avail) v = *reinterpret_cast<const float2*>(xr + 2 * t);
+      else if (2 * t < avail) v.x = xr[2 * t];
+      xin[2 * t] = v.x; xin[2 * t + 1] = v.y;
+    }
 #pragma unroll
     for (int j = 0; j < 21; ++j) {
-      const float xv = xr[j];
-      const float4* wr = reinterpret_cast<const float4*>(wl + (ky * 21 + j) * 64);
+      const float4* wr = reinterpret_cast<const float4*>(wl + (ky * 21 + j) * 64 + cg * 16);
 #pragma unroll
-      for (int c4 = 0; c4 < 16; ++c4) {
+      for (int c4 = 0; c4 < 4; ++c4) {
         const float4 wv = wr[c4];
-        acc[c4 * 4 + 0] = fmaf(xv, wv.x, acc[c4 * 4 + 0]);
-        acc[c4 * 4 + 1] = fmaf(xv, wv.y, acc[c4 * 4 + 1]);
-        acc[c4 * 4 + 2] = fmaf(xv, wv.z, acc[c4 * 4 + 2]);
-        acc[c4 * 4 + 3] = fmaf(xv, wv.w, acc[c4 * 4 + 3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xv = xin[6 * i + j];
+          acc[i][c4 * 4 + 0] = fmaf(xv, wv.x, acc[i][c4 * 4 + 0]);
+          acc[i][c4 * 4 + 1] = fmaf(xv, wv.y, acc[i][c4 * 4 + 1]);
+          acc[i][c4 * 4 + 2] = fmaf(xv, wv.z, acc[i][c4 * 4 + 2]);
+          acc[i][c4 * 4 + 3] = fmaf(xv, wv.w, acc[i][c4 * 4 + 3]);
+        }
       }
     }
   }
-  float4* out = reinterpret_cast<float4*>(y + pix * 64);
+  float4 av[4], bv[4];
+  if (a) {
 #pragma unroll
-  for (int c4 = 0; c4 < 16; ++c4) {
-    float4 v;
-    if (a) {
-      v.x = fmaxf(acc[c4 * 4 + 0] * a[c4 * 4 + 0] + bb[c4 * 4 + 0], 0.f);
-      v.y = fmaxf(acc[c4 * 4 + 1] * a[c4 * 4 + 1] + bb[c4 * 4 + 1], 0.f);
-      v.z = fmaxf(acc[c4 * 4 + 2] * a[c4 * 4 + 2] + bb[c4 * 4 + 2], 0.f);
-      v.w = fmaxf(acc[c4 * 4 + 3] * a[c4 * 4 + 3] + bb[c4 * 4 + 3], 0.f);
-    } else {        // raw conv output (GroupNorm mode)
-      v.x = acc[c4 * 4 + 0]; v.y = acc[c4 * 4 + 1]; v.z = acc[c4 * 4 + 2]; v.w = acc[c4 * 4 + 3];
+    for (int c4 = 0; c4 < 4; ++c4) {
+      av[c4] = *reinterpret_cast<const float4*>(a + cg * 16 + c4 * 4);
+      bv[c4] = *reinterpret_cast<const float4*>(bb + cg * 16 + c4 * 4);
     }
-    out[c4] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!ok[i]) continue;
+    float4* out = reinterpret_cast<float4*>(y + (p0 + i) * 64 + cg * 16);
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      float4 v;
+      if (a) {
+        v.x = fmaxf(acc[i][c4 * 4 + 0] * av[c4].x + bv[c4].x, 0.f);
+        v.y = fmaxf(acc[i][c4 * 4 + 1] * av[c4].y + bv[c4].y, 0.f);
+        v.z = fmaxf(acc[i][c4 * 4 + 2] * av[c4].z + bv[c4].z, 0.f);
+        v.w = fmaxf(acc[i][c4 * 4 + 3] * av[c4].w + bv[c4].w, 0.f);
+      } else {        // raw conv output (GroupNorm mode)
+        v.x = acc[i][c4 * 4 + 0]; v.y = acc[i][c4 * 4 + 1]; v.z = acc[i][c4 * 4 + 2]; v.w = acc[i][c4 * 4 + 3];
+      }
+      out[c4] = v;
+    }
   }
 }
 void launch_stem_fwd(const float* xpad, const float* w, const float* a, const float* b, float* y, int B,
                      int H, int W, int Ho, int Wo, hipStream_t s) {
-  const long P = (long)B * Ho * Wo;
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, xpad, w, a, b, y,
+  const long Q = (long)B * Ho * ((Wo + 3) / 4);        // pixel quads; 64 per workgroup
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(256), 0, s, xpad, w, a, b, y,
                      B, H, W, Ho, Wo);
 }
 
