@@ -1308,6 +1308,15 @@ void launch_absmax(const float* x, long rows, int C, int ld, unsigned* slot, hip
   g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
   hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (int)rows, C4, ld, txs, slot);
 }
+// zero the slots [first, first + count): all AMAX_SUB words of each (hipMemset2DAsync does the same in 3 launches)
+__global__ __launch_bounds__(256) void amax_zero_kernel(unsigned* __restrict__ first, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count * AMAX_SUB) first[(size_t)(i / count) * AMAX_ROW + (i % count)] = 0u;
+}
+void launch_amax_zero(unsigned* first, int count, hipStream_t s) {
+  if (count < 1) return;
+  hipLaunchKernelGGL(amax_zero_kernel, dim3((unsigned)((count * AMAX_SUB + 255) / 256)), dim3(256), 0, s, first, count);
+}
 // one launch for many dense tensors (the weights): segment blockIdx.y = floats [off[y], off[y] + n[y]) of base
 __global__ __launch_bounds__(256) void absmax_segments_kernel(const float* __restrict__ base, const long* __restrict__ off,
                                                               const int* __restrict__ n, unsigned* __restrict__ slots) {

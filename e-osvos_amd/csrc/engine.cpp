@@ -327,9 +327,7 @@ inline size_t amax_tcol(const eosvos_engine* e, int phase, int idx) {
   return (phase == 0 ? 2 : 4) * e->t.convs.size() + (size_t)phase * eosvos_engine::TSLOTS + idx;
 }
 // zero the slots [first, first + count) (all their words)
-inline void amax_zero(unsigned* first, size_t count, hipStream_t st) {
-  (void)hipMemset2DAsync(first, (size_t)AMAX_ROW * 4, 0, count * 4, AMAX_SUB, st);
-}
+inline void amax_zero(unsigned* first, size_t count, hipStream_t st) { launch_amax_zero(first, (int)count, st); }
 inline bool h3_mode() { return conv_mfma_mode() == 2; }
 int amax_init(eosvos_engine* e) {
   if (e->amax) return 0;

@@ -142,6 +142,8 @@ double wgrad_exec_frac(const struct WgradArgs& a);
 int conv_mfma_mode();                // 1: bf16x6 split kernels (default), 0: fp32 MFMA kernels (EOSVOS_MFMA=f32), 2: f16x3 (EOSVOS_MFMA=f16x3)
 // max|x| over rows x C floats (row pitch ld): atomicMax of the bit patterns into *slot (the caller zeroes the slot first)
 void launch_absmax(const float* x, long rows, int C, int ld, unsigned* slot, hipStream_t s);
+// zero `count` consecutive absmax slots (every word of each)
+void launch_amax_zero(unsigned* first, int count, hipStream_t s);
 // many dense tensors in one launch: segment y = floats [dev_off[y], dev_off[y] + dev_n[y]) of base (dev_n % 4 == 0) -> slots[y]
 void launch_absmax_segments(const float* base, const long* dev_off, const int* dev_n, int nseg, unsigned* slots, hipStream_t s);
 // calibration: back-to-back fp32 MFMAs, returns the FLOPs the launch performs
