@@ -39,6 +39,28 @@ __device__ __forceinline__ f32x2 unpack_f16(unsigned w) {
   return __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
 }
 
+
+// split with the mixed-precision FMA instructions: h0 = rn16(a * s) in one v_fma_mixlo/hi_f16 per element, the remainder
+// a * s - h0 in one v_fma_mix_f32 (fp16 operand read in place), h1 = rn16(remainder): 2.5 VALU ops per element instead of 4
+__device__ __forceinline__ unsigned mix_pack(float e0, float e1, float s) {
+  unsigned d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(e0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(e1), "v"(s));
+  return d;
+}
+__device__ __forceinline__ float mix_res_lo(float e, float s, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(e), "v"(s), "v"(h));
+  return r;
+}
+__device__ __forceinline__ float mix_res_hi(float e, float s, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(e), "v"(s), "v"(h));
+  return r;
+}
+#ifndef USE_MIX
+#define USE_MIX 0
+#endif
 // NP 3: bf16x6.  NP 2: f16x3.
 template <int NP, int OCC = 2>
 __global__ __launch_bounds__(256, OCC) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
@@ -79,13 +101,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const float* __restrict_
           if (p + 1 < 3) { v.x -= trunc_bf16(v.x); v.y -= trunc_bf16(v.y); v.z -= trunc_bf16(v.z); v.w -= trunc_bf16(v.w); }
         }
       } else {
-        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
         uint2 w0, w1;
+        if (USE_MIX) {
+          w0.x = mix_pack(v.x, v.y, s);
+          w0.y = mix_pack(v.z, v.w, s);
+          w1.x = pack_f16(mix_res_lo(v.x, s, w0.x), mix_res_hi(v.y, s, w0.x));
+          w1.y = pack_f16(mix_res_lo(v.z, s, w0.y), mix_res_hi(v.w, s, w0.y));
+        } else {
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
         w0.x = pack_f16(v.x, v.y);
         w0.y = pack_f16(v.z, v.w);
         const f32x2 b0 = unpack_f16(w0.x), b1 = unpack_f16(w0.y);
         w1.x = pack_f16(v.x - b0.x, v.y - b0.y);
         w1.y = pack_f16(v.z - b1.x, v.w - b1.y);
+        }
         *reinterpret_cast<uint2*>(S + rr * PITCH + c4 * 8) = w0;
         *reinterpret_cast<uint2*>(S + BM * PITCH + rr * PITCH + c4 * 8) = w1;
       }
@@ -151,6 +180,111 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const float* __restrict_
       }
 }
 
+
+// Variant: the B operand (weights, [N][K] row-major) never touches LDS -- every wave loads the 8 k of its fragment lanes
+// straight from global memory (2 float4 per 16-column fragment), splits them in registers and feeds the MFMAs; only A is
+// staged.  Halves the LDS bytes per K step; B is loaded twice per workgroup (the two waves that share the columns).
+__global__ __launch_bounds__(256, 2) void gemm_bdirect_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                              float* __restrict__ C, int M, int N, int K, float sa, float sb) {
+  constexpr int BM = 128, BN = 128, BK = 32, PITCH = 96, NP = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NP * BM * PITCH];
+  unsigned char* As = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int c4 = tid & 7;
+  const int j = lane >> 3;
+  const int row = (wave << 3) + ((j & 1) << 1) + ((j >> 1) & 1) + (j & 4);
+  const int r = lane & 15, q = lane >> 4;
+  float4 ra[4], rb[4][2];
+  auto load = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* p = B + (size_t)(n0 + wn * 64 + t * 16 + r) * K + ks * BK + q * 8;
+      rb[t][0] = *reinterpret_cast<const float4*>(p);
+      rb[t][1] = *reinterpret_cast<const float4*>(p + 4);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = row + 32 * i;
+      float4 v = ra[i];
+      v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
+      uint2 w0, w1;
+      w0.x = pack_f16(v.x, v.y); w0.y = pack_f16(v.z, v.w);
+      const f32x2 b0 = unpack_f16(w0.x), b1 = unpack_f16(w0.y);
+      w1.x = pack_f16(v.x - b0.x, v.y - b0.y); w1.y = pack_f16(v.z - b1.x, v.w - b1.y);
+      *reinterpret_cast<uint2*>(As + rr * PITCH + c4 * 8) = w0;
+      *reinterpret_cast<uint2*>(As + BM * PITCH + rr * PITCH + c4 * 8) = w1;
+    }
+  };
+  uint4 fb[4][NP];
+  auto split_b = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v[8] = {rb[t][0].x * sb, rb[t][0].y * sb, rb[t][0].z * sb, rb[t][0].w * sb, rb[t][1].x * sb, rb[t][1].y * sb, rb[t][1].z * sb, rb[t][1].w * sb};
+      unsigned h0[4], h1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h0[e] = pack_f16(v[2 * e], v[2 * e + 1]);
+        const f32x2 u = unpack_f16(h0[e]);
+        h1[e] = pack_f16(v[2 * e] - u.x, v[2 * e + 1] - u.y);
+      }
+      fb[t][0] = make_uint4(h0[0], h0[1], h0[2], h0[3]);
+      fb[t][1] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+    }
+  };
+  const int nk = K / BK;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+  load(0);
+  store_a(); split_b();
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) load(ks + 1);
+    __builtin_amdgcn_s_setprio(1);
+    uint4 fa[4][NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t][p] = *reinterpret_cast<const uint4*>(As + p * BM * PITCH + (wm * 64 + t * 16 + r) * PITCH + q * 16);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        f32x4 c = acc[tm][tn];
+        MH(fa[tm][1], fb[tn][0]); MH(fa[tm][0], fb[tn][1]); MH(fa[tm][0], fb[tn][0]);
+        acc[tm][tn] = c;
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (more) { store_a(); split_b(); }
+    __syncthreads();
+  }
+  const float inv = 1.f / (sa * sb);
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + tm * 16 + 4 * q + e;
+        const int n = n0 + wn * 64 + tn * 16 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e] * inv;
+      }
+}
+
 static float pow2_scale(const std::vector<float>& v) {           // power of two that puts the maximum in [2^11, 2^12)
   float mx = 0;
   for (float x : v) mx = fmaxf(mx, fabsf(x));
@@ -166,7 +300,10 @@ static void run(const char* name, const float* dA, const float* dB, float* dC, i
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  auto go = [&]() { hipLaunchKernelGGL((gemm_kernel<NP, OCC>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb); };
+  auto go = [&]() {
+    if (OCC == 9) hipLaunchKernelGGL(gemm_bdirect_kernel, dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
+    else hipLaunchKernelGGL((gemm_kernel<NP, OCC == 9 ? 2 : OCC>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
+  };
   for (int i = 0; i < 3; ++i) go();
   CK(hipDeviceSynchronize());
   const int reps = 20;
@@ -223,6 +360,7 @@ int main(int argc, char** argv) {
     run<3>("bf16x6", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
     run<2>("f16x3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
     run<2, 3>("f16x3 occ3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
+    run<2, 9>("f16x3 Bdir", dA, dB, dC, M, N, K, hA, hB, sa, sb);
     if (data == 2) run<2>("f16x3 s=1", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
   }
