@@ -285,6 +285,119 @@ __global__ __launch_bounds__(256, 2) void gemm_bdirect_kernel(const float* __res
       }
 }
 
+
+// Variant: B (the weights) is split ONCE into two fp16 planes in HBM (prep kernel; 4 bytes per element like the fp32
+// original); the GEMM loads 16-byte pieces of the planes and writes them to LDS untouched -- no B-side VALU work.
+__global__ void presplit_kernel(const float* __restrict__ B, unsigned* __restrict__ P0, unsigned* __restrict__ P1, long n2, float sb) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;      // pair index
+  if (i >= n2) return;
+  const float a = B[2 * i] * sb, b = B[2 * i + 1] * sb;
+  const unsigned h0 = pack_f16(a, b);
+  const f32x2 u = unpack_f16(h0);
+  P0[i] = h0;
+  P1[i] = pack_f16(a - u.x, b - u.y);
+}
+__global__ __launch_bounds__(256, 2) void gemm_bpre_kernel(const float* __restrict__ A, const uint4* __restrict__ P0, const uint4* __restrict__ P1,
+                                                           float* __restrict__ C, int M, int N, int K, float sa, float sb) {
+  constexpr int BM = 128, BN = 128, BK = 32, PITCH = 96, NP = 2;
+  constexpr int OP_BYTES = NP * BM * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP_BYTES];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + OP_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int c4 = tid & 7;
+  const int j = lane >> 3;
+  const int row = (wave << 3) + ((j & 1) << 1) + ((j >> 1) & 1) + (j & 4);
+  const int brow = tid >> 2, bkq = tid & 3;                 // B: 64 rows x 4 sixteen-byte slots per pass, 2 passes per plane
+  const int K8 = K / 8;
+  float4 ra[4];
+  uint4 rb[4];
+  auto load = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 32 * i) * K + ks * BK + c4 * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rb[i] = P0[(size_t)(n0 + brow + 64 * i) * K8 + ks * 4 + bkq];
+      rb[2 + i] = P1[(size_t)(n0 + brow + 64 * i) * K8 + ks * 4 + bkq];
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = row + 32 * i;
+      float4 v = ra[i];
+      v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
+      uint2 w0, w1;
+      w0.x = pack_f16(v.x, v.y); w0.y = pack_f16(v.z, v.w);
+      const f32x2 b0 = unpack_f16(w0.x), b1 = unpack_f16(w0.y);
+      w1.x = pack_f16(v.x - b0.x, v.y - b0.y); w1.y = pack_f16(v.z - b1.x, v.w - b1.y);
+      *reinterpret_cast<uint2*>(As + rr * PITCH + c4 * 8) = w0;
+      *reinterpret_cast<uint2*>(As + BM * PITCH + rr * PITCH + c4 * 8) = w1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(Bs + (brow + 64 * i) * PITCH + bkq * 16) = rb[i];
+      *reinterpret_cast<uint4*>(Bs + BN * PITCH + (brow + 64 * i) * PITCH + bkq * 16) = rb[2 + i];
+    }
+  };
+  const int nk = K / BK;
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+  load(0);
+  store();
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) load(ks + 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn) {
+      uint4 fa[4][NP], fb[2][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t][p] = *reinterpret_cast<const uint4*>(As + p * BM * PITCH + (wm * 64 + t * 16 + r) * PITCH + q * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[t][p] = *reinterpret_cast<const uint4*>(Bs + p * BM * PITCH + (wn * 64 + (hn * 2 + t) * 16 + r) * PITCH + q * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x4 c = acc[tm][hn * 2 + tn];
+          MH(fa[tm][1], fb[tn][0]); MH(fa[tm][0], fb[tn][1]); MH(fa[tm][0], fb[tn][0]);
+          acc[tm][hn * 2 + tn] = c;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (more) store();
+    __syncthreads();
+  }
+  const float inv = 1.f / (sa * sb);
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + tm * 16 + 4 * q + e;
+        const int n = n0 + wn * 64 + tn * 16 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e] * inv;
+      }
+}
+static unsigned *g_P0 = nullptr, *g_P1 = nullptr;
+
 static float pow2_scale(const std::vector<float>& v) {           // power of two that puts the maximum in [2^11, 2^12)
   float mx = 0;
   for (float x : v) mx = fmaxf(mx, fabsf(x));
@@ -302,7 +415,8 @@ static void run(const char* name, const float* dA, const float* dB, float* dC, i
   CK(hipEventCreate(&e1));
   auto go = [&]() {
     if (OCC == 9) hipLaunchKernelGGL(gemm_bdirect_kernel, dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
-    else hipLaunchKernelGGL((gemm_kernel<NP, OCC == 9 ? 2 : OCC>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
+    else if (OCC == 8) hipLaunchKernelGGL(gemm_bpre_kernel, dim3(tiles), dim3(256), 0, 0, dA, (const uint4*)g_P0, (const uint4*)g_P1, dC, M, N, K, sa, sb);
+    else hipLaunchKernelGGL((gemm_kernel<NP, OCC >= 8 ? 2 : OCC>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
   };
   for (int i = 0; i < 3; ++i) go();
   CK(hipDeviceSynchronize());
@@ -360,7 +474,14 @@ int main(int argc, char** argv) {
     run<3>("bf16x6", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
     run<2>("f16x3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
     run<2, 3>("f16x3 occ3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
-    run<2, 9>("f16x3 Bdir", dA, dB, dC, M, N, K, hA, hB, sa, sb);
+    {
+      const long n2 = (long)N * K / 2;
+      CK(hipMalloc(&g_P0, n2 * 4)); CK(hipMalloc(&g_P1, n2 * 4));
+      hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, 0, dB, g_P0, g_P1, n2, sb);
+      CK(hipDeviceSynchronize());
+      run<2, 8>("f16x3 Bpre", dA, dB, dC, M, N, K, hA, hB, sa, sb);
+      CK(hipFree(g_P0)); CK(hipFree(g_P1));
+    }
     if (data == 2) run<2>("f16x3 s=1", dA, dB, dC, M, N, K, hA, hB, 1.f, 1.f);
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
   }
