@@ -491,6 +491,97 @@ __global__ __launch_bounds__(256, 2) void gemm_pf2_kernel(const float* __restric
         C[(size_t)m * N + n] = acc[tm][tn][e] * inv;
       }
 }
+
+// Variant: K step of 64 (half the barriers / LDS turnarounds per FLOP), 144-byte row pitch, still 2 workgroups per CU.
+__global__ __launch_bounds__(256, 2) void gemm_bk64_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                           float* __restrict__ C, int M, int N, int K, float sa, float sb) {
+  constexpr int BM = 128, BN = 128, BK = 64, PITCH = 144, NP = 2;
+  constexpr int OP_BYTES = NP * BM * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP_BYTES];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + OP_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int c4 = tid & 15, row = tid >> 4;            // 16 float4 per 64-k row, 16 rows per pass, 8 passes
+  float4 ra[8], rb[8];
+  auto load = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row + 16 * i) * K + ks * BK + c4 * 4);
+      rb[i] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row + 16 * i) * K + ks * BK + c4 * 4);
+    }
+  };
+  auto store_op = [&](unsigned char* S, const float4* rv, float sc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = row + 16 * i;
+      float4 v = rv[i];
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      uint2 w0, w1;
+      w0.x = pack_f16(v.x, v.y); w0.y = pack_f16(v.z, v.w);
+      const f32x2 b0 = unpack_f16(w0.x), b1 = unpack_f16(w0.y);
+      w1.x = pack_f16(v.x - b0.x, v.y - b0.y); w1.y = pack_f16(v.z - b1.x, v.w - b1.y);
+      *reinterpret_cast<uint2*>(S + rr * PITCH + c4 * 8) = w0;
+      *reinterpret_cast<uint2*>(S + BM * PITCH + rr * PITCH + c4 * 8) = w1;
+    }
+  };
+  const int nk = K / BK;
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+  load(0);
+  store_op(As, ra, sa); store_op(Bs, rb, sb);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) load(ks + 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn) {
+      uint4 fa[4][NP], fb[2][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t][p] = *reinterpret_cast<const uint4*>(As + p * BM * PITCH + (wm * 64 + t * 16 + r) * PITCH + g * 64 + q * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[t][p] = *reinterpret_cast<const uint4*>(Bs + p * BM * PITCH + (wn * 64 + (hn * 2 + t) * 16 + r) * PITCH + g * 64 + q * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          f32x4 c = acc[tm][hn * 2 + tn];
+          MH(fa[tm][1], fb[tn][0]); MH(fa[tm][0], fb[tn][1]); MH(fa[tm][0], fb[tn][0]);
+          acc[tm][hn * 2 + tn] = c;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (more) { store_op(As, ra, sa); store_op(Bs, rb, sb); }
+    __syncthreads();
+  }
+  const float inv = 1.f / (sa * sb);
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + tm * 16 + 4 * q + e;
+        const int n = n0 + wn * 64 + tn * 16 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e] * inv;
+      }
+}
 static unsigned *g_P0 = nullptr, *g_P1 = nullptr;
 
 static float pow2_scale(const std::vector<float>& v) {           // power of two that puts the maximum in [2^11, 2^12)
@@ -510,9 +601,10 @@ static void run(const char* name, const float* dA, const float* dB, float* dC, i
   CK(hipEventCreate(&e1));
   auto go = [&]() {
     if (OCC == 9) hipLaunchKernelGGL(gemm_bdirect_kernel, dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
+    else if (OCC == 6) hipLaunchKernelGGL(gemm_bk64_kernel, dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
     else if (OCC == 7) hipLaunchKernelGGL(gemm_pf2_kernel, dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
     else if (OCC == 8) hipLaunchKernelGGL(gemm_bpre_kernel, dim3(tiles), dim3(256), 0, 0, dA, (const uint4*)g_P0, (const uint4*)g_P1, dC, M, N, K, sa, sb);
-    else hipLaunchKernelGGL((gemm_kernel<NP, OCC >= 7 ? 2 : OCC>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
+    else hipLaunchKernelGGL((gemm_kernel<NP, OCC >= 6 ? 2 : OCC>), dim3(tiles), dim3(256), 0, 0, dA, dB, dC, M, N, K, sa, sb);
   };
   for (int i = 0; i < 3; ++i) go();
   CK(hipDeviceSynchronize());
@@ -571,6 +663,7 @@ int main(int argc, char** argv) {
     run<2>("f16x3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
     run<2, 3>("f16x3 occ3", dA, dB, dC, M, N, K, hA, hB, sa, sb);
     run<2, 7>("f16x3 pf2", dA, dB, dC, M, N, K, hA, hB, sa, sb);
+    run<2, 6>("f16x3 bk64", dA, dB, dC, M, N, K, hA, hB, sa, sb);
     {
       const long n2 = (long)N * K / 2;
       CK(hipMalloc(&g_P0, n2 * 4)); CK(hipMalloc(&g_P1, n2 * 4));
