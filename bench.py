@@ -143,6 +143,9 @@ def roofline_from(rows, steps, mode, lib_version, batch, ms_per_step):
         'peak_basis': (f'dense 16-bit MFMA peak 2500 TFLOP/s / {MFMAS_PER_FMA[mode]} MFMAs per fp32 multiply-accumulate in the '
                        f'{mode} mode (fp32-equivalent)' if mode in MFMAS_PER_FMA else 'fp32 MFMA peak'),
         'frac_of_bf16x6_roof': achieved / (BF16_DENSE_PEAK / 6.0),      # the yardstick of rounds 2-3 (416.7 TFLOP/s)
+        # what the same MFMA stream reaches with its fragments in registers (no memory at all) on random operands -- the chip is
+        # power-limited (profiles/r03_h3_phases_probe.txt: f16x3 516, constant operands 753; r02_x6_phases_probe.txt: bf16x6 305)
+        'measured_mfma_only_tflops': {'f16x3': 516.0, 'bf16x6': 305.0}.get(mode),
         'achieved_is': 'executed fp32-equivalent FLOPs of all launches of this kernel symbol in the profiled steps / their '
                        'summed HIP-event durations (padding taps skipped by the tap tables are not counted)',
         'launches_per_step': launches / steps, 'avg_launch_us': 1e3 * ms / launches,
