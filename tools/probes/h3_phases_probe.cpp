@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256, 2) void phase_kernel(const float* __restrict__
   const int c4 = tid & 7, j = lane >> 3;
   const int row = (wave << 3) + ((j & 1) << 1) + ((j >> 1) & 1) + (j & 4);
   const int r = lane & 15, q = lane >> 4;
+#ifdef SHARED_STRIP
+  const size_t base = (size_t)(blockIdx.x % SHARED_STRIP) * 128 * K;      // the workgroups share SHARED_STRIP operand strips: L2-resident
+#else
   const size_t base = (size_t)blockIdx.x * 128 * K;
+#endif
   float4 ra[4], rb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
