@@ -426,8 +426,13 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   const long sk0 = (long)p.dp_q * p.nwg * ksteps;
   const long a = p.tprefix ? (long)p.tprefix[tile] : (long)tile * ksteps;
   const long b = p.tprefix ? (long)p.tprefix[tile + 1] : a + ksteps;
-  const int g0 = (int)((a - sk0) / p.per), g1 = (int)((b - 1 - sk0) / p.per);
-  if (g0 == g1) return;                       // computed whole by one workgroup
+  // contributors: stream-K -- the workgroups g0..g1 whose unit runs touch the tile; split-K -- workgroups c * tiles + tile
+  const int tiles_all = ((p.M + BM - 1) / BM) * nt;
+  int g0 = 0, g1 = p.splitk - 1;
+  if (p.splitk == 0) {
+    g0 = (int)((a - sk0) / p.per); g1 = (int)((b - 1 - sk0) / p.per);
+    if (g0 == g1) return;                       // computed whole by one workgroup
+  }
   const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
   constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
   const int c_c4 = threadIdx.x % CF4, c_r = threadIdx.x / CF4;
@@ -459,8 +464,9 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
     float4 t[4][RPB];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int gi = g + i <= g1 ? g + i : g1;
-      const int slot = (sk0 + (long)gi * p.per >= a) ? 0 : 1;
+      const int gc = g + i <= g1 ? g + i : g1;
+      const int gi = p.splitk ? gc * tiles_all + tile : gc;
+      const int slot = (p.splitk || sk0 + (long)gi * p.per >= a) ? 0 : 1;
 #pragma unroll
       for (int j = 0; j < RPB; ++j)
         t[i][j] = ldg4(p.ws + ((size_t)gi * 2 + slot) * (BM * BN) + rows[j] * BN + c_c4 * 4);
@@ -789,6 +795,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
   }
 
   unsigned ymax = 0;           // f16x3: absmax of what this workgroup writes (-> p.amax_y)
+  bool splitk_pending = p.splitk > 0;
   for (long u = u_begin;;) {
     int tile, ks_begin, ks_end = ksteps;
     const bool dp = dp_i < p.dp_q;
@@ -797,6 +804,16 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
       ks_begin = 0;
       ++dp_i;
       if (tile >= tiles) continue;
+    } else if (p.splitk > 0) {
+      // uniform split-K, chunk-major: the workgroups of an XCD (consecutive bid) work on the SAME K chunk of neighbouring
+      // tiles at the same time, so the weight slice of a chunk is fetched into the XCD's L2 once instead of once per workgroup
+      if (!splitk_pending) break;
+      splitk_pending = false;
+      tile = bid % tiles;
+      const int c = bid / tiles;
+      const int n_t = p.tprefix ? p.tprefix[tile + 1] - p.tprefix[tile] : ksteps;
+      ks_begin = (int)((long)c * n_t / p.splitk);
+      ks_end = (int)((long)(c + 1) * n_t / p.splitk);
     } else if (u < u_end) {
       if (p.tprefix) {
         int lo = 0, hi = tiles - 1;
@@ -962,7 +979,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
 
     // ---- epilogue: accumulators -> LDS tile -> full-row float4 stores ------------------------
     float* Cs = reinterpret_cast<float*>(smem);
-    const bool full = (ks_begin == 0 && ks_end == ks_total);
+    const bool full = p.splitk == 0 && ks_begin == 0 && ks_end == ks_total;
     constexpr int CF4 = BN / 4, CROWS = 256 / CF4;
     const int c_c4 = tid % CF4, c_r = tid / CF4;
     const int n = n0 + c_c4 * 4;
@@ -1499,6 +1516,24 @@ int conv_plan(ConvArgs& a) {
       nwg = (U + per - 1) / per;
     }
   }
+  a.splitk = 0;
+  {
+    // Long-K launches with few tiles: uniform split-K in chunk-major workgroup order instead of stream-K (see conv_xs_body).
+    // Stream-K gives every workgroup its own K range of one tile -- no two workgroups of an XCD ever want the same operand
+    // bytes, everything comes from the Infinity Cache; here they share the chunk's weight slice through L2.
+    // Measured per launch (tools/layer_times.py, batch 3, one stream): the 3x3 convs of layer2 / layer3 - 7...10 %, layer4's
+    // K = 2048 1x1 convs - 5...10 %, the d = 6 ASPP conv 187 -> 140 us; tap-table launches whose tiles keep very different
+    // numbers of taps (d = 18: 100 -> 135 us) stay with stream-K, which balances them exactly.
+    static const int on = env_int("EOSVOS_TUNE_SPLITK", 1), min_avg = env_int("EOSVOS_TUNE_SPLITK_MINK", 16);
+    const bool even_taps = a.total_units <= 0 || a.total_units * 100 >= 85L * tiles * ksteps;
+    const long budget = conv_wg_budget(a.wg_budget);
+    const long avg = a.total_units > 0 ? a.total_units / tiles : ksteps;
+    const long S = tiles > 0 ? budget / tiles : 0;
+    if (on && conv_mfma_mode() == 2 && !a.deep && even_taps && q == 0 && per > 0 && per < avg && S >= 2 && avg >= min_avg && avg / S >= 12 &&
+        tiles * S * 100 >= 85 * budget) {
+      a.splitk = (int)S; nwg = tiles * S; per = 0;
+    }
+  }
   a.dp_q = (int)q; a.per = (int)per; a.nwg = (int)nwg;
   return (int)nwg;
 }
@@ -1546,7 +1581,7 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const int bk = a.deep == 2 ? EOSVOS_BK_DEEP : EOSVOS_BK;
   const long ksteps = (long)T * ((a.Kc + bk - 1) / bk);
   const long sk_tiles = tiles - (long)a.dp_q * nwg;
-  if (a.per > 0 && sk_tiles > 0 && (a.per % ksteps != 0 || a.tprefix)) {   // some tile is shared between workgroups
+  if (a.splitk > 1 || (a.per > 0 && sk_tiles > 0 && (a.per % ksteps != 0 || a.tprefix))) {   // some tile is shared between workgroups
     ProfScope ps(16, 0.0, s);
     if (bn == 128) hipLaunchKernelGGL((conv_fixup_kernel<128>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);
     else hipLaunchKernelGGL((conv_fixup_kernel<64>), dim3((unsigned)sk_tiles, 8), block, 0, s, a);

@@ -100,6 +100,7 @@ struct ConvArgs {
   long total_units;     // sum of valid K steps when tprefix is set, else 0
   int deep;             // set by conv_plan: 1 / 2 = the 3-workgroups-per-CU kernel variants (K step 32 single stage / 16)
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
+  int splitk;           // set by conv_plan: > 0 = uniform split-K, workgroup b takes K chunk b / tiles of tile b % tiles
   int wg_budget;        // workgroups the launch may plan for (0: two per CU); engines that run beside others split less
   // f16x3 mode: device words holding the bit pattern of max|x| over the gather source, over the weights as passed in `w`
   // (all planes of a batched GEMM) and -- data gradient -- over `kscale`; see launch_absmax
