@@ -1533,6 +1533,13 @@ int conv_plan(ConvArgs& a) {
     if (on && conv_mfma_mode() == 2 && !a.deep && even_taps && q == 0 && per > 0 && per < avg && S >= 2 && avg >= min_avg && avg / S >= min_chunk &&
         tiles * S * 100 >= (long)min_fill * budget) {
       a.splitk = (int)S; nwg = tiles * S; per = 0;
+    } else {
+      // experiment: one whole tile per workgroup (no slabs, no fix-up) when the tiles alone fill s1_fill % of the budget
+      static const int s1_fill = env_int("EOSVOS_TUNE_SPLITK_S1_FILL", 0);
+      if (s1_fill > 0 && on && conv_mfma_mode() == 2 && !a.deep && a.total_units <= 0 && q == 0 && per > 0 && per < avg && S == 1 &&
+          tiles * 100 >= (long)s1_fill * budget) {
+        per = ksteps; nwg = tiles;
+      }
     }
   }
   a.dp_q = (int)q; a.per = (int)per; a.nwg = (int)nwg;
