@@ -800,10 +800,14 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
     int tile, ks_begin, ks_end = ksteps;
     const bool dp = dp_i < p.dp_q;
     if (dp) {
-      tile = dp_i * (int)gridDim.x + bid;
+      // tap-table launch dealt out as whole tiles, longest first (p.torder); odd rounds run backwards so that the
+      // workgroups with the longest first tile get the shortest second one
+      const int idx = dp_i * (int)gridDim.x + ((p.torder && (dp_i & 1)) ? (int)gridDim.x - 1 - bid : bid);
       ks_begin = 0;
       ++dp_i;
-      if (tile >= tiles) continue;
+      if (idx >= tiles) continue;
+      tile = p.torder ? p.torder[idx] : idx;
+      if (p.tprefix) ks_end = p.tprefix[tile + 1] - p.tprefix[tile];
     } else if (p.splitk > 0) {
       // uniform split-K, chunk-major: the workgroups of an XCD (consecutive bid) work on the SAME K chunk of neighbouring
       // tiles at the same time, so the weight slice of a chunk is fetched into the XCD's L2 once instead of once per workgroup
@@ -1486,7 +1490,13 @@ int conv_plan(ConvArgs& a) {
 #endif
   if (a.deep == 2) ksteps = (long)T * ((a.Kc + EOSVOS_BK_DEEP - 1) / EOSVOS_BK_DEEP);
   long nwg = a.deep ? CONV_MAX_WG_DEEP : conv_wg_budget(a.wg_budget), q = 0, per = 0;
-  if (tiles >= nwg && a.total_units <= 0) {
+  static const int tap_whole = env_int("EOSVOS_TUNE_TAP_WHOLE", 1);
+  if (tap_whole && x6 && a.total_units > 0 && a.torder && tiles >= nwg) {
+    // uneven tiles (tap table), at least one per workgroup: whole tiles, longest first, no parked partial tiles and no
+    // fix-up pass (the stride-2 3x3 data gradient at batch 3: 602 tiles of 4 / 8 / 8 / 16 K steps; streamed, nearly every
+    // workgroup parked two slabs: 70 + 20 us)
+    q = (tiles + nwg - 1) / nwg; per = 0;
+  } else if (tiles >= nwg && a.total_units <= 0) {
     q = tiles / nwg;
     const long rem = tiles - q * nwg;
     if (rem > 0) {

@@ -228,7 +228,7 @@ struct eosvos_engine {
   std::vector<float*> zbuf;           // GN: raw conv outputs (then, in backward, their gradients), dense [B*Ho*Wo][cout]
   std::vector<float*> gn_stats;       // GN: per conv {mean, rstd} per (image, group)
   float *gn_sums = nullptr, *gn_partial = nullptr;
-  struct TapTab { int* prefix; int* mask; long total; };
+  struct TapTab { int* prefix; int* mask; long total; int* order; };
   std::map<long, TapTab> tap_tabs;    // (conv, fwd/dgrad, batch) -> compacted K-step table of a dilated conv
   // Grouped weight gradients: the convs of ResNet layer1..3 only queue their WgradArgs; when the stage's data-gradient
   // chain is queued, one launch per tile shape computes all of them (plan_wgrad_group)
@@ -498,16 +498,22 @@ void attach_tap_table(eosvos_engine* e, int ci, int kind, int B, ConvArgs& a) {
     ConvArgs probe = a;
     probe.par = s2_dgrad ? 1 : 0;
     const long total = conv_build_tap_table(probe, prefix, mask);
-    eosvos_engine::TapTab tt{nullptr, nullptr, total};
+    eosvos_engine::TapTab tt{nullptr, nullptr, total, nullptr};
     tt.prefix = (int*)e->falloc((int64_t)prefix.size());
     tt.mask = (int*)e->falloc((int64_t)mask.size());
-    if (!tt.prefix || !tt.mask) return;
+    tt.order = (int*)e->falloc((int64_t)mask.size());
+    if (!tt.prefix || !tt.mask || !tt.order) return;
+    // tiles by descending K steps: the whole-tile plan deals them out longest first (conv_plan, launches with >= budget tiles)
+    std::vector<int> order(mask.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return prefix[x + 1] - prefix[x] > prefix[y + 1] - prefix[y]; });
     if (hipMemcpy(tt.prefix, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
     if (hipMemcpy(tt.mask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+    if (hipMemcpy(tt.order, order.data(), order.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
     it = e->tap_tabs.emplace(key, tt).first;
   }
   if (it->second.total >= tiles * (long)c.T() * ((a.Kc + 31) / 32)) return;   // nothing to skip
-  a.tprefix = it->second.prefix; a.tmask = it->second.mask; a.total_units = it->second.total;
+  a.tprefix = it->second.prefix; a.tmask = it->second.mask; a.total_units = it->second.total; a.torder = it->second.order;
   a.par = s2_dgrad ? 1 : 0;
 }
 

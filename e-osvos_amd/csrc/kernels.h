@@ -97,6 +97,7 @@ struct ConvArgs {
   int dst_up, Hf, Wf;   // dst_up=1: GEMM row (b,oy,ox) is written to pixel (b,2oy,2ox) of an Hf x Wf grid
   const int* tprefix;   // optional (device): compacted K-step prefix per tile (tiles+1), see conv_build_tap_table
   const int* tmask;     // optional (device): valid-tap bit mask per tile
+  const int* torder;    // optional (device): the tiles sorted by descending K steps (whole-tile plan of a tap-table launch)
   long total_units;     // sum of valid K steps when tprefix is set, else 0
   int deep;             // set by conv_plan: 1 / 2 = the 3-workgroups-per-CU kernel variants (K step 32 single stage / 16)
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
