@@ -108,6 +108,9 @@ STRIDED_CASES = [          # (B, H, W, Cin, Cout, k, stride, dil, pad): the non-
     (1, 120, 214, 128, 128, 3, 2, 1, 1),          # layer2.0.conv2: parity-major data gradient
     (2, 30, 54, 1280, 256, 1, 1, 1, 0),           # ASPP projection
     (1, 120, 214, 256, 48, 1, 1, 1, 0),           # decoder.conv1 (N = 48)
+    (3, 120, 214, 128, 128, 3, 2, 1, 1),          # layer2.0.conv2 at batch 3: 602 uneven tiles -> whole tiles, longest first
+    (3, 30, 54, 256, 256, 3, 1, 1, 1),            # layer3 conv2 at batch 3: 76 tiles, K = 2304 -> chunk-major split-K (x6)
+    (3, 30, 54, 2048, 512, 1, 1, 1, 0),           # layer4 conv1 at batch 3: 152 tiles, K = 2048 -> split-K (x3)
 ]
 
 
