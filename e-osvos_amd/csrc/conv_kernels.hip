@@ -1491,10 +1491,11 @@ int conv_plan(ConvArgs& a) {
   if (a.deep == 2) ksteps = (long)T * ((a.Kc + EOSVOS_BK_DEEP - 1) / EOSVOS_BK_DEEP);
   long nwg = a.deep ? CONV_MAX_WG_DEEP : conv_wg_budget(a.wg_budget), q = 0, per = 0;
   static const int tap_whole = env_int("EOSVOS_TUNE_TAP_WHOLE", 1);
-  if (tap_whole && x6 && a.total_units > 0 && a.torder && tiles >= nwg) {
+  if (tap_whole && x6 && a.total_units > 0 && a.torder && tiles >= nwg && ksteps * EOSVOS_BK <= 1536) {
     // uneven tiles (tap table), at least one per workgroup: whole tiles, longest first, no parked partial tiles and no
     // fix-up pass (the stride-2 3x3 data gradient at batch 3: 602 tiles of 4 / 8 / 8 / 16 K steps; streamed, nearly every
-    // workgroup parked two slabs: 70 + 20 us)
+    // workgroup parked two slabs: 70 + 20 us).  Short K only: the 608-tile, K = 2304 data gradients of the dilated ASPP convs
+    // lose more to the quantisation into two rounds (139 + 22 -> 192 us) than the fix-up pass costs.
     q = (tiles + nwg - 1) / nwg; per = 0;
   } else if (tiles >= nwg && a.total_units <= 0) {
     q = tiles / nwg;
