@@ -17,9 +17,17 @@ one task per rank per meta-iteration, a step = one meta-iteration).
 `roofline` is about the kernel symbol that takes the most time in a step, found and timed live: after the timed
 region the same steps run once more with HIP events around every matrix-core launch, recorded on the stream each
 launch runs on (eosvos_profile_launches); achieved = that kernel's executed fp32-equivalent FLOPs / its summed
-duration.  The arithmetic is fp32 (dtype "f32"): in the default matrix mode every fp32 operand is split exactly into
-three bf16 pieces and each product is accumulated in fp32 from its six leading partial products on the bf16 MFMA
-(error <= the fp32 MFMA's, tests/test_gpu_conv_algos.py), so the roof that bounds it is the dense bf16 MFMA peak / 6.
+duration.  Tensors, accumulators and epilogues are fp32; `dtype` names how the contractions use the matrix cores:
+"f32 (f16x3 split)" (default) = per-tensor power-of-two scale, 2 fp16 pieces per operand, 3 of the 4 partial products on
+v_mfma_f32_16x16x32_f16 with fp32 accumulation (roof = dense 16-bit MFMA peak / 3); "f32 (bf16x6 split)" = exact 3-way
+bf16 split, 6 partial products (peak / 6, no range assumption); "f32" = the fp32 MFMA.  EOSVOS_MFMA selects the mode.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N rank processes itself
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, fresh children, before anything here touches the
+GPU) and relays rank 0's line; under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
+`configs` (top level) keeps the other BASELINE shapes next to the headline: batch-1 iteration (C1), one online-adaptation
+round (C3), meta-tasks/s with ONE task per rank (the configs[3] / [4] shape: meta_batch_size = ranks) and with
+`--tasks-per-rank` in flight, each with its all-reduce time, and the same iteration in the other matrix modes.
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,7 +49,7 @@ H, W, BATCH = 480, 854, 3
 FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad as direct convolutions, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_DENSE_PEAK = 2500.0            # TFLOP/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant_kernel.json')
+PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_dominant_kernel.json', 'r03_pmc_dominant_kernel.json')]
 
 
 MFMAS_PER_FMA = {'f16x3': 3, 'bf16x6': 6}      # 16-bit MFMA issues per fp32 multiply-accumulate
@@ -51,6 +59,41 @@ def matrix_peak(mode):
     """fp32-equivalent TFLOP/s roof of the matrix mode = the dense 16-bit MFMA peak / the MFMAs it issues per fp32
     multiply-accumulate (f16x3: 3, bf16x6: 6); the fp32 MFMA peak in the f32 mode."""
     return BF16_DENSE_PEAK / MFMAS_PER_FMA[mode] if mode in MFMAS_PER_FMA else FP32_MATRIX_PEAK
+
+
+def dtype_name(mode):
+    """fp32 tensors / accumulators throughout; the split the contractions run in is part of the name."""
+    return f'f32 ({mode} split)' if mode in MFMAS_PER_FMA else 'f32'
+
+
+def self_launch(a, argv):
+    """`--gpus N > 1` outside torch.distributed.run: start the N ranks as fresh child processes (this process has not
+    touched the GPU: counting devices does not initialise it) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    n = torch.cuda.device_count()
+    if n < a.gpus:
+        raise SystemExit(f'bench.py --gpus {a.gpus}: only {n} GPU(s) visible')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        try:
+            if 'metric' in json.loads(out):
+                line = out.strip()
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(out)                       # anything else the ranks print is not the result line
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit(f'bench.py --gpus {a.gpus}: the rank processes failed (exit code {rc}, result line: {line is not None})')
+    print(line, flush=True)
 
 
 def cpu_threads():
@@ -107,13 +150,17 @@ def cpu_baseline_meta(sd, lrs, x1, y1, xm, ym):
 def pmc_traffic(kernel, lib_version, batch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (tools/pmc_dominant.sh), if they were
     taken for this library version / kernel / batch; else None."""
-    try:
-        p = json.load(open(PMC_FILE))
-    except (OSError, ValueError):
-        return None, 'no PMC artifact'
-    if p.get('kernel') != kernel or p.get('lib_version') != lib_version or p.get('batch') != batch:
-        return None, f"PMC artifact is for {p.get('kernel')} / {p.get('lib_version')} / batch {p.get('batch')}"
-    return p['traffic_bytes_per_launch'], p.get('note', '')
+    why = 'no PMC artifact'
+    for path in PMC_FILES:
+        try:
+            p = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if p.get('kernel') != kernel or p.get('lib_version') != lib_version or p.get('batch') != batch:
+            why = f"PMC artifact is for {p.get('kernel')} / {p.get('lib_version')} / batch {p.get('batch')}"
+            continue
+        return p['traffic_bytes_per_launch'], p.get('note', '')
+    return None, why
 
 
 def profiled_pass(eng, run_step, steps):
@@ -244,7 +291,7 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, m
         out = {
             'metric': 'meta_tasks_per_sec', 'value': world * tpr * a.steps / dt, 'unit': 'meta_tasks/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_name(mode), 'data': 'synthetic',
             'config': {'workload': f'meta-train iteration (BASELINE configs[3..4]): meta_batch_size = {tpr} x ranks, {tpr} tasks per '
                                    f'rank in flight together (one engine each), a task = 5 inner fine-tune steps + 1 meta frame at '
                                    f'batch 1, {H}x{W}, BCE; one all-reduce(sum) of the 40.3 M-float meta-gradient, RAdam + lr clamp '
@@ -281,10 +328,14 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
     a = ap.parse_args(argv)
     if a.steps is None:
         a.steps = 200 if a.metric == 'finetune' else 40
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ and engine_factory is None:
+        return self_launch(a, argv)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: one rank per GPU is the contract')
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -331,6 +382,14 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
     ms_per_step = 1e3 * dt / a.steps
     value = world * a.steps / dt
     last_loss = eng.finetune_step(xg, yg)           # sanity: still finite after K steps
+    # `value` is the EXACT K steps the caller asked for (median of 3 when K < 100); a short K is a 0.2 s region, so the same
+    # step is also timed over >= 100 steps (one region, about 2 s) and both are reported
+    long_run = None
+    if a.steps < 100:
+        nl = 200
+        dtl = timed(step, nl, barrier, dist, dev)
+        long_run = {'steps': nl, 'ms_per_step': 1e3 * dtl / nl, 'value': world * nl / dtl,
+                    'note': f'the same step over one timed region of {nl} steps (the caller asked for {a.steps})'}
 
     # dominant kernel: the same steps once more with HIP events around every matrix-core launch
     psteps = min(a.steps, 20)
@@ -341,11 +400,7 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         # `achieved` above times the kernel while the other stream's launches share the chip with it (weight-gradient
         # launches run beside the data-gradient chain).  The same kernel with the chip to itself: an engine without the
         # side stream, every launch in one queue.
-        os.environ['EOSVOS_NO_SIDE_STREAM'] = '1'
-        try:
-            e1 = Engine('resnet50', H, W, max_batch=BATCH, device=dev)
-        finally:
-            os.environ.pop('EOSVOS_NO_SIDE_STREAM', None)
+        e1 = Engine('resnet50', H, W, max_batch=BATCH, device=dev, side_stream=False)
         e1.load_model_state(sd, lrs)
         step1 = lambda: e1.finetune_step(xg, yg, sync_loss=False)
         for _ in range(3):
@@ -405,38 +460,62 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         'ms_per_round': 1e3 * dtr / nr, 'finetune_iters_per_sec': world * 10 * nr / dtr,
         'note': 'iterations/s over the whole round (inference and the weight restore included)'}
     eng.reset()
+    configs = {'c1_b1_ms': extra['c1_batch1']['ms_per_step'], 'c1_b1_iters_per_sec': extra['c1_batch1']['finetune_iters_per_sec'],
+               'c1_b1_executed_frac': extra['c1_batch1']['whole_step_executed_frac'],
+               'c3_round_ms': extra['c3_online_adaptation_round']['ms_per_round']}
     if not a.no_meta:
-        # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4]), tasks in flight together.
+        # meta-train metric: tasks/s with K=5 inner steps + meta frame at B=1 (configs[3..4]).  Two shapes: `--tasks-per-rank`
+        # tasks in flight together on one engine each (what a GPU can do), and ONE task per rank per meta-iteration -- the
+        # shape BASELINE configs[3] / [4] name (meta_batch_size = ranks; src/util/meta_run.py:39).
         # (Before the A/B extras below: they create and destroy streams, and which hardware queue a later stream lands on
         # depends on that history -- engines whose streams share a pipe lose a quarter of their rate, profiles/r03_hw_queue_sweep.txt.)
         # An extra of this line: a failure here (every rank raises alike: the only rank-dependent step is the all-reduce)
         # is recorded, not allowed to take the headline with it.
-        tpr = a.tasks_per_rank
-        try:
+        def measure_meta(tpr, with_roofline):
             mt, mstep, _, extra_eng = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory or Engine)
             mstep()                                                             # warm-up
-            n_it = 4
+            n_it = 4 if tpr > 1 else 8
             dtm, msamples = timed_median(mstep, n_it, barrier, dist, dev, repeats=3)
-            extra['meta_tasks_per_sec'] = world * tpr * n_it / dtm
-            extra['meta_config'] = (f'meta_batch_size={world * tpr} ({tpr} tasks per GPU in flight on one engine each), 5 inner steps + '
-                                    f'1 meta frame, batch 1, {H}x{W}')
+            out = {'tasks_per_sec': world * tpr * n_it / dtm, 'ms_per_meta_iteration': 1e3 * dtm / n_it,
+                   'config': (f'meta_batch_size={world * tpr} ({tpr} task(s) per GPU' + (' in flight on one engine each' if tpr > 1 else '') +
+                              f'), 5 inner steps + 1 meta frame, batch 1, {H}x{W}'), 'timed_region_samples_s': msamples}
             mt.profile = {}
             for _ in range(2):
                 mstep()
-            extra['meta_phase_ms_per_meta_iteration'] = {k: v / mt.profile['iterations'] for k, v in mt.profile.items() if k != 'iterations'}
+            out['phase_ms_per_meta_iteration'] = {k: v / mt.profile['iterations'] for k, v in mt.profile.items() if k != 'iterations'}
             mt.profile = None
-            mrows, _ = profiled_pass(eng, mstep, 2)                             # the first engine's launches (one of `tpr` in flight)
-            extra['meta_roofline'] = roofline_from(mrows, 2, mode, lib_version, 1, 1e3 * dtm / n_it)
-            extra['meta_roofline']['note'] = ('HIP-event profile of the first of the engines that run tasks side by side; whole_step_* '
-                                              'fields relate its FLOPs to the whole meta-iteration time and are not meaningful here')
-            extra['meta_timed_region_samples_s'] = msamples
-            if rank == 0 and world == 1 and not a.no_cpu_baseline:
-                extra['meta_cpu_baseline'] = cpu_baseline_meta(sd, lrs, x[:1], y[:1], torch.flip(x[:1], dims=[3]), torch.flip(y[:1], dims=[3]))
+            if with_roofline:
+                mrows, _ = profiled_pass(mt.eng, mstep, 2)                      # the first engine's launches (one of `tpr` in flight)
+                out['roofline'] = roofline_from(mrows, 2, mode, lib_version, 1, 1e3 * dtm / n_it)
+                out['roofline']['note'] = ('HIP-event profile of the first of the engines that run tasks side by side; whole_step_* '
+                                           'fields relate its FLOPs to the whole meta-iteration time and are not meaningful here')
             for e in extra_eng:
                 e.close()
+            return out
+        tpr = a.tasks_per_rank
+        try:
+            m4 = measure_meta(tpr, True)
+            extra['meta_tasks_per_sec'] = m4['tasks_per_sec']
+            extra['meta_config'] = m4['config']
+            extra['meta_phase_ms_per_meta_iteration'] = m4['phase_ms_per_meta_iteration']
+            extra['meta_roofline'] = m4['roofline']
+            extra['meta_timed_region_samples_s'] = m4['timed_region_samples_s']
+            configs[f'meta_tasks_per_sec_tpr{tpr}'] = m4['tasks_per_sec']
+            configs[f'meta_tpr{tpr}_allreduce_ms'] = m4['phase_ms_per_meta_iteration'].get('allreduce_ms')
+            configs[f'meta_tpr{tpr}_outer_step_ms'] = m4['phase_ms_per_meta_iteration'].get('outer_step_ms')
+            if tpr != 1:
+                m1 = measure_meta(1, False)
+                extra['meta_one_task_per_rank'] = m1
+                configs['meta_tasks_per_sec_tpr1'] = m1['tasks_per_sec']
+                configs['meta_tpr1_allreduce_ms'] = m1['phase_ms_per_meta_iteration'].get('allreduce_ms')
+                configs['meta_tpr1_outer_step_ms'] = m1['phase_ms_per_meta_iteration'].get('outer_step_ms')
+                eng.reset()
+            if rank == 0 and world == 1 and not a.no_cpu_baseline:
+                extra['meta_cpu_baseline'] = cpu_baseline_meta(sd, lrs, x[:1], y[:1], torch.flip(x[:1], dims=[3]), torch.flip(y[:1], dims=[3]))
         except Exception as exc:                                                # noqa: BLE001
             extra['meta_tasks_per_sec'] = None
             extra['meta_error'] = f'{type(exc).__name__}: {exc}'
+            configs['meta_error'] = extra['meta_error']
 
     if not a.no_ab and world == 1:
         # same engine, same buffers, fp32-MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the split kernels
@@ -450,6 +529,7 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
             engine_mod.set_matrix_mode(mode)
             eng.reset()
             extra[key] = 1e3 * dto / min(a.steps, 30)
+            configs['bf16x6_ms' if other == 'bf16x6' else 'fp32_mfma_ms'] = extra[key]
     if not a.no_ab and world == 1 and torch.cuda.is_available():
         # the objects of a multi-object sequence are independent fine-tunes (evaluate.py:132): three of them in flight, one
         # engine and ONE queue each (no side stream, each launch planned for half the chip, fresh consecutive streams:
@@ -471,6 +551,7 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         n3 = min(a.steps, 30)
         dt3 = timed(step3, n3, barrier, dist, dev)
         extra['finetune_iters_per_sec_3_objects_in_flight'] = 3 * n3 / dt3
+        configs['iters_per_sec_3_objects_in_flight'] = extra['finetune_iters_per_sec_3_objects_in_flight']
         for e2 in others:
             e2.close()
     cpu = None
@@ -480,11 +561,11 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         out = {
             'metric': 'finetune_iters_per_sec', 'value': value, 'unit': 'finetune_iters/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_name(mode), 'data': 'synthetic',
             'config': {'workload': 'e-OSVOS-50 fine-tune iteration (BASELINE configs[1]): DeepLabV3+-ResNet50, '
                                    f'batch {BATCH}, {H}x{W}, BCE, per-neuron-lr SGD; one (sequence, object) per rank',
                        'batch': BATCH, 'height': H, 'width': W, 'parallelism': f'replicas x{world}'},
-            'roofline': roofline, 'cpu_baseline': cpu, 'extra': extra,
+            'roofline': roofline, 'cpu_baseline': cpu, 'configs': configs, 'long_run': long_run, 'extra': extra,
         }
         print(json.dumps(out), flush=True)
     eng.close()

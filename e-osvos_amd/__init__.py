@@ -18,7 +18,20 @@ import os as _os_env
 # more queues than streams every stream owns one, and engines built back to back WITHOUT a side stream sit on consecutive
 # queues = different pipes.  A lone engine is unaffected (90.1 / 90.3 / 90.2 it/s with 4 / 8 / 16 queues).
 # The HIP runtime reads this when it initialises (first GPU call), so it is set as early as this package can.
-_os_env.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
+# It is a LAUNCHER setting: it changes the queue allocation of every GPU user of the process, and it has no effect when
+# the host application initialised HIP before importing this package -- that case gets a warning instead of silence.
+if 'GPU_MAX_HW_QUEUES' not in _os_env.environ:
+    import sys as _sys
+    _t = _sys.modules.get('torch')
+    if _t is not None and getattr(_t, 'cuda', None) is not None and _t.cuda.is_initialized():
+        import warnings as _w
+        _w.warn('e-osvos_amd: the GPU runtime was initialised before this package was imported, so GPU_MAX_HW_QUEUES=24 cannot '
+                'take effect; engines that run side by side (meta tasks / objects in flight) may share hardware queues and lose '
+                'about a quarter of their rate.  Export GPU_MAX_HW_QUEUES=24 in the launcher.', RuntimeWarning)
+        del _w
+    else:
+        _os_env.environ['GPU_MAX_HW_QUEUES'] = '24'
+    del _sys, _t
 del _os_env
 
 __version__ = '0.5.0'

@@ -28,6 +28,8 @@ _SIGNATURES = {
     'eosvos_norm_count': (ctypes.c_int64, [ctypes.c_int]),
     'eosvos_create': (ctypes.c_int, [ctypes.POINTER(_E), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'eosvos_create_ex': (ctypes.c_int, [ctypes.POINTER(_E), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'eosvos_destroy': (ctypes.c_int, [_E]),
     'eosvos_synchronize': (ctypes.c_int, [_E]),
     'eosvos_debug_check_guards': (ctypes.c_int, [_E]),

@@ -248,6 +248,7 @@ struct eosvos_engine {
   bool have_loss_grad = false;
   int force_algo = 0;                 // EOSVOS_ALGO_*: 0 = plan by work size; the op-level parity tests force one path
   int wg_budget = 0;                  // eosvos_set_wg_budget: workgroups a launch plans for (0 = the whole chip)
+  int plan_mode = -1;                 // matrix mode the cached launch plans (wg_plans, upd_tab) were built for, see plans_match_mode()
 
   // f16x3 matrix mode: absmax slots (bit patterns of max|x|), kind-major [AM_KINDS][nconv]; see amax_get()
   unsigned* amax = nullptr;
@@ -1073,6 +1074,18 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
   return 0;
 }
 
+// The grouped weight-gradient tables (WgradArgs with or without absmax slots, split counts) and the update tables (slab
+// counts per conv) depend on the process-wide matrix mode: a mode switch on a live engine drops them.
+void plans_match_mode(eosvos_engine* e) {
+  const int mode = conv_mfma_mode();
+  if (e->plan_mode == mode) return;
+  e->plan_mode = mode;
+  e->wg_plans.clear();                             // (the device tables stay allocated until the engine goes: a few KB per switch)
+  for (auto& tab : e->upd_tab) tab = nullptr;
+  e->wino_v_batch.clear();                         // Winograd selection differs per mode: V / dM of the other mode are stale
+  for (auto& kv : e->wino_dm_batch) kv.second = 0;
+}
+
 int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 // slab sizing: the K splits of a weight gradient depend on the matrix mode (tile rules), which may change after create
 int wgrad_max_splits(int P, int Cout, int Cin, int T, int wg_budget) {
@@ -1147,7 +1160,12 @@ int64_t eosvos_norm_count(int arch) { Topo t; return build_topo(arch, t) ? t.nno
 
 int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int width, int max_batch,
                   int device_id, void* stream) {
+  return eosvos_create_ex(out, arch, norm_mode, height, width, max_batch, device_id, stream, 0);
+}
+int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, int width, int max_batch,
+                     int device_id, void* stream, int flags) {
   if (!out) return fail("null out");
+  if (flags & ~EOSVOS_CREATE_NO_SIDE_STREAM) return fail("unknown construction flag");
   if (norm_mode != EOSVOS_NORM_BN_FROZEN && norm_mode != EOSVOS_NORM_GN16) return fail("unknown norm mode");
   if (height < 32 || width < 32 || max_batch < 1) return fail("bad geometry");
   {
@@ -1332,7 +1350,7 @@ int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int 
   if (upload_resize(e, make_resize(wl, W, false), wl, W, e->fin_w)) { eosvos_destroy(e); return 1; }
   {
     const char* v = getenv("EOSVOS_NO_SIDE_STREAM");
-    if (!(v && v[0] == '1')) {
+    if (!(v && v[0] == '1') && !(flags & EOSVOS_CREATE_NO_SIDE_STREAM)) {
 #ifdef EOSVOS_SIDE_LOWPRIO        // experiment: the side stream yields to the main (critical) chain
       int plo = 0, phi = 0;
       HIPOK(hipDeviceGetStreamPriorityRange(&plo, &phi));       // plo = least, phi = greatest priority
@@ -1550,6 +1568,7 @@ int eosvos_restore_params(eosvos_engine* e) {
 static int forward_impl(eosvos_engine* e, const float* images, int B) {
   const Topo& t = e->t;
   hipStream_t s = e->s;
+  plans_match_mode(e);
   amax_new_phase(e, 0);
   if (h3_mode() && amax_init(e)) return fail("f16x3 matrix mode: no room for the absmax slots of this topology");
   if (h3_mode()) {
@@ -1670,6 +1689,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   const int B = e->lastB;
   if (B < 1 || !e->have_loss_grad) return fail("backward without forward + loss");
   if (accumulate && !e->gsum) return fail("accumulate without eosvos_meta_task_begin");
+  plans_match_mode(e);
   const int64_t P4 = (int64_t)B * e->h4 * e->w4;
   const int P16 = e->h16 * e->w16;
   amax_new_phase(e, 1);

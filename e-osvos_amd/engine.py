@@ -72,19 +72,9 @@ class Engine:
         warm_stream_pool(self.device)
         self.stream = torch.cuda.current_stream(self.device)
         h = ctypes.c_void_p()
-        import os
-        had = os.environ.get('EOSVOS_NO_SIDE_STREAM')
-        if not side_stream:
-            os.environ['EOSVOS_NO_SIDE_STREAM'] = '1'        # read by eosvos_create
-        try:
-            _ffi.check(self.lib.eosvos_create(ctypes.byref(h), self.arch, 1 if norm == 'gn' else 0, height, width, max_batch,
-                                              self.device.index or 0, ctypes.c_void_p(self.stream.cuda_stream)))
-        finally:
-            if not side_stream:
-                if had is None:
-                    os.environ.pop('EOSVOS_NO_SIDE_STREAM', None)
-                else:
-                    os.environ['EOSVOS_NO_SIDE_STREAM'] = had
+        _ffi.check(self.lib.eosvos_create_ex(ctypes.byref(h), self.arch, 1 if norm == 'gn' else 0, height, width, max_batch,
+                                             self.device.index or 0, ctypes.c_void_p(self.stream.cuda_stream),
+                                             0 if side_stream else 1))          # EOSVOS_CREATE_NO_SIDE_STREAM
         self.h = h
         self._loss = torch.zeros(1, device=self.device)
         # host-side view of the engine's state (networks.DeepLabV3Plus carries it across an engine re-creation)

@@ -307,6 +307,12 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         workers = getattr(model, '_object_workers', None)
         if workers is None or len(workers) != objects_in_flight:
             workers = model._object_workers = object_workers(model, meta_optim, cfg['meta_optim_cfg'], objects_in_flight)
+        else:
+            # cached workers are spawned COPIES: the caller may have loaded another parent checkpoint since (one per dataset
+            # key, evaluate.py:46-50) -- MetaOptimizer.load_state_dict never touches the frozen norm statistics, and with
+            # `learn_model_init: False` not the weights either
+            for w in workers:
+                w.model.copy_state_from(model)
     J_seq, labels_out, item, eval_time, num_frames = [], {}, 0, 0.0, 0
     # File readers (`prefetchable`) are used through shallow copies on two worker threads: sequence k + 1 is decoded while
     # sequence k is fine-tuned, and the PNGs / J of sequence k are written while k + 1 runs (PIL releases the GIL).

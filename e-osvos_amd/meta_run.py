@@ -237,8 +237,10 @@ class MetaTrainer:
             if self.state.is_cuda and getattr(self.eng, 'stream', None) is not None:
                 torch.cuda.current_stream(self.state.device).wait_stream(self.eng.stream)
         t1 = tick()
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
-            self.dist.all_reduce(self.grad)             # sum over ranks, one 161 MB message
+        if self.dist is not None and self.dist.is_initialized():
+            # sum over ranks, one 161 MB message (also with ONE rank: the collective, its device binding and its stream
+            # ordering are then the code that runs on a node -- tests/test_gpu_nccl.py)
+            self.dist.all_reduce(self.grad)
         t2 = tick()
         self.outer_step()
         if prof is not None:

@@ -156,6 +156,13 @@ class DeepLabV3Plus:
         m.training, m._dropout_off = self.training, self._dropout_off
         return m
 
+    def copy_state_from(self, other):
+        """Take `other`'s learned init and frozen norm statistics (a spawned worker re-synchronised with its parent after
+        the parent loaded another checkpoint: `evaluate_dataset` per dataset key, reference `evaluate.py:46-50`)."""
+        self._flat.copy_(other._flat)
+        self._norm = OrderedDict((k, v.clone()) for k, v in other._norm.items())
+        self._dirty = True
+
     def set_side_stream(self, on):
         """`eosvos_set_side_stream` of this model's engine, now and whenever the engine is rebuilt (False while it runs
         beside other engines: `evaluate.run_objects_in_flight`)."""

@@ -135,6 +135,12 @@ def main(argv=None, height=480, width=854, num_frames=12, num_meta_iters=None, d
     cfg = config_mod.parse_cli(sys.argv[1:] if argv is None else argv)
     if num_meta_iters is None and os.environ.get('EOSVOS_NUM_META_ITERS'):
         num_meta_iters = int(os.environ['EOSVOS_NUM_META_ITERS'])
+    # frame size / sequence length of the SYNTHETIC data (no dataset root): for the command line, which has no such
+    # arguments in the reference's grammar (`EOSVOS_SYNTHETIC_SIZE=96x160 EOSVOS_SYNTHETIC_FRAMES=4 python -m eosvos_amd.train_meta with ...`)
+    if os.environ.get('EOSVOS_SYNTHETIC_SIZE'):
+        height, width = (int(v) for v in os.environ['EOSVOS_SYNTHETIC_SIZE'].lower().split('x'))
+    if os.environ.get('EOSVOS_SYNTHETIC_FRAMES'):
+        num_frames = int(os.environ['EOSVOS_SYNTHETIC_FRAMES'])
     run = cfg['env_suffix'] or 'run'
     run_dir = os.path.join(cfg['save_dir'], run)
     meta_mode = cfg['num_meta_processes_per_gpu'] != 0
@@ -285,7 +291,7 @@ def _run(cfg, run, run_dir, meta_mode, eval_proc, height, width, num_frames, num
         losses = mt.meta_iteration(tasks, inner_steps=cfg['num_epochs']['train'], bptt_epochs=cfg['bptt_epochs'],
                                    multi_step_bptt_loss=cfg['multi_step_bptt_loss'] or None)
         done = meta_iter + it + 1
-        if dist is not None:                                    # one decision for all ranks
+        if dist is not None and handlers:                       # one decision for all ranks (only a signal can set the flag)
             flag = torch.tensor([1.0 if stop['flag'] else 0.0], device=mt.state.device)
             dist.all_reduce(flag)
             stop['flag'] = bool(flag.item() > 0)

@@ -111,6 +111,12 @@ int64_t eosvos_norm_count(int arch);
  * `stream` is a hipStream_t (NULL = the device's default stream). */
 int eosvos_create(eosvos_engine** out, int arch, int norm_mode, int height, int width,
                   int max_batch, int device_id, void* stream);
+/* Same with construction flags.  EOSVOS_CREATE_NO_SIDE_STREAM: the engine never creates its second HIP stream (an engine
+ * that will run beside other engines of the process: one hardware queue each, see eosvos_set_side_stream); the
+ * environment variable EOSVOS_NO_SIDE_STREAM=1 sets the same flag for every engine of the process. */
+#define EOSVOS_CREATE_NO_SIDE_STREAM 1
+int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, int width,
+                     int max_batch, int device_id, void* stream, int flags);
 int eosvos_destroy(eosvos_engine* e);
 int eosvos_synchronize(eosvos_engine* e);
 

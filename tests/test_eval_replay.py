@@ -259,6 +259,45 @@ def test_more_objects_than_workers():
     assert len({round(float(h[0][-1]), 6) for _, h in one}) >= 3         # the objects really differ
 
 
+def test_object_workers_follow_the_parent_checkpoint_of_each_dataset_key(tmp_path):
+    """`evaluate()` loads the parent checkpoint of every dataset key into the model (`evaluate.py:46-50`).  The cached
+    object workers are spawned copies: a second `evaluate_dataset` after `model.load_state_dict(other parent)` must run the
+    multi-object sequences on the NEW weights and norm statistics (with `learn_model_init: False` the meta-optimizer
+    state carries neither)."""
+    sc = SCENARIOS[0]                                   # 'bear': two objects -> fine-tuned on the worker models
+    cfg = config_mod.parse_cli([])
+    cfg['num_epochs']['eval'] = 2
+    cfg['eval_online_adapt'].update(step=0, reset_model_mode='FIRST_STEP', num_epochs=1, min_prop=0.5)
+    cfg['data_cfg']['batch_sizes']['train'] = 2
+    cfg['meta_optim_cfg']['learn_model_init'] = False
+    cfg['datasets']['val'] = {'name': 'DAVIS-2017', 'split': 'val_seqs', 'eval': True}
+    model = FakeDeepLab('resnet50', num_classes=1, batch_norm=cfg['parent_model']['batch_norm'], max_batch=2)
+    model._views['backbone.conv1.weight'].view(-1)[0] = 0.3
+    mo = MetaOptimizer(model, **cfg['meta_optim_cfg'])
+    msd = mo.state_dict()
+    assert not any(k.startswith('model_init_') for k in msd)
+    ds = ScenarioDataset(sc)
+    res_a = product_eval.evaluate_dataset(model, mo, msd, ds, cfg, 'val', objects_in_flight=2)
+    workers = model._object_workers
+    sd_b = model.state_dict()
+    sd_b['backbone.conv1.weight'] = sd_b['backbone.conv1.weight'].clone()
+    sd_b['backbone.conv1.weight'].view(-1)[0] = -0.7
+    sd_b['backbone.bn1.running_var'] = sd_b['backbone.bn1.running_var'] * 3.0
+    model.load_state_dict(sd_b)                          # the other dataset key's parent checkpoint
+    res_b = product_eval.evaluate_dataset(model, mo, msd, ds, cfg, 'val', objects_in_flight=2)
+    assert model._object_workers is workers              # the cache was reused ...
+    for w in workers:                                    # ... and every worker engine now holds parent B
+        assert float(w.model.engine.init[0]) == pytest.approx(-0.7)
+        assert torch.allclose(w.model.engine.norm_args[3][:64], torch.full((64,), 3.0))
+    one = FakeDeepLab('resnet50', num_classes=1, batch_norm=cfg['parent_model']['batch_norm'], max_batch=2)
+    one.load_state_dict(sd_b)
+    mo1 = MetaOptimizer(one, **cfg['meta_optim_cfg'])
+    res_1 = product_eval.evaluate_dataset(one, mo1, msd, ds, cfg, 'val', objects_in_flight=1)
+    for seq in sc['seqs']:
+        assert torch.equal(res_b['labels'][seq], res_1['labels'][seq])
+    assert res_b['J_seq'] == res_1['J_seq']
+
+
 def test_schedule_function_matches_reference_rounds():
     """`online_adapt_schedule` alone against the inference ranges / propagated frames of the reference run."""
     for sc in SCENARIOS:

@@ -278,6 +278,36 @@ def test_finetune_trajectory_in_every_matrix_mode(mode):
     assert bool(torch.isfinite(params).all())
 
 
+@pytest.mark.parametrize('side_stream', [True, False], ids=['two_streams', 'one_queue'])
+def test_matrix_mode_switch_on_a_live_engine(side_stream):
+    """The matrix mode is process-wide and may change under an engine that has already run a backward pass (bench.py's
+    A/B extras do exactly that).  The cached launch plans -- grouped weight-gradient tables (with or without absmax
+    slots), slab counts of the update tables -- depend on the mode: bf16x6 -> f16x3 -> f32 -> f16x3 on ONE engine, every
+    segment continues the oracle's trajectory (a stale plan sums the wrong number of slabs or dereferences a null slot)."""
+    from eosvos_amd import synthetic
+    from oracle import meta
+    H, W, B = 96, 160, 2
+    sd = synthetic.synthetic_state('resnet50')
+    lrs = synthetic.synthetic_lrs('resnet50')
+    x, y = synthetic.synthetic_frames(B, H, W, seed=7)
+    order = ['bf16x6', 'f16x3', 'f32', 'f16x3']
+    ref_losses, _ = meta.finetune(sd, lrs, [(x, y)] * (2 * len(order)))
+    prev = engine_mod.get_matrix_mode()
+    losses = []
+    try:
+        engine_mod.set_matrix_mode(order[0])
+        e = Engine('resnet50', H, W, max_batch=B, device=DEV, side_stream=side_stream)
+        e.load_model_state(sd, lrs)
+        for mode in order:
+            engine_mod.set_matrix_mode(mode)
+            losses += [e.finetune_step(x.to(DEV), y.to(DEV)) for _ in range(2)]
+        e.close()
+    finally:
+        engine_mod.set_matrix_mode(prev)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 2e-4 * abs(b), (losses, ref_losses)
+
+
 def test_f16x3_is_invariant_under_power_of_two_reparametrisation():
     """Scaling a conv's weights by 2^-30 and its frozen-norm scale by 2^30 leaves the network unchanged in exact arithmetic;
     in the f16x3 mode the per-tensor scales absorb the factor exactly (same fp16 pieces), so the logits are bit-identical

@@ -67,8 +67,28 @@ def test_bench_control_flow_two_ranks(tmp_path, metric):
     if metric == 'meta':
         assert line['config']['meta_batch_size'] == 8 and line['config']['tasks_per_rank'] == 4
     assert line['roofline']['kernel'] == 'stand_in_kernel' and line['cpu_baseline'] is None and line['vs_baseline'] is None
+    assert line['dtype'].startswith('f32')
     if metric == 'finetune':
         assert line['extra']['meta_tasks_per_sec'] > 0
+        # the shapes BASELINE names beside the headline survive in the top-level keys the driver stores
+        c = line['configs']
+        assert c['meta_tasks_per_sec_tpr1'] > 0 and c['meta_tasks_per_sec_tpr4'] == line['extra']['meta_tasks_per_sec']
+        assert c['meta_tpr1_allreduce_ms'] >= 0 and c['c1_b1_ms'] > 0 and c['c3_round_ms'] > 0
+        assert line['long_run']['steps'] >= 100 and line['long_run']['value'] > 0
+
+
+def test_bench_gpus_flag_must_match_the_world_size(tmp_path):
+    """`--gpus N` is the contract, not a hint: a rank started with another WORLD_SIZE refuses to run (and N > 1 without
+    WORLD_SIZE self-launches N ranks, which needs N GPUs: here it must fail loudly, there being none)."""
+    env = dict(os.environ, OMP_NUM_THREADS='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and 'GPU(s) visible' in p.stderr and p.stdout.strip() == ''
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=dict(env, WORLD_SIZE='1', RANK='0'),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and 'WORLD_SIZE=1' in p.stderr and p.stdout.strip() == ''
 
 
 def test_evaluation_sharded_over_ranks_equals_single_process(tmp_path):

@@ -17,7 +17,8 @@ for infer_batch in (1, 8, 1):
         model, _ = init_parent_model(**dict(cfg['parent_model']))
         model.to('cuda:0'); model.max_batch = 3
         model.load_state_dict(synthetic.synthetic_state('resnet50'))
-        torch.manual_seed(1); mo = MetaOptimizer(model, **cfg['meta_optim_cfg'])      # (the lr init draws from torch's global RNG); msd = mo.state_dict()
+        torch.manual_seed(1); mo = MetaOptimizer(model, **cfg['meta_optim_cfg'])      # (the lr init draws from torch's global RNG)
+        msd = mo.state_dict()
         res = ev.evaluate_dataset(model, mo, msd, ds, cfg, 'val', objects_in_flight=1)
         lab = res['labels']['synthetic00']
         print('augment', aug, 'infer batch', infer_batch, 'rep', rep, 'labels md5', hashlib.md5(lab.numpy().tobytes()).hexdigest()[:10],

@@ -12,7 +12,8 @@ for in_flight in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3"
     model, _ = init_parent_model(**dict(cfg['parent_model']))
     model.to('cuda:0'); model.max_batch = 3
     model.load_state_dict(synthetic.synthetic_state('resnet50'))
-    torch.manual_seed(1); mo = MetaOptimizer(model, **cfg['meta_optim_cfg'])      # (the lr init draws from torch's global RNG); msd = mo.state_dict()
+    torch.manual_seed(1); mo = MetaOptimizer(model, **cfg['meta_optim_cfg'])      # (the lr init draws from torch's global RNG)
+    msd = mo.state_dict()
     ev.evaluate_dataset(model, mo, msd, data.SyntheticSequences(1, 4, H, W, seed=3), dict(cfg, num_epochs=dict(cfg['num_epochs'], eval=2)), 'val', objects_in_flight=in_flight)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = ev.evaluate_dataset(model, mo, msd, ds, cfg, 'val', objects_in_flight=in_flight)
