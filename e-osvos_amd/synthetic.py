@@ -37,6 +37,37 @@ def synthetic_state(encoder='resnet50', seed=99, dtype=torch.float32):
     return sd
 
 
+def heavy_tailed_state(encoder='resnet50', seed=99, stat_seed=1234, sigma_var=2.3, sigma_gamma=1.6, dead_frac=0.05,
+                       dead_scale=1e-5):
+    """The seeded recipe above with the BatchNorm statistics of a TRAINED parent checkpoint's kind instead of the benign
+    U(0.8, 1.2) ones: running_var and gamma log-normal over >= 3 decades each (sigma of ln: 2.3 / 1.6, i.e. +-3 sigma spans 6 /
+    4 decades), `dead_frac` of every layer's channels near-dead (gamma x dead_scale).  Each layer's gamma is then
+    rescaled by ONE factor so that the folded scale a = gamma / sqrt(var + eps) keeps the root-mean-square of the benign
+    recipe's -- the network stays trainable, but a few channels carry most of each activation tensor and many sit
+    4-6 decades below the tensor's maximum: the regime in which a per-tensor power-of-two scale (the f16x3 matrix mode)
+    has the least headroom.  Fixture G19 pins the engine against the unmodified reference on this state."""
+    sd = synthetic_state(encoder, seed)
+    g = torch.Generator().manual_seed(stat_seed)
+    for c in conv_infos(encoder):
+        if c.norm is None:
+            continue
+        n = c.cout
+        gamma0, var0 = sd[c.norm + '.weight'], sd[c.norm + '.running_var']
+        rms0 = float((gamma0 / torch.sqrt(var0 + 1e-5)).pow(2).mean().sqrt())
+        var = torch.exp(torch.randn(n, generator=g) * sigma_var)
+        gamma = torch.exp(torch.randn(n, generator=g) * sigma_gamma)
+        sign = torch.where(torch.rand(n, generator=g) < 0.1, -1.0, 1.0)           # trained gammas are occasionally negative
+        dead = torch.rand(n, generator=g) < dead_frac
+        gamma = torch.where(dead, gamma * dead_scale, gamma) * sign
+        a = gamma / torch.sqrt(var + 1e-5)
+        gamma = gamma * (rms0 / float(a.pow(2).mean().sqrt()))
+        sd[c.norm + '.weight'] = gamma
+        sd[c.norm + '.running_var'] = var
+        # the running mean of a channel scales with its standard deviation
+        sd[c.norm + '.running_mean'] = sd[c.norm + '.running_mean'] * torch.sqrt(var)
+    return sd
+
+
 def synthetic_lrs(encoder='resnet50', init_lr=1e-3, seed=1):
     """List of NEURON lr tensors aligned with `trainable(encoder)`."""
     g = torch.Generator().manual_seed(seed)

@@ -1,0 +1,107 @@
+"""G19: the envelope of the default matrix mode.  f16x3 puts every fp32 contraction on the fp16 matrix cores under ONE
+power-of-two scale per operand tensor, so elements far below their tensor's maximum keep fewer bits.  The other fixtures
+use the benign synthetic recipe (BatchNorm gamma, running_var ~ U(0.8, 1.2)); a trained parent checkpoint has statistics
+spanning decades and dead channels.  `synthetic.heavy_tailed_state` draws them log-normally over 4-6 decades with 5 %
+near-dead channels, and `tests/golden/make_golden.py --only g19` ran the UNMODIFIED reference on it (fp32 throughout:
+`src/networks/deeplabv3plus.py:282-301`, `src/meta_optim/meta_optim.py:201-212`).  Asserted in the DEFAULT mode at the
+north_star tolerance: logits <= 1e-3, label bits exact outside the reference's own near-zero count, first-step gradients
+<= 1e-3 of each tensor's maximum; the exact-split mode (bf16x6) runs the same assertions beside it.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from eosvos_amd import engine as engine_mod
+from eosvos_amd import synthetic, topology
+from eosvos_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+FULL, SMALL = (480, 854), (96, 160)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def run_g19(mode):
+    """(measured margins dict) of the G19 scenario in `mode`; raises nothing -- the caller asserts."""
+    g = np.load(os.path.join(GOLDEN, 'g19_heavy_tailed.npz'))
+    sd, lrs = synthetic.heavy_tailed_state(), synthetic.synthetic_lrs()
+    tr = topology.trainable('resnet50')
+    offs = np.cumsum([0] + [int(np.prod(s)) for _, s in tr])
+    prev = engine_mod.get_matrix_mode()
+    m = {}
+    try:
+        engine_mod.set_matrix_mode(mode)
+        eng = Engine('resnet50', *FULL, max_batch=3, device=DEV)
+        eng.load_model_state(sd, lrs)
+        batches = [synthetic.synthetic_frames(3, *FULL, seed=21 + it) for it in range(3)]
+        eng.keep_grads(True)
+        losses = []
+        for it, (x, y) in enumerate(batches):
+            losses.append(eng.finetune_step(x.to(DEV), y.to(DEV)))
+            if it == 0:
+                grads = eng.get_grads().cpu()
+        eng.keep_grads(False)
+        m['loss_rel'] = float(np.max(np.abs(np.array(losses) - g['losses']) / np.abs(g['losses'])))
+        m['grad_elem'] = {}
+        for i in g['ids']:
+            ref = g[f'grad_{i}']
+            got = grads[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
+            m['grad_elem'][tr[i][0]] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        m['grad_l2'] = max(abs(float(grads[offs[i]:offs[i + 1]].double().norm()) - g['grad_fp'][i][1]) / (g['grad_fp'][i][1] + 1e-30)
+                           for i in range(len(tr)))
+        m['grad_absmax'] = max(abs(float(grads[offs[i]:offs[i + 1]].abs().max()) - g['grad_absmax'][i]) / (g['grad_absmax'][i] + 1e-30)
+                               for i in range(len(tr)))
+        params = eng.get_params().cpu()
+        m['param_elem'] = max(float(np.abs(params[offs[i]:offs[i + 1]].view(*g[f'param_{i}'].shape).numpy() - g[f'param_{i}']).max()
+                                    / np.abs(g[f'param_{i}']).max()) for i in list(g['ids'][:1]) + list(g['ids'][-3:]))
+        out = eng.forward(batches[0][0].to(DEV)).cpu()
+        m['logits_abs'] = float(np.abs(out[:, 0, ::8, ::7].numpy() - g['final_logits_sub']).max())
+        mask = np.packbits((out >= 0).numpy().astype(np.uint8))
+        m['mask_bits'] = int(np.unpackbits(mask ^ g['final_mask']).sum())
+        m['near_zero'] = int(g['final_near_zero'][0])
+        m['finite'] = bool(torch.isfinite(out).all() and torch.isfinite(params).all())
+        eng.close()
+        # the K = 2 meta task at 96x160
+        e2 = Engine('resnet50', *SMALL, max_batch=1, device=DEV)
+        e2.load_model_state(sd, lrs)
+        x, y = synthetic.synthetic_frames(1, *SMALL, seed=1002)
+        x, y = x.to(DEV), y.to(DEV)
+        e2.meta_task_begin()
+        tl = [e2.finetune_step(x, y, accumulate=True) for _ in range(2)]
+        flat = torch.zeros(e2.n_lr + e2.n_param, device=DEV)
+        ml = e2.meta_grad(torch.flip(x, dims=[3]).contiguous(), torch.flip(y, dims=[3]).contiguous(), flat)
+        flat = flat.cpu()
+        m['meta_train_rel'] = float(np.max(np.abs(np.array(tl) - g['meta_train_losses']) / np.abs(g['meta_train_losses'])))
+        m['meta_loss_rel'] = abs(ml - float(g['meta_loss'][0])) / abs(float(g['meta_loss'][0]))
+        ref = g['meta_lr_grad']
+        m['meta_lr_grad'] = float(np.abs(flat[:e2.n_lr].numpy() - ref).max() / np.abs(ref).max())
+        names = [n for n, _ in tr]
+        k = names.index('decoder.conv1.weight')
+        ref = g['meta_init_grad_dec1']
+        got = flat[e2.n_lr + offs[k]:e2.n_lr + offs[k + 1]].view(*ref.shape).numpy()
+        m['meta_init_grad_dec1'] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        m['meta_init_l2'] = max(abs(float(flat[e2.n_lr + offs[i]:e2.n_lr + offs[i + 1]].double().norm()) - g['meta_init_grad_fp'][i][1])
+                                / (g['meta_init_grad_fp'][i][1] + 1e-30) for i in range(len(tr)))
+        e2.close()
+    finally:
+        engine_mod.set_matrix_mode(prev)
+    return m
+
+
+@pytest.mark.parametrize('mode', ['default', 'bf16x6'])
+def test_g19_heavy_tailed_norm_statistics_vs_reference(mode):
+    if mode == 'default':
+        mode = engine_mod.get_matrix_mode()
+    m = run_g19(mode)
+    print('G19 margins', mode, m)
+    assert m['finite']
+    assert m['loss_rel'] <= 1e-4, m
+    assert max(m['grad_elem'].values()) <= 1e-3, m                 # first-step gradients: <= 1e-3 of each tensor's maximum
+    assert m['grad_l2'] <= 1e-3 and m['grad_absmax'] <= 1e-3, m    # all 64 tensors
+    assert m['param_elem'] <= 1e-5, m
+    assert m['logits_abs'] <= 1e-3, m                              # north_star: logits within 1e-3
+    assert m['mask_bits'] <= m['near_zero'], m                     # label bits exact outside the near-zero count
+    assert m['meta_train_rel'] <= 1e-4 and m['meta_loss_rel'] <= 2e-4, m
+    assert m['meta_lr_grad'] <= 2e-3 and m['meta_init_grad_dec1'] <= 2e-3 and m['meta_init_l2'] <= 2e-3, m

@@ -260,3 +260,29 @@ def test_g14_bptt_schedules(golden_dir, tag, bptt, multi):
         fp_close(a, b, rtol=2e-3)
     ref_last = g[tag + '_init_grad_last']
     assert np.abs(out['g_init'][-2].numpy() - ref_last).max() <= 2e-3 * np.abs(ref_last).max()
+
+
+def test_g19_heavy_tailed_state_meta_task(golden_dir):
+    """The oracle on `synthetic.heavy_tailed_state` (BatchNorm statistics over 4-6 decades, near-dead channels) against
+    the reference's autograd: K = 2 meta task at 96x160 of fixture G19."""
+    g = np.load(os.path.join(golden_dir, 'g19_heavy_tailed.npz'))
+    sd, lrs = synthetic.heavy_tailed_state(), synthetic.synthetic_lrs()
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=1002)
+    out = meta.meta_task(sd, lrs, [(x, y)] * 2, (torch.flip(x, dims=[3]), torch.flip(y, dims=[3])))
+    np.testing.assert_allclose(out['train_losses'], g['meta_train_losses'], rtol=2e-4)
+    assert abs(out['meta_loss'] - g['meta_loss'][0]) < 2e-4 * abs(g['meta_loss'][0])
+    lr_g = torch.cat([t.flatten() for t in out['g_lr']]).numpy()
+    assert np.abs(lr_g - g['meta_lr_grad']).max() <= 2e-3 * np.abs(g['meta_lr_grad']).max()
+    for a, b in zip(np.stack([fp(t) for t in out['g_init']]), g['meta_init_grad_fp']):
+        fp_close(a, b, rtol=2e-3)
+
+
+def test_g19_heavy_tailed_state_c2_first_iteration(golden_dir):
+    """Same state, the benchmarked shape (480x854, batch 3): loss and all 64 gradient norms of the first iteration."""
+    g = np.load(os.path.join(golden_dir, 'g19_heavy_tailed.npz'))
+    sd, lrs = synthetic.heavy_tailed_state(), synthetic.synthetic_lrs()
+    x, y = synthetic.synthetic_frames(3, 480, 854, seed=21)
+    loss, grads, _ = meta.finetune_step(sd, lrs, x, y)
+    assert abs(float(loss) - g['losses'][0]) <= 2e-5 * g['losses'][0]
+    for gr, ref in zip(grads, g['grad_fp']):
+        assert abs(float(gr.double().norm()) - ref[1]) <= 1e-3 * ref[1] + 1e-12
