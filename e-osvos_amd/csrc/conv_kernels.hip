@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
       if (p.scale) sc = ldg4(p.scale + n);
       if (p.bias) bi = ldg4(p.bias + n);
     }
-    const bool use_mask = p.mask && n >= p.mask_c0;
+    const bool use_mask8 = p.mask8 && n >= p.mask_c0;
+    const bool use_mask = !use_mask8 && p.mask && n >= p.mask_c0;
+    const bool write_m8 = p.mask8_out && p.relu;
 #pragma unroll
     for (int ep = 0; ep < EPASS; ++ep) {
       if (ep) __syncthreads();
@@ -367,7 +369,8 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
           for (int it0 = 0; it0 < NIT; it0 += EB) {
             size_t md[EB];
             bool ok[EB];
-            float4 rs[EB], ac[EB], mk[EB];
+            float4 rs[EB], ac[EB];
+            unsigned mk8[EB];                 // ReLU mask bits of the row's 4 channels (from mask bytes, or from the fp32 activation)
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
               const int m = m0 + trow(c_r + (it0 + j) * CROWS);
@@ -382,9 +385,12 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
 #pragma unroll
               for (int j = 0; j < EB; ++j) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
             }
-            if (use_mask) {
+            if (use_mask8) {
 #pragma unroll
-              for (int j = 0; j < EB; ++j) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
+              for (int j = 0; j < EB; ++j) mk8[j] = p.mask8[md[j] * p.ldm8 + (n >> 2)];
+            } else if (use_mask) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) mk8[j] = relu_bits(ldg4(p.mask + md[j] * p.ldmask + n));
             }
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
@@ -394,11 +400,11 @@ __global__ __launch_bounds__(256, DEEP ? 3 : EOSVOS_OCC) void conv_igemm_kernel(
               if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
               if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
               if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-              if (use_mask) {
-                v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
-                v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
+              if (use_mask8 || use_mask) relu_mask8(v, mk8[j]);
+              if (ok[j]) {
+                *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+                if (write_m8) p.mask8_out[md[j] * p.ldm8_out + (n >> 2)] = relu_bits(v);
               }
-              if (ok[j]) *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
             }
           }
         }
@@ -444,11 +450,13 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.scale) sc = ldg4(p.scale + n);
   if (p.bias) bi = ldg4(p.bias + n);
-  const bool use_mask = p.mask && n >= p.mask_c0;
+  const bool use_mask8 = p.mask8 && n >= p.mask_c0;
+  const bool use_mask = !use_mask8 && p.mask && n >= p.mask_c0;
   size_t md[RPB];
+  unsigned mk8[RPB];
   bool ok[RPB];
   int rows[RPB];
-  float4 rs[RPB], ac[RPB], mk[RPB], sum[RPB];
+  float4 rs[RPB], ac[RPB], sum[RPB];
 #pragma unroll
   for (int j = 0; j < RPB; ++j) {
     rows[j] = blockIdx.y * (BM / 8) + c_r + j * CROWS;
@@ -458,7 +466,8 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
     sum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.res) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
     if (p.accum) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
-    if (use_mask) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
+    if (use_mask) mk8[j] = relu_bits(ldg4(p.mask + md[j] * p.ldmask + n));
+    if (use_mask8) mk8[j] = p.mask8[md[j] * p.ldm8 + (n >> 2)];
   }
   for (int g = g0; g <= g1; g += 4) {
     float4 t[4][RPB];
@@ -488,11 +497,9 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
     if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
     if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (use_mask) {
-      v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
-      v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
-    }
+    if (use_mask8 || use_mask) relu_mask8(v, mk8[j]);
     *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+    if (p.mask8_out && p.relu) p.mask8_out[md[j] * p.ldm8_out + (n >> 2)] = relu_bits(v);
     ymax = amax_f4(ymax, v);
   }
   if (p.amax_y) amax_block_commit(ymax, p.amax_y);
@@ -992,7 +999,9 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
       if (p.scale) sc = ldg4(p.scale + n);
       if (p.bias) bi = ldg4(p.bias + n);
     }
-    const bool use_mask = p.mask && n >= p.mask_c0;
+    const bool use_mask8 = p.mask8 && n >= p.mask_c0;
+    const bool use_mask = !use_mask8 && p.mask && n >= p.mask_c0;
+    const bool write_m8 = p.mask8_out && p.relu;
     {
       // D of 16x16x32: lane (fr = column, fq) holds rows 4*fq .. 4*fq+3 of the fragment
 #pragma unroll
@@ -1012,7 +1021,8 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
           for (int it0 = 0; it0 < NIT; it0 += EB) {
             size_t md[EB];
             bool ok[EB];
-            float4 rs[EB], ac[EB], mk[EB];
+            float4 rs[EB], ac[EB];
+            unsigned mk8[EB];                 // ReLU mask bits of the row's 4 channels (from mask bytes, or from the fp32 activation)
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
               const int m = m0 + c_r + (it0 + j) * CROWS;
@@ -1027,9 +1037,12 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
 #pragma unroll
               for (int j = 0; j < EB; ++j) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
             }
-            if (use_mask) {
+            if (use_mask8) {
 #pragma unroll
-              for (int j = 0; j < EB; ++j) mk[j] = ldg4(p.mask + md[j] * p.ldmask + n);
+              for (int j = 0; j < EB; ++j) mk8[j] = p.mask8[md[j] * p.ldm8 + (n >> 2)];
+            } else if (use_mask) {
+#pragma unroll
+              for (int j = 0; j < EB; ++j) mk8[j] = relu_bits(ldg4(p.mask + md[j] * p.ldmask + n));
             }
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
@@ -1039,12 +1052,10 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
               if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
               if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
               if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-              if (use_mask) {
-                v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
-                v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
-              }
+              if (use_mask8 || use_mask) relu_mask8(v, mk8[j]);
               if (ok[j]) {
                 *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+                if (write_m8) p.mask8_out[md[j] * p.ldm8_out + (n >> 2)] = relu_bits(v);
                 if (NP == 2) ymax = amax_f4(ymax, v);
               }
             }

@@ -267,6 +267,14 @@ struct eosvos_engine {
   std::map<const float*, TRec> treg[2];
   static constexpr int TSLOTS = 384;   // per phase
 
+  // ReLU masks as bytes (ConvArgs::mask8): one buffer per activation tensor a data gradient masks with, written by the
+  // forward epilogue that applies the ReLU (frozen-BN mode: every producer has the fused write; GroupNorm mode has none and
+  // keeps reading the fp32 activation)
+  std::map<const float*, uint8_t*> mask8;
+  uint8_t* m8(const float* key) const {
+    auto it = mask8.find(key);
+    return it == mask8.end() ? nullptr : it->second;
+  }
   int64_t max_alloc_floats = 0;      // largest single allocation (every conv operand is one of them)
   // EOSVOS_DEBUG_GUARD=1: every buffer sits between two 256 KB guard bands filled with a pattern;
   // eosvos_debug_check_guards reports bands a kernel wrote into (out-of-bounds writes)
@@ -646,14 +654,15 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     // the output transform writes y (directly, or the raw conv output of the GroupNorm mode)
     unsigned* yslot = gn ? nullptr : twrite_fused(e, 0, ykey, ldy == c.cout);
     if (gn) twrite_plain(e, 0, ykey);
+    uint8_t* ym8 = (gn || !e->m8(ykey)) ? nullptr : e->m8(ykey) + (y - ykey) / 4;
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
     if (wg.tm == 4)
       launch_wino4_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
-                          (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st, yslot);
+                          (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st, yslot, ym8, ldy / 4);
     else
       launch_wino_output(e->wino_m, prow, c.cout, B, a.Ho, a.Wo, th, tw, wg.d, gn ? nullptr : e->A_(ci), gn ? nullptr : e->B_(ci),
-                         (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st, yslot);
+                         (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st, yslot, ym8, ldy / 4);
     if (gn)
       launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
                         a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st);
@@ -664,6 +673,8 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   } else {
     a.scale = e->A_(ci); a.bias = e->B_(ci);
     a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
+    if (relu)
+      if (uint8_t* m = e->m8(ykey)) { a.mask8_out = m + (y - ykey) / 4; a.ldm8_out = ldy / 4; }
   }
   attach_tap_table(e, ci, 0, B, a);
   if (h3_mode() && !amax_init(e)) {
@@ -699,6 +710,8 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   a.M = B * Hin * Win; a.wN = c.cout; a.wK = c.cin; a.kmajor = 1;
   a.kscale = e->A_(ci);
   a.mask = mask; a.ldmask = ldmask; a.mask_c0 = mask_c0; a.accum = accum ? 1 : 0;
+  const uint8_t* mask8 = mask ? e->m8(mask) : nullptr;      // the byte form of the same mask, when its producer wrote one
+  a.mask8 = mask8; a.ldm8 = ldmask / 4;
   a.res = add; a.ldres = ldadd;
   const bool wino_dg = !add && wino_on(e, ci, B, Hin, Win);
   if (h3_mode() && !wino_dg && !amax_init(e)) {
@@ -753,9 +766,11 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
       launch_conv(m, e->s);
     }
     if (wg.tm == 4)
-      launch_wino4_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s, gxs);
+      launch_wino4_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s, gxs,
+                                mask8, ldmask / 4);
     else
-      launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s, gxs);
+      launch_wino_dgrad_output(e->wino_dv, prow, c.cin, B, Hin, Win, th, tw, wg.d, mask, ldmask, mask_c0, accum ? 1 : 0, gx, ldgx, e->s, gxs,
+                               mask8, ldmask / 4);
     return;
   }
   if (c.k == 1 && c.stride == 2 && !add) {
@@ -775,6 +790,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     launch_conv(a, e->s);
     b.N = tail; b.w += a.N; b.y += a.N;
     if (b.mask) { b.mask += a.N; b.mask_c0 = b.mask_c0 > a.N ? b.mask_c0 - a.N : 0; }
+    if (b.mask8) b.mask8 += a.N / 4;
     if (b.res) b.res += a.N;
     trace("dgrad", ci, b.M, b.N, (long)c.T() * c.cout, conv_plan(b));
     launch_conv(b, e->s);
@@ -1304,6 +1320,22 @@ int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, i
   ALLOC(e->lowlog, n4); ALLOC(e->g_low, n4);
   ALLOC(e->logits, (int64_t)B * H * W); ALLOC(e->dlogits, (int64_t)B * H * W);
   ALLOC(e->loss_dev, 4); ALLOC(e->bce_partial, 4 * 1024 + 16);
+  if (!e->gn() && !getenv("EOSVOS_TUNE_NO_MASK8")) {          // (A/B switch: data gradients read the fp32 activations as masks)
+    auto m8alloc = [&](const float* key, int64_t floats) {     // one byte per 4 floats
+      float* p = e->falloc((floats / 4 + 3) / 4);
+      if (p) e->mask8[key] = (uint8_t*)p;
+      return p != nullptr;
+    };
+    bool ok = true;
+    for (size_t i = 0; i < t.blocks.size(); ++i) {
+      const Block& b = t.blocks[i];
+      const auto& f = e->bb[i];
+      const int64_t nm = (int64_t)B * f.Hm * f.Wm, no = (int64_t)B * f.Ho * f.Wo;
+      ok = ok && m8alloc(f.t1, nm * t.convs[b.c1].cout) && m8alloc(f.t2, no * t.convs[b.c2].cout) && m8alloc(f.out, no * t.convs[b.c3].cout);
+    }
+    ok = ok && m8alloc(e->cat, n16 * 1280) && m8alloc(e->dcat, n4 * 304) && m8alloc(e->d1, n4 * 256);
+    if (!ok) { eosvos_destroy(e); return fail("hipMalloc ReLU mask bytes"); }
+  }
   for (int i = 0; i < 4; ++i) track(t.aspp[i], e->h16, e->w16);
   track(t.project, e->h16, e->w16);
   if (t.v3) {
@@ -1636,7 +1668,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
     if ((int)i == t.layer1_last_block && fside && !t.v3) {
       // decoder.conv1 reads the layer1 feature only: it runs beside layer2..4 + ASPP
       fork(t.dec1);
-      conv_fwd(e, t.dec1, f.out, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true, true);
+      conv_fwd(e, t.dec1, f.out, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true, true, nullptr, e->dcat);
       (void)hipEventRecord(e->ev[t.dec_a], e->s2);
     }
   }
@@ -1652,7 +1684,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   } else {
     launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, s);
   }
-  launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s);
+  launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s, e->m8(e->cat) ? e->m8(e->cat) + 1024 / 4 : nullptr, 1280 / 4);
   if (h3_mode() && !e->gn() && !amax_init(e)) {
     // cat = 4 conv outputs (their epilogues fed the tensor's slot) + the broadcast pooling branch (its B x 256 values here)
     if (unsigned* cs = tslot(e, 0, e->cat)) { launch_absmax(e->poolout, 1, B * 256, B * 256, cs, s); tmark_valid(e, 0, e->cat); }
@@ -1666,7 +1698,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   } else {
     const float* low = e->bb[t.layer1_last_block].out;
     if (fside) (void)hipStreamWaitEvent(s, e->ev[t.dec_a], 0);
-    else conv_fwd(e, t.dec1, low, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true);
+    else conv_fwd(e, t.dec1, low, 256, e->h4, e->w4, e->dcat + 256, 304, B, nullptr, 0, true, false, nullptr, e->dcat);
     launch_resize_fwd(e->proj, 256, e->dcat, 304, B, 256, e->up_h, e->up_w, s);
     conv_fwd(e, t.dec_a, e->dcat, 304, e->h4, e->w4, e->d1, 256, B, nullptr, 0, true);
     conv_fwd(e, t.dec_b, e->d1, 256, e->h4, e->w4, e->d2, 256, B, nullptr, 0, true);
@@ -1810,7 +1842,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     if (b.ds >= 0 && flush_wgrad_group(e, t.stage[b.c1], B)) return 1;
   }
   // stem
-  launch_maxpool_bwd(e->g_p1, e->p1idx, e->c1, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s);
+  launch_maxpool_bwd(e->g_p1, e->p1idx, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s);
   {
     const int chunks = stem_wgrad_chunks(B, e->h2, e->w2);
     const float* gc1 = e->g_c1;

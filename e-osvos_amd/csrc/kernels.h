@@ -22,6 +22,13 @@ __device__ __forceinline__ unsigned amax_f4(unsigned m, const float4& v) {
   const unsigned q = ab > cd ? ab : cd;
   return m > q ? m : q;
 }
+// ReLU mask bytes (ConvArgs::mask8): bit j of a byte = (channel 4q + j > 0)
+__device__ __forceinline__ uint8_t relu_bits(const float4& v) {
+  return (uint8_t)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+}
+__device__ __forceinline__ void relu_mask8(float4& v, unsigned bits) {
+  v.x = (bits & 1u) ? v.x : 0.f; v.y = (bits & 2u) ? v.y : 0.f; v.z = (bits & 4u) ? v.z : 0.f; v.w = (bits & 8u) ? v.w : 0.f;
+}
 // An absmax slot is AMAX_SUB words, AMAX_ROW words apart (word j of slot s = base[j * AMAX_ROW + s]): a workgroup
 // raises word (its index % AMAX_SUB) with one fire-and-forget atomic, the consumer takes the maximum of the AMAX_SUB
 // words.  Measured (tools/probes/atomic_probe.cpp, 2048 workgroups): all on ONE word 25 us (11 ns per atomic, they
@@ -88,6 +95,14 @@ struct ConvArgs {
   int ldres;
   const float* mask;    // dgrad: out = 0 where mask[m][n] <= 0 for n >= mask_c0
   int ldmask, mask_c0;
+  // ReLU masks as bytes: one byte per 4 consecutive channels of a pixel, bit j = (channel 4q + j of the forward activation
+  // > 0), ldm8 bytes per pixel (= the tensor's floats per pixel / 4).  The forward epilogue that applies the ReLU writes
+  // them (mask8_out), the data gradient reads them (mask8, used instead of `mask` when set): 1/16 of the fp32 activation
+  // the mask used to be read from.  Pointers carry the same channel offset (/ 4) as the views they describe.
+  const uint8_t* mask8;
+  int ldm8;
+  uint8_t* mask8_out;
+  int ldm8_out;
   int relu;
   int accum;            // dgrad: add the existing contents of y
   int plane_rows;       // != 0: batched GEMM -- rows [k*plane_rows, (k+1)*plane_rows) use the weights w + k*w_plane
@@ -191,14 +206,18 @@ void launch_wino4_grad(const float* g, int ldg, int C, int B, int H, int W, int 
                        hipStream_t s, unsigned* amax = nullptr);
 void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscale, float* U, float* Us, hipStream_t s, unsigned* amax_u = nullptr, unsigned* amax_us = nullptr);
 void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                         const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax = nullptr);
+                         const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax = nullptr,
+                         uint8_t* mask8_out = nullptr, int ldm8 = 0);
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
 void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax = nullptr);   // U = G (rowscale*w) G^T
+                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax = nullptr,
+                               const uint8_t* mask8 = nullptr, int ldm8 = 0);   // U = G (rowscale*w) G^T
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax = nullptr);   // dX = mask?(B dV B^T, overlapped)
+                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax = nullptr,
+                              const uint8_t* mask8 = nullptr, int ldm8 = 0);   // dX = mask?(B dV B^T, overlapped)
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                        const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax = nullptr);        // y = epilogue(A^T M A)
+                        const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax = nullptr,
+                        uint8_t* mask8_out = nullptr, int ldm8 = 0);        // y = epilogue(A^T M A)
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s);
 
 // ---------------------------------------------------------------------------------
@@ -223,8 +242,9 @@ int stem_wgrad_chunks(int B, int Ho, int Wo);
 
 void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int Ho,
                         int Wo, hipStream_t s);
-// g_x = relu_mask(x) * scatter(g_y)   (x = the ReLU output that was pooled)
-void launch_maxpool_bwd(const float* gy, const uint8_t* idx, const float* x, float* gx, int B, int H,
+// g_x = relu_mask(x) * scatter(g_y)   (x = the ReLU output that was pooled: bit 7 of idx = "the window's maximum is > 0",
+// i.e. the ReLU mask of the one input pixel the gradient goes to -- the backward pass does not read x)
+void launch_maxpool_bwd(const float* gy, const uint8_t* idx, float* gx, int B, int H,
                         int W, int C, int Ho, int Wo, hipStream_t s);
 
 // Bilinear resize tables (host-built, PyTorch's index/weight rule) live in device memory:
@@ -252,7 +272,7 @@ void launch_gemv_fwd(const float* W, const float* v, const float* a, const float
 void launch_gemv_bwd(const float* W, const float* v, const float* gp, const float* a, float* gv,
                      float* dW, int B, int N, int K, hipStream_t s);
 void launch_bcast_pixels(const float* v /*[B][C]*/, float* y, int ldy, int B, int P, int C, float alpha,
-                         hipStream_t s);
+                         hipStream_t s, uint8_t* mask8_out = nullptr, int ldm8 = 0);   // mask8_out: (value > 0) bytes, see ConvArgs
 
 // classifier 1x1 conv with Cout = 1 (+bias) and its backward
 void launch_last_fwd(const float* x, const float* w, const float* bias, float* y, int64_t P, int C,

@@ -343,6 +343,9 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
       }
     }
     *reinterpret_cast<float4*>(y + pix * C + c4 * 4) = make_float4(m[0], m[1], m[2], m[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (m[j] > 0.f) mi[j] |= 0x80;            // the ReLU mask of the pixel the gradient will go to
     *reinterpret_cast<uchar4*>(idx + pix * C + c4 * 4) = make_uchar4(mi[0], mi[1], mi[2], mi[3]);
   }
 }
@@ -353,7 +356,7 @@ void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, in
                      Wo);
 }
 __global__ void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
-                                   const float* __restrict__ x, float* __restrict__ gx, int B, int H, int W,
+                                   float* __restrict__ gx, int B, int H, int W,
                                    int C, int Ho, int Wo) {
   const int C4 = C >> 2;
   const long n = (long)B * H * W * C4;
@@ -370,7 +373,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* 
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
         if (ox >= Wo) continue;
         const int kx = ix + 1 - 2 * ox;
-        const unsigned char k = (unsigned char)(ky * 3 + kx);
+        const unsigned char k = (unsigned char)((ky * 3 + kx) | 0x80);      // argmax here AND its value > 0
         const long o = (((long)b * Ho + oy) * Wo + ox) * C + c4 * 4;
         const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o);
         const float4 g = *reinterpret_cast<const float4*>(gy + o);
@@ -380,16 +383,13 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* 
         if (id.w == k) s[3] += g.w;
       }
     }
-    const float4 xv = *reinterpret_cast<const float4*>(x + pix * C + c4 * 4);
-    *reinterpret_cast<float4*>(gx + pix * C + c4 * 4) =
-        make_float4(xv.x > 0.f ? s[0] : 0.f, xv.y > 0.f ? s[1] : 0.f, xv.z > 0.f ? s[2] : 0.f,
-                    xv.w > 0.f ? s[3] : 0.f);
+    *reinterpret_cast<float4*>(gx + pix * C + c4 * 4) = make_float4(s[0], s[1], s[2], s[3]);
   }
 }
-void launch_maxpool_bwd(const float* gy, const uint8_t* idx, const float* x, float* gx, int B, int H, int W,
+void launch_maxpool_bwd(const float* gy, const uint8_t* idx, float* gx, int B, int H, int W,
                         int C, int Ho, int Wo, hipStream_t s) {
   const long n = (long)B * H * W * (C >> 2);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, gy, idx, x, gx, B, H, W, C,
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, gy, idx, gx, B, H, W, C,
                      Ho, Wo);
 }
 
@@ -572,7 +572,7 @@ void launch_gemv_bwd(const float* W, const float* v, const float* gp, const floa
   hipLaunchKernelGGL(gemv_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, W, v, gp, a, gv, dW, B, N, K);
 }
 __global__ void bcast_pixels_kernel(const float* __restrict__ v, float* __restrict__ y, int ldy, int B, int P,
-                                    int C, float alpha) {
+                                    int C, float alpha, uint8_t* __restrict__ mask8_out, int ldm8) {
   const int C4 = C >> 2;
   const long n = (long)B * P * C4;
   GRID_STRIDE(e, n) {
@@ -582,11 +582,12 @@ __global__ void bcast_pixels_kernel(const float* __restrict__ v, float* __restri
     float4 t = *reinterpret_cast<const float4*>(v + (long)b * C + c4 * 4);
     t.x *= alpha; t.y *= alpha; t.z *= alpha; t.w *= alpha;
     *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = t;
+    if (mask8_out) mask8_out[pix * ldm8 + c4] = relu_bits(t);
   }
 }
-void launch_bcast_pixels(const float* v, float* y, int ldy, int B, int P, int C, float alpha, hipStream_t s) {
+void launch_bcast_pixels(const float* v, float* y, int ldy, int B, int P, int C, float alpha, hipStream_t s, uint8_t* mask8_out, int ldm8) {
   const long n = (long)B * P * (C >> 2);
-  hipLaunchKernelGGL(bcast_pixels_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, v, y, ldy, B, P, C, alpha);
+  hipLaunchKernelGGL(bcast_pixels_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, v, y, ldy, B, P, C, alpha, mask8_out, ldm8);
 }
 
 // ---- classifier conv (Cout = 1, bias) ------------------------------------------------------------
@@ -1528,7 +1529,8 @@ void launch_wino_weight(const float* w, int Cout, int Cin, const float* rowscale
 __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
                                                                  int W, int th, int tw, int dil,
                                                                  const float* __restrict__ mask, int ldmask, int mask_c0,
-                                                                 int accum, float* __restrict__ gx, int ldgx, unsigned* __restrict__ amax) {
+                                                                 int accum, float* __restrict__ gx, int ldgx, unsigned* __restrict__ amax,
+                                                                 const uint8_t* __restrict__ mask8, int ldm8) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;      // one 2x2 block of a sub-grid per tile position
   unsigned am = 0;
@@ -1603,7 +1605,9 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
           const float4 o = *reinterpret_cast<const float4*>(gx + pix * ldgx + c4 * 4);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-        if (mask && c4 * 4 >= mask_c0) {
+        if (mask8 && c4 * 4 >= mask_c0) {
+          relu_mask8(v, mask8[pix * ldm8 + c4]);
+        } else if (mask && c4 * 4 >= mask_c0) {
           const float4 m = *reinterpret_cast<const float4*>(mask + pix * ldmask + c4 * 4);
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
@@ -1615,16 +1619,17 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_kernel(const float* __r
   if (amax) amax_block_commit(am, amax);
 }
 void launch_wino_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax) {
+                              const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax,
+                              const uint8_t* mask8, int ldm8) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
-                     dil, mask, ldmask, mask_c0, accum, gx, ldgx, amax);
+                     dil, mask, ldmask, mask_c0, accum, gx, ldgx, amax, mask8, ldm8);
 }
 // y (NHWC, ld ldy) = relu?(scale * (A^T M A) + bias) from M[p][tile][c], A^T = [[1,1,1,0],[0,1,-1,-1]]
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
                                                            int th, int tw, int dil, const float* __restrict__ scale,
                                                            const float* __restrict__ bias, int relu, float* __restrict__ y,
-                                                           int ldy, unsigned* __restrict__ amax) {
+                                                           int ldy, unsigned* __restrict__ amax, uint8_t* __restrict__ mask8_out, int ldm8) {
   const int C4 = C >> 2;
   const long ntile = (long)B * dil * dil * th * tw, n = ntile * C4;
   unsigned am = 0;
@@ -1662,16 +1667,17 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         am = amax_f4(am, v);
         *reinterpret_cast<float4*>(y + (((long)b * H + yy) * W + xx) * ldy + c4 * 4) = v;
+        if (mask8_out) mask8_out[(((long)b * H + yy) * W + xx) * ldm8 + c4] = relu_bits(v);
       }
     }
   }
   if (amax) amax_block_commit(am, amax);
 }
 void launch_wino_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                        const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax) {
+                        const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax, uint8_t* mask8_out, int ldm8) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, dil,
-                     scale, bias, relu, y, ldy, amax);
+                     scale, bias, relu, y, ldy, amax, relu ? mask8_out : nullptr, ldm8);
 }
 void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
   const long n = (long)Cout * (Cin / 4);
@@ -1842,7 +1848,7 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, long prow, int C, int B, int H, int W,
                                                             int th, int tw, int dil, const float* __restrict__ scale,
                                                             const float* __restrict__ bias, int relu, float* __restrict__ y,
-                                                            int ldy, unsigned* __restrict__ amax) {
+                                                            int ldy, unsigned* __restrict__ amax, uint8_t* __restrict__ mask8_out, int ldm8) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
   unsigned am = 0;
@@ -1882,6 +1888,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         am = amax_f4(am, v);
         *reinterpret_cast<float4*>(y + (((long)b * H + yy) * W + xx) * ldy + c4 * 4) = v;
+        if (mask8_out) mask8_out[(((long)b * H + yy) * W + xx) * ldm8 + c4] = relu_bits(v);
       }
     }
   }
@@ -1935,7 +1942,8 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
 __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __restrict__ dV, long prow, int C, int B, int H,
                                                                   int W, int th, int tw, int dil,
                                                                   const float* __restrict__ mask, int ldmask, int mask_c0,
-                                                                  int accum, float* __restrict__ gx, int ldgx, unsigned* __restrict__ amax) {
+                                                                  int accum, float* __restrict__ gx, int ldgx, unsigned* __restrict__ amax,
+                                                                  const uint8_t* __restrict__ mask8, int ldm8) {
   const int C4 = C >> 2;
   const long n = (long)B * dil * dil * th * tw * C4;
   unsigned am = 0;
@@ -2019,7 +2027,9 @@ __global__ __launch_bounds__(256) void wino4_dgrad_output_kernel(const float* __
           const float4 o = *reinterpret_cast<const float4*>(gx + pix * ldgx + c4 * 4);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-        if (mask && c4 * 4 >= mask_c0) {
+        if (mask8 && c4 * 4 >= mask_c0) {
+          relu_mask8(v, mask8[pix * ldm8 + c4]);
+        } else if (mask && c4 * 4 >= mask_c0) {
           const float4 m = *reinterpret_cast<const float4*>(mask + pix * ldmask + c4 * 4);
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
@@ -2046,19 +2056,20 @@ void launch_wino4_weight(const float* w, int Cout, int Cin, const float* rowscal
   hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, Cout, Cin, rowscale, U, Us, amax_u, amax_us);
 }
 void launch_wino4_output(const float* M, long prow, int C, int B, int H, int W, int th, int tw, int dil, const float* scale,
-                         const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax) {
+                         const float* bias, int relu, float* y, int ldy, hipStream_t s, unsigned* amax, uint8_t* mask8_out, int ldm8) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, M, prow, C, B, H, W, th, tw, dil,
-                     scale, bias, relu, y, ldy, amax);
+                     scale, bias, relu, y, ldy, amax, relu ? mask8_out : nullptr, ldm8);
 }
 void launch_wino4_wgrad_finish(const float* ws, int splits, int Cout, int Cin, float* dst, hipStream_t s) {
   const long n = (long)Cout * Cin;
   hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, ws, splits, Cout, Cin, dst);
 }
 void launch_wino4_dgrad_output(const float* dV, long prow, int C, int B, int H, int W, int th, int tw, int dil,
-                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax) {
+                               const float* mask, int ldmask, int mask_c0, int accum, float* gx, int ldgx, hipStream_t s, unsigned* amax,
+                               const uint8_t* mask8, int ldm8) {
   const long n = (long)B * dil * dil * th * tw * (C / 4);
   hipLaunchKernelGGL(wino4_dgrad_output_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, dV, prow, C, B, H, W, th, tw,
-                     dil, mask, ldmask, mask_c0, accum, gx, ldgx, amax);
+                     dil, mask, ldmask, mask_c0, accum, gx, ldgx, amax, mask8, ldm8);
 }
 }  // namespace eosvos
