@@ -68,6 +68,11 @@ _SIGNATURES = {
                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, ctypes.c_int, ctypes.c_float, ctypes.c_float]),
     'eosvos_clamp': (ctypes.c_int, [_E, c_float_p, ctypes.c_int64, ctypes.c_float, ctypes.c_float]),
+    'eosvos_outer_step': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_int, ctypes.c_int64, ctypes.c_int64]),
+    'eosvos_alias_state': (ctypes.c_int, [_E, _E]),
     'eosvos_time_hot_kernel': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                               ctypes.POINTER(ctypes.c_double)]),
     'eosvos_bench_conv': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

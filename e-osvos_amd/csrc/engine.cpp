@@ -248,6 +248,8 @@ struct eosvos_engine {
   bool have_loss_grad = false;
   int force_algo = 0;                 // EOSVOS_ALGO_*: 0 = plan by work size; the op-level parity tests force one path
   int wg_budget = 0;                  // eosvos_set_wg_budget: workgroups a launch plans for (0 = the whole chip)
+  OuterEnt* outer_tab = nullptr;      // eosvos_outer_step: device table of the trainable tensors
+  int outer_blocks = 0;
   int plan_mode = -1;                 // matrix mode the cached launch plans (wg_plans, upd_tab) were built for, see plans_match_mode()
 
   // f16x3 matrix mode: absmax slots (bit patterns of max|x|), kind-major [AM_KINDS][nconv]; see amax_get()
@@ -2103,6 +2105,63 @@ int eosvos_radam_step(eosvos_engine* e, float* param, const float* grad, float* 
   launch_radam(param, grad, exp_avg, exp_avg_sq, n, lr, weight_decay, beta1, beta2, eps, (float)step_size,
                use_denom, grad_scale, grad_clip, e->s);
   HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_outer_step(eosvos_engine* e, float* state, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_lr,
+                      int learn_model_init, int step, float lr_lr, float init_lr, float weight_decay, float beta1, float beta2,
+                      float eps, float grad_scale, float grad_clip, float lr_lo, float lr_hi, int use_log,
+                      int64_t frozen_lr, int64_t frozen_param) {
+  if (!e || !state || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail("bad argument");
+  const Topo& t = e->t;
+  if (n_lr != t.nlr) return fail("eosvos_outer_step handles the NEURON lr hierarchy level only (n_lr must be eosvos_lr_count)");
+  if (!e->outer_tab) {
+    std::vector<OuterEnt> tab;
+    int blk = 0;
+    for (const ConvL& c : t.convs) {
+      OuterEnt o;
+      o.off = c.poff; o.O = c.cout; o.I = c.cin; o.T = c.T();
+      o.n = (int)(c.wsize() + (c.bias ? c.cout : 0)); o.blk0 = blk;
+      blk += (o.n + 1023) / 1024;
+      tab.push_back(o);
+    }
+    if (tab.size() > 256) return fail("eosvos_outer_step: more than 256 trainable tensors");
+    e->outer_tab = (OuterEnt*)e->falloc((int64_t)(tab.size() * sizeof(OuterEnt) + 3) / 4);
+    if (!e->outer_tab) return fail("hipMalloc outer-step table");
+    HIPOK(hipMemcpy(e->outer_tab, tab.data(), tab.size() * sizeof(OuterEnt), hipMemcpyHostToDevice));
+    e->outer_blocks = blk;
+  }
+  // radam.py:62-79 in double, as the reference's Python floats (same as eosvos_radam_step)
+  const double b1 = beta1, b2 = beta2;
+  const double beta2_t = pow(b2, (double)step);
+  const double n_sma_max = 2.0 / (1.0 - b2) - 1.0;
+  const double n_sma = n_sma_max - 2.0 * step * beta2_t / (1.0 - beta2_t);
+  OuterHyper h;
+  memset(&h, 0, sizeof(h));
+  if (n_sma >= 5.0) {
+    h.step_size = (float)(sqrt((1.0 - beta2_t) * (n_sma - 4.0) / (n_sma_max - 4.0) * (n_sma - 2.0) / n_sma * n_sma_max /
+                               (n_sma_max - 2.0)) / (1.0 - pow(b1, (double)step)));
+    h.use_denom = 1;
+  } else {
+    h.step_size = (float)(1.0 / (1.0 - pow(b1, (double)step)));
+  }
+  h.n_lr = n_lr; h.frozen_lr = frozen_lr; h.frozen_param = frozen_param;
+  h.lr_lr = lr_lr; h.init_lr = init_lr; h.wd = weight_decay; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
+  h.grad_scale = grad_scale; h.grad_clip = grad_clip; h.lr_lo = lr_lo; h.lr_hi = lr_hi; h.use_log = use_log ? 1 : 0;
+  const int lr_blocks = (int)((n_lr + 1023) / 1024);
+  if (learn_model_init) wino_weights_changed(e);
+  launch_outer_step(e->outer_tab, (int)t.convs.size(), lr_blocks, lr_blocks + (learn_model_init ? e->outer_blocks : 0), state, grad,
+                    exp_avg, exp_avg_sq, e->Winit, e->Wp, e->lr, h, e->s);
+  e->lr_level = EOSVOS_LR_NEURON; e->lr_log = use_log ? 1 : 0;
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int eosvos_alias_state(eosvos_engine* e, eosvos_engine* src) {
+  if (!e || !src) return fail("null engine");
+  if (e == src) return 0;
+  if (e->dev != src->dev || e->arch != src->arch) return fail("eosvos_alias_state: engines of different devices / architectures");
+  HIPOK(hipStreamSynchronize(e->s));
+  e->Winit = src->Winit;              // (e's own buffers stay in its allocation list until it is destroyed)
+  e->lr = src->lr;
   return 0;
 }
 int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi) {

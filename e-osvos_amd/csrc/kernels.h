@@ -336,5 +336,22 @@ void launch_radam(float* p, const float* g, float* m, float* v, int64_t n, float
                   float beta1, float beta2, float eps, float step_size, int use_denom,
                   float grad_scale, float grad_clip, hipStream_t s);
 void launch_clamp(float* p, int64_t n, float lo, float hi, hipStream_t s);
+// Whole outer step of meta-training in ONE launch over the flat learned state [lr state | model_init (OIHW)]
+// (train_meta.py:361-373, radam.py:28-94, meta_optim.py:116-133): g = clip(grad * scale); RAdam with the per-group lr /
+// weight decay; lr-state clamp; grad <- 0; and the engine's copies written on the way out -- the effective per-neuron lr
+// and the init / current weights in the engine layout O,(kh,kw),I.  Tensor entries of the init part:
+struct OuterEnt {
+  long off;        // flat offset of the tensor (weight [+ bias]) = its offset in the engine arena
+  int O, I, T;     // OIHW dims (T = kh * kw)
+  int n;           // elements incl. the bias that follows the weight
+  int blk0;        // first workgroup of this entry (1024 elements per workgroup), counted after the lr-state workgroups
+};
+struct OuterHyper {
+  long n_lr, frozen_lr, frozen_param;     // lr-state elements; leading elements of each part whose group lr is 0 (freeze_encoder)
+  float lr_lr, init_lr, wd, beta1, beta2, eps, step_size, grad_scale, grad_clip, lr_lo, lr_hi;
+  int use_denom, use_log;
+};
+void launch_outer_step(const OuterEnt* tab, int nent, int lr_blocks, int nblocks, float* state, float* grad, float* m, float* v,
+                       float* Winit, float* Wp, float* lr_eff, const OuterHyper& h, hipStream_t s);
 
 }  // namespace eosvos

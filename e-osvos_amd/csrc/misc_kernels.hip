@@ -800,6 +800,74 @@ void launch_radam(float* p, const float* g, float* m, float* v, int64_t n, float
   hipLaunchKernelGGL(radam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, (long)n, lr, wd, beta1,
                      beta2, eps, step_size, use_denom, grad_scale, grad_clip);
 }
+// one RAdam element update, the arithmetic (and its order) of radam_kernel above
+__device__ __forceinline__ float outer_radam(float pv, float graw, float& mm, float& vv, float lr, float wd, const OuterHyper& h) {
+  float gr = graw * h.grad_scale;
+  if (h.grad_clip > 0.f) gr = fminf(fmaxf(gr, -h.grad_clip), h.grad_clip);
+  vv = vv * h.beta2 + (1.f - h.beta2) * gr * gr;
+  mm = mm * h.beta1 + (1.f - h.beta1) * gr;
+  if (wd != 0.f) pv += (-wd * lr) * pv;
+  if (h.use_denom) pv += (-h.step_size * lr) * (mm / (sqrtf(vv) + h.eps));
+  else pv += (-h.step_size * lr) * mm;
+  return pv;
+}
+// Workgroups [0, lr_blocks): the lr state (1024 elements each); the rest: the init part, tensor by tensor in OIHW order
+// (the 4 state streams are read and written coalesced; the two engine-layout writes are scattered by the O,(kh,kw),I permute
+// -- neighbouring threads of a 3x3 conv write kh*kw lines apart, the L2 merges them into full lines).
+__global__ __launch_bounds__(256) void outer_step_kernel(const OuterEnt* __restrict__ tab, int nent, int lr_blocks,
+                                                          float* __restrict__ state, float* __restrict__ grad, float* __restrict__ m,
+                                                          float* __restrict__ v, float* __restrict__ Winit, float* __restrict__ Wp,
+                                                          float* __restrict__ lr_eff, const OuterHyper h) {
+  if ((int)blockIdx.x < lr_blocks) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long i = (long)blockIdx.x * 1024 + j * 256 + threadIdx.x;
+      if (i >= h.n_lr) break;
+      float mm = m[i], vv = v[i];
+      float pv = outer_radam(state[i], grad[i], mm, vv, i < h.frozen_lr ? 0.f : h.lr_lr, 0.f, h);
+      pv = fminf(fmaxf(pv, h.lr_lo), h.lr_hi);                 // clamp_init_lr
+      m[i] = mm; v[i] = vv; state[i] = pv; grad[i] = 0.f;
+      if (lr_eff) lr_eff[i] = h.use_log ? expf(pv) : pv;
+    }
+    return;
+  }
+  __shared__ int blk0s[256];
+  for (int i = threadIdx.x; i < nent; i += 256) blk0s[i] = tab[i].blk0;
+  __syncthreads();
+  const int wb = (int)blockIdx.x - lr_blocks;
+  int lo = 0, hi = nent - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (wb >= blk0s[mid]) lo = mid; else hi = mid - 1;
+  }
+  const OuterEnt t = tab[lo];
+  const int wsize = t.O * t.I * t.T;
+  float* const st = state + h.n_lr;
+  float* const gr = grad + h.n_lr;
+  float* const mo = m + h.n_lr;
+  float* const vo = v + h.n_lr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = (wb - t.blk0) * 1024 + j * 256 + threadIdx.x;
+    if (e >= t.n) break;
+    const long f = t.off + e;                                 // flat (OIHW) index = [o][i][t]
+    float mm = mo[f], vv = vo[f];
+    const float pv = outer_radam(st[f], gr[f], mm, vv, f < h.frozen_param ? 0.f : h.init_lr, h.wd, h);
+    mo[f] = mm; vo[f] = vv; st[f] = pv; gr[f] = 0.f;
+    long d = f;                                               // engine layout [o][t][i]; the bias keeps its place
+    if (e < wsize && t.T > 1) {
+      const int tt = e % t.T, io = e / t.T;
+      const int ii = io % t.I, oo = io / t.I;
+      d = t.off + ((long)oo * t.T + tt) * t.I + ii;
+    }
+    Winit[d] = pv;
+    Wp[d] = pv;
+  }
+}
+void launch_outer_step(const OuterEnt* tab, int nent, int lr_blocks, int nblocks, float* state, float* grad, float* m, float* v,
+                       float* Winit, float* Wp, float* lr_eff, const OuterHyper& h, hipStream_t s) {
+  hipLaunchKernelGGL(outer_step_kernel, dim3(nblocks), dim3(256), 0, s, tab, nent, lr_blocks, state, grad, m, v, Winit, Wp, lr_eff, h);
+}
 __global__ void clamp_kernel(float* p, long n, float lo, float hi) {
   GRID_STRIDE(i, n) p[i] = fminf(fmaxf(p[i], lo), hi);
 }

@@ -291,6 +291,29 @@ class Engine:
     def clamp(self, param, lo, hi):
         _ffi.check(self.lib.eosvos_clamp(self.h, _ptr(param), param.numel(), lo, hi))
 
+    def outer_step(self, state, grad, exp_avg, exp_avg_sq, n_lr, learn_model_init, step, lr_lr, init_lr, weight_decay,
+                   grad_scale=1.0, grad_clip=0.0, lr_lo=0.0, lr_hi=float('inf'), use_log=False, frozen_lr=0, frozen_param=0,
+                   betas=(0.9, 0.999), eps=1e-8):
+        """`eosvos_outer_step`: scale + clip + RAdam (both parameter groups) + lr clamp + grad zero in one launch that also
+        leaves the new learned state in this engine (effective lr, init = current weights).  NEURON level only."""
+        self._check_stream()
+        for t in (state, grad, exp_avg, exp_avg_sq):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == state.numel()
+        assert state.numel() == n_lr + (self.n_param if learn_model_init else 0) and n_lr == self.n_lr
+        _ffi.check(self.lib.eosvos_outer_step(self.h, _ptr(state), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n_lr,
+                                              int(bool(learn_model_init)), int(step), lr_lr, init_lr, weight_decay, betas[0], betas[1],
+                                              eps, grad_scale, grad_clip, lr_lo, lr_hi, int(bool(use_log)), int(frozen_lr),
+                                              int(frozen_param)))
+        self.lr_level, self.lr_log, self.n_lr_store = 'NEURON', bool(use_log), self.n_lr
+        if learn_model_init:
+            self.steps_since_reset = 0
+
+    def alias_state(self, src):
+        """`eosvos_alias_state`: this engine reads `src`'s learned init and per-neuron lr from now on (engines that run the
+        tasks of one meta-batch side by side); `src` must stay alive as long as this engine."""
+        _ffi.check(self.lib.eosvos_alias_state(self.h, src.h))
+        self._alias_of = src              # keeps `src` alive
+
     def synchronize(self):
         _ffi.check(self.lib.eosvos_synchronize(self.h))
 

@@ -84,6 +84,15 @@ class MetaTrainer:
         self.exp_avg_sq = torch.zeros(n, device=dev)
         self.step = 0
         self.skipped_tasks = 0
+        # One launch for the whole outer step (`eosvos_outer_step`) where the engine offers it: NEURON level, and the state
+        # vector holding the init part (learn_model_init) or only the lr state.  The extra engines then READ the first
+        # engine's learned init / lr (`eosvos_alias_state`): nothing is uploaded per engine after a step.
+        # EOSVOS_NO_FUSED_OUTER=1: the separate RAdam / clamp / zero / upload calls (A/B, and what the CPU stand-in runs).
+        self.fused_outer = (hasattr(engine, 'outer_step') and lr_hierarchy_level == 'NEURON' and
+                            os.environ.get('EOSVOS_NO_FUSED_OUTER', '0') != '1')
+        if self.fused_outer:
+            for e in self.engines[1:]:
+                e.alias_state(engine)
 
     # ---- state ------------------------------------------------------------------------
     def load_state(self, model_state, lrs):
@@ -266,8 +275,29 @@ class MetaTrainer:
         nl = self.n_lr
         scale = 1.0 / self.meta_batch_size
         clip = float(self.grad_clip) if self.grad_clip is not None else 0.0
-        ranges = []                                          # (lo, hi, lr, weight decay): the reference's per-tensor groups
         fl, fp = (self._backbone_lr, self._backbone_param) if self.freeze_encoder else (0, 0)
+        if self.use_log:                                    # clamp_init_lr, meta_optim.py:116-133
+            lo, hi = -33.0, float('inf') if self.max_lr is None else math.log(self.max_lr)
+        else:
+            lo, hi = 0.0, float('inf') if self.max_lr is None else float(self.max_lr)
+        # the gradient was summed by torch on the CURRENT stream; the engine's kernels run on ITS stream (the same one for an
+        # engine built on the default stream, a different one for engines built for side-by-side work)
+        es = getattr(eng, 'stream', None)
+        cur = torch.cuda.current_stream(self.state.device) if self.state.is_cuda else None
+        if es is not None and cur is not None and es != cur:
+            es.wait_stream(cur)
+        if self.fused_outer:
+            n = nl + (eng.n_param if self.learn_model_init else 0)
+            with _on_stream(eng):
+                eng.outer_step(self.state[:n], self.grad[:n], self.exp_avg[:n], self.exp_avg_sq[:n], nl, self.learn_model_init,
+                               self.step, self.log_init_lr_lr, self.model_init_lr, self.wd, grad_scale=scale, grad_clip=clip,
+                               lr_lo=lo, lr_hi=hi, use_log=self.use_log, frozen_lr=fl, frozen_param=fp)
+                if not self.learn_model_init:
+                    self.grad[n:].zero_()               # the init part of the task gradients is not a Parameter: dropped
+            if es is not None and cur is not None and es != cur:
+                cur.wait_stream(es)
+            return
+        ranges = []                                          # (lo, hi, lr, weight decay): the reference's per-tensor groups
         if fl:
             ranges.append((0, fl, 0.0, 0.0))
         ranges.append((fl, nl, self.log_init_lr_lr, 0.0))
@@ -275,19 +305,11 @@ class MetaTrainer:
             if fp:
                 ranges.append((nl, nl + fp, 0.0, self.wd))
             ranges.append((nl + fp, self.state.numel(), self.model_init_lr, self.wd))
-        # the gradient was summed by torch on the CURRENT stream; the engine's kernels run on ITS stream (the same one for an
-        # engine built on the default stream, a different one for engines built for side-by-side work)
-        es = getattr(eng, 'stream', None)
-        cur = torch.cuda.current_stream(self.state.device) if self.state.is_cuda else None
-        if es is not None and cur is not None and es != cur:
-            es.wait_stream(cur)
-        for lo, hi, lr, wd in ranges:
-            eng.radam_step(self.state[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                           lr, wd, self.step, grad_scale=scale, grad_clip=clip)
-        if self.use_log:                                    # clamp_init_lr, meta_optim.py:116-133
-            eng.clamp(self.state[:nl], -33.0, float('inf') if self.max_lr is None else math.log(self.max_lr))
-        else:
-            eng.clamp(self.state[:nl], 0.0, float('inf') if self.max_lr is None else float(self.max_lr))
+        with _on_stream(eng):
+            for a, b, lr, wd in ranges:
+                eng.radam_step(self.state[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b],
+                               lr, wd, self.step, grad_scale=scale, grad_clip=clip)
+            eng.clamp(self.state[:nl], lo, hi)
         if es is not None and cur is not None and es != cur:
             cur.wait_stream(es)
         self.grad.zero_()

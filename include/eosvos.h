@@ -263,6 +263,26 @@ int eosvos_radam_step(eosvos_engine* e, float* param, const float* grad, float* 
                       float beta2, float eps, int step, float grad_scale, float grad_clip);
 /* param <- clamp(param, lo, hi)  (clamp_init_lr; pass hi = +inf for max_lr None). */
 int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi);
+/* The whole outer step of meta-training in ONE launch (replaces train_meta.py:361-373 + RAdam.step radam.py:28-94 +
+ * clamp_init_lr meta_optim.py:116-133 + the upload of the new learned state into the engine):
+ *   state / grad / exp_avg / exp_avg_sq: flat device vectors [lr state (n_lr) | model_init (OIHW, eosvos_param_count)];
+ *   grad <- clip(grad * grad_scale, +-grad_clip) (grad_clip <= 0: none); RAdam step `step` (>= 1) with the reference's
+ *   two parameter groups: lr `lr_lr`, no weight decay for the lr state; lr `init_lr`, weight decay `weight_decay` for
+ *   model_init (skipped when learn_model_init == 0: the vectors then hold the lr state only); the first `frozen_lr` /
+ *   `frozen_param` elements of each part take lr 0 (freeze_encoder, train_meta.py:120-121); the lr state is clamped to
+ *   [lr_lo, lr_hi]; grad is zeroed; the engine's own copies are written by the same kernel: effective per-neuron lr
+ *   (exp() of the state when use_log) and learned init = current weights in the engine layout (as eosvos_set_lr_state +
+ *   eosvos_set_init would leave them).  NEURON hierarchy level only (the other levels go through eosvos_radam_step /
+ *   eosvos_set_lr_state); the arithmetic per element is eosvos_radam_step's. */
+int eosvos_outer_step(eosvos_engine* e, float* state, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_lr,
+                      int learn_model_init, int step, float lr_lr, float init_lr, float weight_decay, float beta1, float beta2,
+                      float eps, float grad_scale, float grad_clip, float lr_lo, float lr_hi, int use_log,
+                      int64_t frozen_lr, int64_t frozen_param);
+/* Engines that run the tasks of one meta-batch side by side always hold the same learned state: `e` drops its own copy of
+ * the learned init and of the per-neuron lr and reads `src`'s from now on (no upload per engine after an outer step -- one
+ * eosvos_outer_step / eosvos_set_init / eosvos_set_lr on `src` serves all of them).  `src` must outlive `e`, both on one
+ * device; the caller orders `e`'s stream after the stream of `src` that wrote the state. */
+int eosvos_alias_state(eosvos_engine* e, eosvos_engine* src);
 
 /* ---- instrumentation ----------------------------------------------------------------- */
 /* Time `reps` launches of the largest conv_igemm launch of a fine-tune iteration (decoder.last_conv.0

@@ -385,6 +385,57 @@ def test_meta_trainer_single_rank(small_engine, weights):
     eng.load_model_state(*weights)
 
 
+@pytest.mark.parametrize('case', ['default', 'clip_freeze_maxlr', 'log_lr', 'no_model_init', 'two_engines'])
+def test_fused_outer_step_equals_the_separate_calls(weights, case, monkeypatch):
+    """`eosvos_outer_step` (one launch: scale + clip + RAdam of both parameter groups + lr clamp + grad zero + the engine's
+    lr / init copies) against the separate RAdam / clamp / zero / upload calls it replaces (`src/train_meta.py:361-373`,
+    `src/util/radam.py:28-94`, `meta_optim.py:116-133`): the learned state after 7 meta-iterations (across the N_sma >= 5
+    switch of RAdam at step 6) is bit-identical, and so are the weights / lrs the engines fine-tune with afterwards."""
+    from eosvos_amd.engine import Engine
+    from eosvos_amd.meta_run import MetaTrainer
+    kw = {'default': {}, 'clip_freeze_maxlr': dict(grad_clip=1e-3, freeze_encoder=True, max_lr=1.2e-3),
+          'log_lr': dict(use_log_init_lr=True, max_lr=2e-3), 'no_model_init': dict(learn_model_init=False), 'two_engines': {}}[case]
+    sd, lrs = weights
+    if kw.get('use_log_init_lr'):
+        lrs = [l.log() for l in lrs]
+    x, y = synthetic.synthetic_frames(1, *SMALL, seed=5)
+    xg, yg = x.to(DEV), y.to(DEV)
+    xm, ym = torch.flip(xg, dims=[3]).contiguous(), torch.flip(yg, dims=[3]).contiguous()
+    tasks = [(xg, yg, xm, ym), (xm, ym, xg, yg)]
+    out = []
+    for fused in (True, False):
+        monkeypatch.setenv('EOSVOS_NO_FUSED_OUTER', '0' if fused else '1')
+        engines = []
+        for _ in range(2 if case == 'two_engines' else 1):
+            with torch.cuda.stream(torch.cuda.Stream()):
+                engines.append(Engine('resnet50', *SMALL, max_batch=1, device=DEV, side_stream=False))
+        mt = MetaTrainer(engines[0], dist=None, meta_batch_size=2, extra_engines=engines[1:], **kw)
+        assert mt.fused_outer == fused
+        mt.load_state(sd, lrs)
+        losses = [mt.meta_iteration(tasks, inner_steps=1) for _ in range(7)]
+        torch.cuda.synchronize()
+        probe = []
+        for e in engines:                                   # what every engine now fine-tunes from / with
+            with torch.cuda.stream(e.stream):
+                e.reset()
+                p0 = e.get_params()
+                e.finetune_step(xg, yg)
+                probe.append((p0.cpu(), e.get_params().cpu()))
+        out.append((mt.state.clone().cpu(), mt.exp_avg.clone().cpu(), mt.exp_avg_sq.clone().cpu(), mt.grad.clone().cpu(), losses, probe))
+        for e in engines:
+            e.close()
+    a, b = out
+    assert a[4] == b[4]                                     # meta losses of all 7 iterations
+    for k in range(3):
+        assert torch.equal(a[k], b[k]), (case, k, float((a[k] - b[k]).abs().max()))
+    assert float(a[3].abs().max()) == 0.0 and float(b[3].abs().max()) == 0.0       # gradient buffer zeroed
+    for (p0a, p1a), (p0b, p1b) in zip(a[5], b[5]):
+        assert torch.equal(p0a, p0b) and torch.equal(p1a, p1b)
+    if case != 'no_model_init':
+        assert torch.equal(a[5][0][0], a[0][engines[0].n_lr:])                    # engine init == the learned state
+    assert float((a[0][:engines[0].n_lr] - torch.cat([l.reshape(-1) for l in lrs])).abs().max()) > 0
+
+
 @pytest.mark.parametrize('shape', [(1, 97, 161), (2, 130, 182), (1, 480, 910)])
 def test_shape_polymorphism_vs_oracle(weights, shape):
     """Odd / non-multiple-of-16 frame sizes (DAVIS 480p frames are not all 854 wide): forward logits and
