@@ -314,6 +314,14 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
             for w in workers:
                 w.model.copy_state_from(model)
     J_seq, labels_out, item, eval_time, num_frames = [], {}, 0, 0.0, 0
+    phases = {}                                  # seconds per phase on the calling thread (EOSVOS_EVAL_TIMING=1 drains the GPU at the boundaries)
+    drain = os.environ.get('EOSVOS_EVAL_TIMING') == '1' and torch.device(device or model.device).type == 'cuda'
+
+    def tick(name, t_start):
+        if drain:
+            torch.cuda.synchronize()
+        phases[name] = phases.get(name, 0.0) + time.perf_counter() - t_start
+        return time.perf_counter()
     # File readers (`prefetchable`) are used through shallow copies on two worker threads: sequence k + 1 is decoded while
     # sequence k is fine-tuned, and the PNGs / J of sequence k are written while k + 1 runs (PIL releases the GIL).
     # EOSVOS_EVAL_PREFETCH=0 keeps everything on the calling thread.
@@ -346,6 +354,7 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         return 0.0 if ds.test_mode else sequence_J(labels.numpy(), ds.label_maps(sq), n_obj)     # evaluate.py:344-346
 
     for k, seq in enumerate(seqs):
+        tp = time.perf_counter()
         if pool:
             frames, gts, fids = ahead.result()
             frames, gts = frames.to(device or model.device), [g.to(device or model.device) for g in gts]
@@ -353,6 +362,7 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
                 ahead = pool.submit(load, seqs[k + 1])
         else:
             frames, gts, fids = read(dataset, seq, device or model.device)
+        tp = tick('read_s', tp)
         n = frames.shape[0]
         probs = torch.zeros(len(gts), n, *frames.shape[-2:], device=frames.device)
         t0 = time.perf_counter()
@@ -375,15 +385,18 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
         if world > 1:
             dist.all_reduce(probs)
         eval_time += time.perf_counter() - t0
+        tp = tick('finetune_s', tp)
         num_frames += n * len(gts)                                              # per (object, frame), evaluate.py:320
         if model.engine is None:                                                # this rank had no item yet
             model._ensure_engine(frames.shape[2], frames.shape[3], 1)
         labels = merge_objects(model.engine, [probs[o] for o in range(len(gts))]).cpu()
         labels_out[seq] = labels
+        tp = tick('merge_s', tp)
         if pool:
             finishing.append(pool.submit(finish, copy.copy(dataset), seq, labels, len(gts)))
         else:
             finishing.append(finish(dataset, seq, labels, len(gts)))
+        tp = tick('finish_s', tp)
     for seq, j in zip(seqs, finishing):
         J_seq.append(j.result() if pool else j)
         if log is not None and rank == 0:
@@ -403,4 +416,4 @@ def evaluate_dataset(model, meta_optim, meta_optim_state_dict, dataset, cfg, dat
             save_meta_checkpoint(os.path.join(save_dir, f'best_{dataset_key}_meta_iter.model'), meta_optim_state_dict,
                                  meta_iter, meta_epoch, vis_win_names)
     return {'J_seq': J_seq, 'mean_J': mean_J, 'best_mean_J': out_best, 'labels': labels_out,
-            'time_per_frame': eval_time / max(num_frames, 1), 'meta_iter': meta_iter}
+            'time_per_frame': eval_time / max(num_frames, 1), 'meta_iter': meta_iter, 'phases': phases}

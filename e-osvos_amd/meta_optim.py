@@ -137,10 +137,19 @@ class MetaOptimizer:
         missing = [k for k in self._params if k not in sd]
         if missing:
             raise KeyError(f'missing keys: {missing[:4]}...')
+        # The evaluation loop reloads the SAME learned state for every object and every adaptation round
+        # (evaluate.py:196,200): when neither the source tensors nor this optimizer's own storage changed since the last
+        # load (same storages, same in-place version counters) the 161 MB copy and the engine upload it triggers are skipped.
+        stamp = [(sd[k].data_ptr(), sd[k]._version, tuple(sd[k].shape)) for k in self._params]
+        own = (self._lr_flat._version, self.model._flat._version, self.model._lr_flat is self._lr_flat)
+        if getattr(self, '_loaded_stamp', None) == (stamp, own) and not self.model._dirty:
+            return
         for k, p in self._params.items():
             p.data.copy_(sd[k].reshape(p.data.shape))
         self.model._lr_flat = self._lr_flat
         self.model._dirty = True
+        self._loaded_stamp = (stamp, (self._lr_flat._version, self.model._flat._version, True))
+        self._loaded_refs = [sd[k] for k in self._params]       # keeps the storages alive: an address cannot be reused by another tensor
 
     def zero_grad(self):
         if self._grad_flat is not None:

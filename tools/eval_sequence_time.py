@@ -32,7 +32,8 @@ for name, extra in (('e-OSVOS-50', ['num_epochs.eval=50']),
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(json.dumps({'config': name, 'frames': N, 'objects': 2, 'objects_in_flight': in_flight, 'inference_batch': infer_batch,
                           'sequences': NSEQ, 'seconds_per_sequence': round(dt / NSEQ, 3), 'seconds_per_object': round(dt / NSEQ / 2, 3),
-                          'ms_per_object_frame': round(1e3 * res['time_per_frame'], 2), 'mean_J': round(res['mean_J'], 4)}), flush=True)
+                          'ms_per_object_frame': round(1e3 * res['time_per_frame'], 2), 'mean_J': round(res['mean_J'], 4),
+                          'phases_s': {k: round(v, 3) for k, v in res.get('phases', {}).items()}}), flush=True)
         for w in getattr(model, '_object_workers', None) or []:
             if w.model.engine is not None:
                 w.model.engine.close()
