@@ -513,6 +513,7 @@ static int env_int(const char* name, int dflt);
 // (9.97 -> 10.12 ms) although the single-stream per-layer times predict a small gain; batch 1: 5.46 -> 5.33 ms.
 // EOSVOS_TUNE_BN64_TILES / _KSTEPS move the two thresholds (0 tiles: never).
 int conv_bn(const ConvArgs& a) {
+  if (a.nseg > 0) return 128;                     // the K-concatenated kernel exists for 128-wide tiles only
   if (a.N <= 64) return 64;
   static const int thr = env_int("EOSVOS_TUNE_BN64_TILES", 256), kthr = env_int("EOSVOS_TUNE_BN64_KSTEPS", 40);
   static const int kthr_anyb = env_int("EOSVOS_TUNE_BN64_ANYB_KSTEPS", 0);     // experiment: the rule at any batch for K steps <= this
@@ -560,6 +561,53 @@ long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vect
   prefix.back() = (int)total;
   return total;
 }
+
+// K-concatenated data gradient: global tap ids (segment-major, then ky, kx), per-tile lists of the taps that reach the
+// image for at least one pixel of the tile, K-step prefix (every segment has the same Kc = a.Kc reduction channels).
+long conv_build_multi_table(const ConvArgs& a, const ConvSegHost* segs, int nseg, std::vector<int>& prefix,
+                            std::vector<unsigned char>& taplist, std::vector<ConvTap>& taps) {
+  const int chunks = (a.Kc + EOSVOS_BK - 1) / EOSVOS_BK;
+  const int nt = (a.N + 127) / 128, mt = (a.M + 127) / 128;
+  taps.clear();
+  for (int g = 0; g < nseg; ++g) {
+    const ConvSegHost& sg = segs[g];
+    const int T = sg.k * sg.k;
+    for (int ky = 0; ky < sg.k; ++ky)
+      for (int kx = 0; kx < sg.k; ++kx) {
+        ConvTap t;
+        t.dy = sg.pad - ky * sg.dil; t.dx = sg.pad - kx * sg.dil;
+        t.xoff = sg.xoff;
+        t.wbase = (int)(sg.woff + (long)(ky * sg.k + kx) * a.wK);
+        t.wrow = T * a.wK;
+        t.ksoff = sg.ksoff; t.seg = g; t.pad_ = 0;
+        taps.push_back(t);
+      }
+  }
+  prefix.assign((size_t)mt * nt + 1, 0);
+  taplist.assign((size_t)mt * nt * 32, 0);
+  long total = 0;
+  for (int tm = 0; tm < mt; ++tm) {
+    std::vector<unsigned char> keep;
+    for (size_t id = 0; id < taps.size(); ++id) {
+      bool any = false;
+      for (int m = tm * 128; m < a.M && m < tm * 128 + 128 && !any; ++m) {
+        const int hw = a.Ho * a.Wo, rem = m % hw;
+        const int sy = rem / a.Wo + taps[id].dy, sx = rem % a.Wo + taps[id].dx;
+        any = sy >= 0 && sx >= 0 && sy < a.Hi && sx < a.Wi;
+      }
+      if (any) keep.push_back((unsigned char)id);
+    }
+    for (int tn = 0; tn < nt; ++tn) {
+      const size_t tile = (size_t)tm * nt + tn;
+      prefix[tile] = (int)total;
+      for (size_t k = 0; k < keep.size() && k < 32; ++k) taplist[tile * 32 + k] = keep[k];
+      total += (long)keep.size() * chunks;
+    }
+  }
+  prefix.back() = (int)total;
+  return total;
+}
+bool conv_multi_supported() { return conv_mfma_mode() >= 1; }
 
 
 // ---------------------------------------------------------------------------------------
@@ -755,7 +803,7 @@ __device__ __forceinline__ void x6_mma_step(const unsigned char* As, const unsig
 constexpr int xs_max(int a, int b) { return a > b ? a : b; }
 // LDS of a conv workgroup: NP operand planes, or the C tile that the epilogue stages through the same bytes
 template <int BN, int NP> constexpr int conv_xs_smem() { return xs_max(NP * (128 + BN) * X6_ROWB, 128 * (BN + 4) * 4); }
-template <int BN, bool KMAJOR, int NP>
+template <int BN, bool KMAJOR, int NP, bool MULTI = false>
 __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* smem) {
   constexpr int BM = 128, BK = 32;
   constexpr int A_BYTES = NP * BM * X6_ROWB;
@@ -792,14 +840,29 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
   const int up = 1 << p.upshift;
   constexpr int TN = BN / 32;                            // 16-column fragments per wave
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (p.plane_rows ? (long)p.nplanes : 1L) * p.wN * T * p.wK * 4);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, MULTI ? p.w_floats * 4 : (p.plane_rows ? (long)p.nplanes : 1L) * p.wN * T * p.wK * 4);
   float sa = 1.f, sb = 1.f, inv_ab = 1.f;
-  if (NP == 2) {
+  if (NP == 2 && !MULTI) {
     float ia, ib;
     sa = h3_scale(p.amax_x, KMAJOR ? p.amax_ks : nullptr, ia);
     sb = h3_scale(p.amax_w, nullptr, ib);
     inv_ab = ia * ib;
   }
+  // K-concatenated launch: operand scales per segment (f16x3); the accumulators live in units of 1 / inv_ab of the segment
+  // they were last added to and are rescaled (exact: powers of two) where the K loop enters the next one
+  float seg_sa[4] = {1.f, 1.f, 1.f, 1.f}, seg_sb[4] = {1.f, 1.f, 1.f, 1.f}, seg_inv[4] = {1.f, 1.f, 1.f, 1.f};
+  if (MULTI && NP == 2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g >= p.nseg) break;
+      float ia, ib;
+      seg_sa[g] = h3_scale(p.amax_x, p.seg_amax_ks[g], ia);
+      seg_sb[g] = h3_scale(p.seg_amax_w[g], nullptr, ib);
+      seg_inv[g] = ia * ib;
+    }
+  }
+  auto pick4 = [](const float (&v)[4], int g) { return g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3])); };
+  int seg_ld = 0, seg_acc = 0;   // segment of the operands in flight / of the accumulators' unit
 
   unsigned ymax = 0;           // f16x3: absmax of what this workgroup writes (-> p.amax_y)
   bool splitk_pending = p.splitk > 0;
@@ -845,7 +908,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
     }
     const int ks_total = p.tprefix ? p.tprefix[tile + 1] - p.tprefix[tile] : ksteps;
     unsigned long long tappack = 0x876543210ULL;
-    if (p.tprefix) {
+    if (!MULTI && p.tprefix) {
       const int mask = p.tmask[tile];
       tappack = 0;
       int nv = 0;
@@ -888,26 +951,40 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
       }
     }
     int cur_tap = -1;
+    int m_wrow = 0, m_ksoff = 0;     // K-concatenated launch: k-row pitch of the segment's weights, offset of its norm scale
     auto load_tiles = [&](int ks) {
       const int vt = ks / chunks;
       const int c0 = (ks - vt * chunks) * BK;
-      const int tap = p.tprefix ? (int)((tappack >> (4 * vt)) & 15) : vt;
+      const int tap = MULTI ? vt : (p.tprefix ? (int)((tappack >> (4 * vt)) & 15) : vt);
       if (tap != cur_tap) {          // wave-uniform
         cur_tap = tap;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int dy = ky * p.kstep, dx = kx * p.kstep;
+        int dy, dx, xoff = 0;
+        if (MULTI) {
+          const int id = __builtin_amdgcn_readfirstlane((int)p.taplist[(size_t)tile * 32 + vt]);
+          const ConvTap d = p.taps[id];
+          dy = d.dy; dx = d.dx; xoff = d.xoff; m_wrow = d.wrow; m_ksoff = d.ksoff; seg_ld = d.seg;
+          if (NP == 2) { sa = pick4(seg_sa, seg_ld); sb = pick4(seg_sb, seg_ld); }
+#pragma unroll
+          for (int i = 0; i < BPASS; ++i) {
+            const int n = n0 + b_n4 * 4;
+            b_off[i] = n < p.N ? d.wbase + (b_kq * RPT + i) * d.wrow + n : -1;
+          }
+        } else {
+          const int ky = tap / p.KW, kx = tap - ky * p.KW;
+          dy = ky * p.kstep; dx = kx * p.kstep;
+        }
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
           const int sy = a_sy0[i] + dy, sx = a_sx0[i] + dx;
           bool ok = sy >= 0 && sx >= 0 && ((sy | sx) & (up - 1)) == 0;
           const int iy = sy >> p.upshift, ix = sx >> p.upshift;
           ok = ok && iy < p.Hi && ix < p.Wi;
-          a_off[i] = ok ? (a_img[i] + iy * p.Wi + ix) * p.ldx + a_c4 * 4 : -1;
+          a_off[i] = ok ? (a_img[i] + iy * p.Wi + ix) * p.ldx + a_c4 * 4 + xoff : -1;
         }
       }
       const bool cok = (c0 + a_c4 * 4) < p.Kc;
       float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (KMAJOR && p.kscale && cok) ks4 = ldg4(p.kscale + c0 + a_c4 * 4);
+      if (KMAJOR && p.kscale && cok) ks4 = ldg4(p.kscale + (MULTI ? m_ksoff : 0) + c0 + a_c4 * 4);
 #pragma unroll
       for (int i = 0; i < APASS; ++i) {
         const unsigned off = (cok && a_off[i] >= 0) ? (unsigned)(a_off[i] + c0) * 4u : OOB;
@@ -918,7 +995,10 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         unsigned off;
-        if (KMAJOR) {
+        if (MULTI) {
+          const int k = c0 + b_kq * RPT + i;
+          off = (b_off[i] >= 0 && k < p.Kc) ? (unsigned)(b_off[i] + c0 * m_wrow) * 4u : OOB;
+        } else if (KMAJOR) {
           const int k = c0 + b_kq * RPT + i;
           off = (b_off[i] >= 0 && k < p.Kc) ? (unsigned)(b_off[i] + (c0 * T + tap) * p.wK) * 4u : OOB;
         } else {
@@ -976,6 +1056,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
     __syncthreads();            // previous segment's epilogue reads of smem are done
     store_tiles();
     __syncthreads();
+    if (MULTI) seg_acc = seg_ld;
 
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       const bool more = (ks + 1) < ks_end;
@@ -985,8 +1066,20 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();                       // every wave is done reading the stage
       if (more) store_tiles();
+      if (MULTI && NP == 2 && more && seg_ld != seg_acc) {
+        // the next K step belongs to another segment: its operands were staged under that segment's scales
+        const float f = pick4(seg_inv, seg_acc) / pick4(seg_inv, seg_ld);      // power of two: exact
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] *= f;
+        seg_acc = seg_ld;
+      }
       __syncthreads();
     }
+    if (MULTI && NP == 2) inv_ab = pick4(seg_inv, seg_acc);
 
     // ---- epilogue: accumulators -> LDS tile -> full-row float4 stores ------------------------
     float* Cs = reinterpret_cast<float*>(smem);
@@ -1082,6 +1175,15 @@ template <int BN, bool KMAJOR>
 __global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[conv_xs_smem<BN, 2>()];
   conv_xs_body<BN, KMAJOR, 2>(p, smem);
+}
+// K-concatenated data gradient (ConvArgs::nseg > 0): several convolutions' gradients into one destination
+__global__ __launch_bounds__(256, 2) void conv_h3_multi_kernel(const ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[conv_xs_smem<128, 2>()];
+  conv_xs_body<128, true, 2, true>(p, smem);
+}
+__global__ __launch_bounds__(256, 2) void conv_x6_multi_kernel(const ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[conv_xs_smem<128, 3>()];
+  conv_xs_body<128, true, 3, true>(p, smem);
 }
 
 // Weight gradient on the bf16 matrix cores: same split, both operands K-major (a pixel's channels are contiguous).
@@ -1398,7 +1500,8 @@ const char* const kProfNames[] = {
     "wgrad_x6_group_kernel<128, 128>", "wgrad_x6_group_kernel<128, 64>", "wgrad_x6_group_kernel<64, 128>", "wgrad_x6_group_kernel<64, 64>",
     "conv_h3_kernel<128, false>", "conv_h3_kernel<128, true>", "conv_h3_kernel<64, false>", "conv_h3_kernel<64, true>",
     "wgrad_h3_kernel<128, 128>", "wgrad_h3_kernel<128, 64>", "wgrad_h3_kernel<64, 128>", "wgrad_h3_kernel<64, 64>",
-    "wgrad_h3_group_kernel<128, 128>", "wgrad_h3_group_kernel<128, 64>", "wgrad_h3_group_kernel<64, 128>", "wgrad_h3_group_kernel<64, 64>"};
+    "wgrad_h3_group_kernel<128, 128>", "wgrad_h3_group_kernel<128, 64>", "wgrad_h3_group_kernel<64, 128>", "wgrad_h3_group_kernel<64, 64>",
+    "conv_h3_multi_kernel", "conv_x6_multi_kernel"};
 constexpr int kProfKernels = sizeof(kProfNames) / sizeof(kProfNames[0]);
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -1574,10 +1677,13 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
   const dim3 grid(nwg), block(256);
   const int mode = conv_mfma_mode();
-  const int pk = (mode == 2 ? 21 : mode == 1 ? 0 : 8) + (bn == 128 ? 0 : 2) + (a.kmajor ? 1 : 0);
+  const int pk = a.nseg > 0 ? (mode == 2 ? 33 : 34) : (mode == 2 ? 21 : mode == 1 ? 0 : 8) + (bn == 128 ? 0 : 2) + (a.kmajor ? 1 : 0);
   {
   ProfScope ps(pk, 2.0 * a.M * a.N * a.KH * a.KW * a.Kc * conv_exec_frac(a), s);
-  if (mode == 2) {
+  if (a.nseg > 0) {
+    if (mode == 2) hipLaunchKernelGGL(conv_h3_multi_kernel, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(conv_x6_multi_kernel, grid, block, 0, s, a);
+  } else if (mode == 2) {
     if (a.kmajor) {
       if (bn == 128) hipLaunchKernelGGL((conv_h3_kernel<128, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((conv_h3_kernel<64, true>), grid, block, 0, s, a);

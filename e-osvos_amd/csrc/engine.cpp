@@ -248,6 +248,9 @@ struct eosvos_engine {
   bool have_loss_grad = false;
   int force_algo = 0;                 // EOSVOS_ALGO_*: 0 = plan by work size; the op-level parity tests force one path
   int wg_budget = 0;                  // eosvos_set_wg_budget: workgroups a launch plans for (0 = the whole chip)
+  // K-concatenated data gradient of the four ASPP branches (ConvArgs::nseg): device tables per batch size
+  struct MultiTab { int* prefix; unsigned char* taplist; ConvTap* taps; long total; };
+  std::map<int, MultiTab> aspp_multi;
   OuterEnt* outer_tab = nullptr;      // eosvos_outer_step: device table of the trainable tensors
   int outer_blocks = 0;
   int plan_mode = -1;                 // matrix mode the cached launch plans (wg_plans, upd_tab) were built for, see plans_match_mode()
@@ -1092,6 +1095,77 @@ int flush_updates(eosvos_engine* e, int B, bool update, bool accumulate, int par
   return 0;
 }
 
+// The four ASPP branches' data gradients into d(layer4 output) as ONE K-concatenated launch (ConvArgs::nseg): K = 256 (1x1)
+// + 3 x 9 taps x 256 (dilated 3x3, taps that fall into the padding for a whole tile skipped), no accumulate
+// read-modify-write between the branches, one fix-up pass.  Returns false when this engine / mode has to run them one by
+// one (GroupNorm mode: the gradients w.r.t. the raw conv outputs live in separate buffers; fp32-MFMA mode: no such kernel).
+bool aspp_dgrad_merged(eosvos_engine* e, int B, float* g_l4, const float* l4) {
+  static const bool off = getenv("EOSVOS_TUNE_NO_ASPP_MERGE") != nullptr;
+  const Topo& t = e->t;
+  if (off || e->gn() || !conv_multi_supported() || e->force_algo != 0) return false;
+  for (int i = 0; i < 4; ++i) {
+    const ConvL& c = t.convs[t.aspp[i]];
+    if (c.cout != 256 || c.cin != t.convs[t.aspp[0]].cin || c.stride != 1 || t.aspp[i] != t.aspp[0] + i) return false;
+    if (wino_on(e, t.aspp[i], B, e->h16, e->w16)) return false;
+  }
+  const ConvL& c0 = t.convs[t.aspp[0]];
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wg_budget = e->wg_budget;
+  a.x = e->g_cat; a.w = e->W_(t.aspp[0]); a.y = g_l4; a.ws = e->ws_conv;
+  a.B = B; a.Hi = e->h16; a.Wi = e->w16; a.ldx = 1280; a.Kc = 256;
+  a.Ho = e->h16; a.Wo = e->w16; a.N = c0.cin; a.ldy = c0.cin; a.KH = a.KW = 1;
+  a.mul = 1; a.off0 = 0; a.kstep = 0; a.upshift = 0;
+  a.M = B * e->h16 * e->w16; a.wN = 256; a.wK = c0.cin; a.kmajor = 1;
+  a.kscale = e->A_(t.aspp[0]);
+  a.mask = l4; a.ldmask = c0.cin; a.mask_c0 = 0; a.accum = 1;
+  a.mask8 = e->m8(l4); a.ldm8 = c0.cin / 4;
+  a.nseg = 4;
+  a.w_floats = 0;
+  ConvSegHost segs[4];
+  for (int i = 0; i < 4; ++i) {
+    const ConvL& c = t.convs[t.aspp[i]];
+    segs[i] = ConvSegHost{c.k, c.dil, c.pad, 256 * i, (long)(c.poff - c0.poff), (int)(c.noff - c0.noff)};
+    a.w_floats = (long)(c.poff - c0.poff) + c.wsize();
+  }
+  auto it = e->aspp_multi.find(B);
+  if (it == e->aspp_multi.end()) {
+    std::vector<int> prefix;
+    std::vector<unsigned char> taplist;
+    std::vector<ConvTap> taps;
+    const long total = conv_build_multi_table(a, segs, 4, prefix, taplist, taps);
+    eosvos_engine::MultiTab mt{nullptr, nullptr, nullptr, total};
+    mt.prefix = (int*)e->falloc((int64_t)prefix.size());
+    mt.taplist = (unsigned char*)e->falloc((int64_t)(taplist.size() + 3) / 4);
+    mt.taps = (ConvTap*)e->falloc((int64_t)(taps.size() * sizeof(ConvTap) + 3) / 4);
+    if (!mt.prefix || !mt.taplist || !mt.taps) return false;
+    if (hipMemcpy(mt.prefix, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemcpy(mt.taplist, taplist.data(), taplist.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemcpy(mt.taps, taps.data(), taps.size() * sizeof(ConvTap), hipMemcpyHostToDevice) != hipSuccess) return false;
+    it = e->aspp_multi.emplace(B, mt).first;
+  }
+  a.tprefix = it->second.prefix; a.taplist = it->second.taplist; a.taps = it->second.taps; a.total_units = it->second.total;
+  if (h3_mode()) {
+    if (amax_init(e)) return false;
+    amax_weights(e, e->s);
+    a.amax_x = tlookup(e, 1, e->g_cat);
+    if (!a.amax_x) a.amax_x = amax_get(e, AM_G, t.aspp[0], e->g_cat, (long)B * e->h16 * e->w16, 1280, 1280, e->s);
+    for (int i = 0; i < 4; ++i) {
+      a.seg_amax_w[i] = amax_slot(e, AM_W, t.aspp[i]);
+      a.seg_amax_ks[i] = amax_ks(e, t.aspp[i], e->s);
+    }
+    a.amax_y = twrite_fused(e, 1, g_l4, true);         // every element of g_l4 is rewritten (accumulating the pooling branch's broadcast)
+  }
+  double fl = 0;
+  for (int i = 0; i < 4; ++i) fl += 2.0 * a.M * a.N * t.convs[t.aspp[i]].T() * 256.0;
+  if (trace_on())
+    fprintf(stderr, "EOSVOS_TRACE dgrad conv=%d M=%d N=%d K=%ld splits=%d flops=%.0f\n", t.aspp[0], a.M, a.N, (long)(a.total_units * 32 / (((a.M + 127) / 128) * ((a.N + 127) / 128))), conv_plan(a),
+            2.0 * 128 * 128 * 32 * (double)a.total_units);
+  (void)fl;
+  launch_conv(a, e->s);
+  return true;
+}
+
 // The grouped weight-gradient tables (WgradArgs with or without absmax slots, split counts) and the update tables (slab
 // counts per conv) depend on the process-wide matrix mode: a mode switch on a live engine drops them.
 void plans_match_mode(eosvos_engine* e) {
@@ -1790,12 +1864,14 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     twrite_plain(e, 1, g_l4);
     apply_update(e, t.pool, 1, update, accumulate);
   }
-  for (int i = 0; i < 4; ++i) {
-    int sp = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B, e->g_cat);
-    const bool lastone = i == 3;
-    conv_dgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, e->h16, e->w16, g_l4, 2048, B, true,
-               lastone ? l4 : nullptr, 2048, 0, nullptr, 0, e->g_cat);
-    apply_update(e, t.aspp[i], sp, update, accumulate);
+  {
+    int sp[4];
+    for (int i = 0; i < 4; ++i) sp[i] = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B, e->g_cat);
+    if (!aspp_dgrad_merged(e, B, g_l4, l4))
+      for (int i = 0; i < 4; ++i)
+        conv_dgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, e->h16, e->w16, g_l4, 2048, B, true, i == 3 ? l4 : nullptr, 2048, 0, nullptr, 0,
+                   e->g_cat);
+    for (int i = 0; i < 4; ++i) apply_update(e, t.aspp[i], sp[i], update, accumulate);
   }
   // bottlenecks, last to first.  g_out of each block = dL/d(pre-ReLU block output).
   const int first_l4_block = (int)t.blocks.size() - 3;

@@ -118,12 +118,33 @@ struct ConvArgs {
   int dp_q, per, nwg;   // set by conv_plan: whole tiles per workgroup, streamed units per workgroup, workgroups
   int splitk;           // set by conv_plan: > 0 = uniform split-K, workgroup b takes K chunk b / tiles of tile b % tiles
   int wg_budget;        // workgroups the launch may plan for (0: two per CU); engines that run beside others split less
+  // K-concatenated launch (nseg > 0; data gradients only): the reduction runs over `nseg` convolutions that ADD into the same
+  // output -- the four ASPP branches' data gradients into d(layer4 output) as one launch: no accumulate read-modify-write
+  // between them, one fix-up pass instead of one each.  The convs share the gather source tensor (x, ldx; segment s reads
+  // channels [xoff_s, xoff_s + Kc)) and the destination; each has its own filter (taps / dilation / padding), weights
+  // (offset from w), norm scale (offset from kscale) and -- f16x3 -- its own operand scales (the accumulators are rescaled by
+  // an exact power of two where the K loop crosses into the next segment).  `taps` (device) describes every (segment, ky, kx)
+  // as a global tap id, `taplist` (device, 32 bytes per tile) lists the ids a tile keeps, tprefix counts its K steps.
+  int nseg;
+  const struct ConvTap* taps;
+  const unsigned char* taplist;
+  long w_floats;                // extent of the weights of all segments from `w`
+  const unsigned* seg_amax_w[4];
+  const unsigned* seg_amax_ks[4];
   // f16x3 mode: device words holding the bit pattern of max|x| over the gather source, over the weights as passed in `w`
   // (all planes of a batched GEMM) and -- data gradient -- over `kscale`; see launch_absmax
   const unsigned* amax_x;
   const unsigned* amax_w;
   const unsigned* amax_ks;
   unsigned* amax_y;     // optional: atomicMax of the bit patterns of |y| as written (the absmax slot of the destination tensor)
+};
+struct ConvTap {
+  int dy, dx;      // source pixel = destination pixel + (dy, dx)   (data gradient: pad - k * dilation)
+  int xoff;        // channel offset of the segment's slice in the gather source
+  int wbase;       // offset (floats, from ConvArgs::w) of W_seg[k = 0][this tap][n = 0]
+  int wrow;        // floats between consecutive k rows of W_seg (= taps of the segment x wK)
+  int ksoff;       // offset of the segment's norm scale from ConvArgs::kscale
+  int seg, pad_;
 };
 // Parity-major row order of a stride-2 data gradient: rows [0, M) walk the (even,even) output pixels of all
 // images, then (even,odd), (odd,even), (odd,odd).  A pixel of parity (py,px) only receives the filter taps with
@@ -170,6 +191,13 @@ int64_t conv_ws_floats();
 #include <vector>
 namespace eosvos {
 long conv_build_tap_table(const ConvArgs& a, std::vector<int>& prefix, std::vector<int>& mask);            // size of ConvArgs::ws the launch may use
+// K-concatenated data gradient: per segment (kernel size k, dilation, padding, channel offset, weight offset, norm-scale
+// offset); fills the global tap descriptors, the per-tile tap lists (32 bytes per tile) and the K-step prefix; returns the
+// total number of K steps
+struct ConvSegHost { int k, dil, pad, xoff; long woff; int ksoff; };
+long conv_build_multi_table(const ConvArgs& a, const ConvSegHost* segs, int nseg, std::vector<int>& prefix,
+                            std::vector<unsigned char>& taplist, std::vector<ConvTap>& taps);
+bool conv_multi_supported();     // the current matrix mode has the K-concatenated kernel (the split modes)
 
 // Weight gradient: ws[z][cout][tap][cin] = sum over the z-th pixel chunk of
 //   G[p][cout] * X[src(p,tap)][cin]
