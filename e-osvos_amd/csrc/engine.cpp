@@ -1696,7 +1696,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   } else {
     launch_stem_fwd(e->xpad, e->W_(0), e->A_(0), e->B_(0), e->c1, B, e->H, e->W, e->h2, e->w2, s);
   }
-  launch_maxpool_fwd(e->c1, e->p1, e->p1idx, B, e->h2, e->w2, 64, e->h4, e->w4, s);
+  launch_maxpool_fwd(e->c1, e->p1, e->p1idx, B, e->h2, e->w2, 64, e->h4, e->w4, s, twrite_fused(e, 0, e->p1, true));
   // independent forward branches go to the side stream (frozen-BN mode; the GroupNorm kernels share scratch)
 #ifdef EOSVOS_NO_FWD_SIDE          // A/B switch
   const bool fside = false;
@@ -1840,8 +1840,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     apply_update(e, t.dec1, sp, update, accumulate);
   }
   // decoder upsample backward (+ ReLU mask of the projection output)
-  launch_resize_bwd(e->g_dcat, 304, e->g_proj, 256, e->proj, 256, B, 256, e->up_h, e->up_w, s);
-  twrite_plain(e, 1, e->g_proj);
+  launch_resize_bwd(e->g_dcat, 304, e->g_proj, 256, e->proj, 256, B, 256, e->up_h, e->up_w, s, twrite_fused(e, 1, e->g_proj, true));
   }
   // ASPP projection
   {

@@ -269,7 +269,7 @@ void launch_stem_wgrad(const float* xpad, const float* g, float* ws /*[chunks][6
 int stem_wgrad_chunks(int B, int Ho, int Wo);
 
 void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int Ho,
-                        int Wo, hipStream_t s);
+                        int Wo, hipStream_t s, unsigned* amax = nullptr);      // amax: absmax slot of y (f16x3 mode)
 // g_x = relu_mask(x) * scatter(g_y)   (x = the ReLU output that was pooled: bit 7 of idx = "the window's maximum is > 0",
 // i.e. the ReLU mask of the one input pixel the gradient goes to -- the backward pass does not read x)
 void launch_maxpool_bwd(const float* gy, const uint8_t* idx, float* gx, int B, int H,
@@ -288,7 +288,7 @@ void launch_resize_fwd(const float* x, int ldx, float* y, int ldy, int B, int C,
                        ResizeTab tw, hipStream_t s);
 // gx = (mask? mask>0 : 1) * resize_backward(gy)
 void launch_resize_bwd(const float* gy, int ldgy, float* gx, int ldgx, const float* mask, int ldmask,
-                       int B, int C, ResizeTab th, ResizeTab tw, hipStream_t s);
+                       int B, int C, ResizeTab th, ResizeTab tw, hipStream_t s, unsigned* amax = nullptr);   // amax: absmax slot of gx
 
 // ASPP image-pooling branch
 void launch_colsum(const float* x, int ldx, float* out /*[B][C]*/, int B, int P, int C, float alpha,

@@ -317,10 +317,11 @@ void launch_stem_wgrad(const float* xpad, const float* g, float* ws, int B, int 
 }
 
 // ---- max-pool 3x3 s2 p1 ------------------------------------------------------------------
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                   uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long n = (long)B * Ho * Wo * C4;
+  unsigned am = 0;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long pix = e / C4;
@@ -342,18 +343,21 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
         first = false;
       }
     }
-    *reinterpret_cast<float4*>(y + pix * C + c4 * 4) = make_float4(m[0], m[1], m[2], m[3]);
+    const float4 out = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(y + pix * C + c4 * 4) = out;
+    am = amax_f4(am, out);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (m[j] > 0.f) mi[j] |= 0x80;            // the ReLU mask of the pixel the gradient will go to
     *reinterpret_cast<uchar4*>(idx + pix * C + c4 * 4) = make_uchar4(mi[0], mi[1], mi[2], mi[3]);
   }
+  if (amax) amax_block_commit(am, amax);
 }
 void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int Ho, int Wo,
-                        hipStream_t s) {
+                        hipStream_t s, unsigned* amax) {
   const long n = (long)B * Ho * Wo * (C >> 2);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, y, idx, B, H, W, C, Ho,
-                     Wo);
+                     Wo, amax);
 }
 __global__ void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
                                    float* __restrict__ gx, int B, int H, int W,
@@ -433,11 +437,12 @@ void launch_resize_fwd(const float* x, int ldx, float* y, int ldy, int B, int C,
   }
 }
 template <int V>
-__global__ void resize_bwd_kernel(const float* __restrict__ gy, int ldgy, float* __restrict__ gx, int ldgx,
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ gy, int ldgy, float* __restrict__ gx, int ldgx,
                                   const float* __restrict__ mask, int ldmask, int B, int C, ResizeTab th,
-                                  ResizeTab tw) {
+                                  ResizeTab tw, unsigned* __restrict__ amax) {
   const int CV = C / V;
   const long n = (long)B * th.in * tw.in * CV;
+  unsigned am = 0;
   GRID_STRIDE(e, n) {
     const int cv = (int)(e % CV);
     const long pix = e / CV;
@@ -463,23 +468,23 @@ __global__ void resize_bwd_kernel(const float* __restrict__ gy, int ldgy, float*
     if (mask) {
       const float* mk = mask + pix * ldmask + cv * V;
 #pragma unroll
-      for (int j = 0; j < V; ++j) d[j] = mk[j] > 0.f ? acc[j] : 0.f;
-    } else {
-#pragma unroll
-      for (int j = 0; j < V; ++j) d[j] = acc[j];
+      for (int j = 0; j < V; ++j) acc[j] = mk[j] > 0.f ? acc[j] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { d[j] = acc[j]; const unsigned q = amax_f1(acc[j]); am = am > q ? am : q; }
   }
+  if (amax) amax_block_commit(am, amax);
 }
 void launch_resize_bwd(const float* gy, int ldgy, float* gx, int ldgx, const float* mask, int ldmask, int B,
-                       int C, ResizeTab th, ResizeTab tw, hipStream_t s) {
+                       int C, ResizeTab th, ResizeTab tw, hipStream_t s, unsigned* amax) {
   if ((C & 3) == 0) {
     const long n = (long)B * th.in * tw.in * (C / 4);
     hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, gy, ldgy, gx,
-                       ldgx, mask, ldmask, B, C, th, tw);
+                       ldgx, mask, ldmask, B, C, th, tw, amax);
   } else {
     const long n = (long)B * th.in * tw.in * C;
     hipLaunchKernelGGL((resize_bwd_kernel<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, gy, ldgy, gx,
-                       ldgx, mask, ldmask, B, C, th, tw);
+                       ldgx, mask, ldmask, B, C, th, tw, amax);
   }
 }
 

@@ -33,6 +33,18 @@ def get_matrix_mode():
     return {0: 'f32', 1: 'bf16x6', 2: 'f16x3'}[_ffi.load().eosvos_get_matrix_mode()]
 
 
+# f16x3 range guard (see Engine.verify_matrix_mode): absolute / relative logit difference against the exact-split mode above
+# which the process falls back to bf16x6.  A tenth of the north_star logit tolerance; measured differences between the two
+# modes: 1e-5 on the benign synthetic state, 1e-5 on the heavy-tailed one of fixture G19 (profiles/r04_g19_margins.txt).
+GUARD_ABS_TOL, GUARD_REL_TOL = 1e-4, 1e-4
+GUARD_LOG = []                       # (reason, max difference) of every fallback this process took
+
+
+def _guard_enabled():
+    import os
+    return os.environ.get('EOSVOS_MODE_GUARD', '1') != '0'
+
+
 _POOL_WARMED = []
 
 
@@ -92,12 +104,15 @@ class Engine:
             pass
 
     # ---- state ----------------------------------------------------------------------
-    def set_init(self, flat):
+    def set_init(self, flat, verify=True):
+        """`verify=False`: a state that evolves in small steps from one the range guard has seen (the outer loop's upload)."""
         flat = _dev_f32(flat, self.device)
         assert flat.numel() == self.n_param
         _ffi.check(self.lib.eosvos_set_init(self.h, _ptr(flat)))
         self.synchronize()
         self.steps_since_reset = 0
+        if verify:
+            self._verify_pending = True      # new weights: the f16x3 range guard looks at the next forward
 
     def set_lr(self, flat):
         flat = _dev_f32(flat, self.device)
@@ -131,6 +146,7 @@ class Engine:
         assert all(t.numel() == self.n_norm for t in ts)
         _ffi.check(self.lib.eosvos_set_norm(self.h, *[_ptr(t) for t in ts], ctypes.c_float(eps)))
         self.synchronize()
+        self._verify_pending = True          # new norm statistics: same
 
     def load_model_state(self, state_dict, lrs=None):
         """Convenience: reference-style model state dict (+ list of NEURON lr tensors)."""
@@ -183,8 +199,50 @@ class Engine:
         assert c == 3 and h == self.height and w == self.width and 1 <= b <= self.max_batch, images.shape
         return b
 
+    def verify_matrix_mode(self, images):
+        """Range guard of the default matrix mode.  f16x3 runs every fp32 contraction on the fp16 matrix cores under ONE
+        power-of-two scale per operand tensor: elements more than ~2^-18 below their tensor's largest magnitude keep fewer
+        bits (absolute error floor 2^-40 of that maximum).  Reference-generated fixtures cover benign and heavy-tailed
+        (BatchNorm statistics over 4-6 decades, G19) states; for anything outside, this check compares the forward pass of
+        the ACTUAL weights / norm statistics / input in f16x3 against the exact-split mode (bf16x6: no range assumption) and,
+        if the logits differ by more than GUARD_ABS_TOL + GUARD_REL_TOL * max|logit| (or are not finite in f16x3 only),
+        switches the PROCESS to bf16x6 (`eosvos_set_matrix_mode`) with a warning.  Runs automatically at the first forward /
+        fine-tune step after new weights or norm statistics were set (EOSVOS_MODE_GUARD=0 disables); costs two extra forward
+        passes per loaded state.  Returns the mode in effect afterwards."""
+        self._verify_pending = False
+        if get_matrix_mode() != 'f16x3':
+            return get_matrix_mode()
+        b = self._check_images(images)
+        a = torch.empty(b, 1, self.height, self.width, device=self.device)
+        ref = torch.empty_like(a)
+        _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(a)))
+        set_matrix_mode('bf16x6')
+        try:
+            _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(ref)))
+            fin_a, fin_r = bool(torch.isfinite(a).all()), bool(torch.isfinite(ref).all())
+            scale = float(ref[torch.isfinite(ref)].abs().max()) if bool(torch.isfinite(ref).any()) else 0.0
+            diff = float((a - ref).abs().max()) if (fin_a and fin_r) else float('inf')
+            bad = (fin_r and not fin_a) or (fin_a and fin_r and diff > GUARD_ABS_TOL + GUARD_REL_TOL * scale)
+        except Exception:
+            set_matrix_mode('f16x3')
+            raise
+        if bad:
+            import warnings
+            GUARD_LOG.append(('f16x3 logits differ from the exact-split mode', diff))
+            warnings.warn(f'e-osvos_amd: f16x3 logits differ from the exact-split mode by {diff:.3g} (scale {scale:.3g}) for this '
+                          'state / input: the dynamic range inside an operand tensor exceeds what one power-of-two scale per '
+                          'tensor covers.  The process continues in the bf16x6 matrix mode.', RuntimeWarning)
+            return 'bf16x6'
+        set_matrix_mode('f16x3')
+        return 'f16x3'
+
+    def _guard(self, images):
+        if getattr(self, '_verify_pending', False) and _guard_enabled():
+            self.verify_matrix_mode(images)
+
     def forward(self, images, want_logits=True):
         b = self._check_images(images)
+        self._guard(images)
         out = torch.empty(b, 1, self.height, self.width, device=self.device) if want_logits else None
         _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(out) if want_logits else None))
         return out
@@ -227,6 +285,7 @@ class Engine:
     def finetune_step(self, images, masks, accumulate=False, sync_loss=True):
         b = self._check_images(images)
         assert masks.is_cuda and masks.is_contiguous() and masks.shape[0] == b
+        self._guard(images)
         self.steps_since_reset += 1
         if sync_loss:
             l = ctypes.c_float()
@@ -246,6 +305,7 @@ class Engine:
 
     def infer(self, images):
         b = self._check_images(images)
+        self._guard(images)
         out = torch.empty(b, 1, self.height, self.width, device=self.device)
         _ffi.check(self.lib.eosvos_infer(self.h, _ptr(images), b, _ptr(out)))
         return out

@@ -137,7 +137,10 @@ class MetaTrainer:
                 if k and getattr(e, 'stream', None) is not None:
                     e.stream.wait_stream(self.eng.stream)       # the outer step wrote the state on the first engine's stream
                 e.set_lr_state(self.level, self.use_log, self.state[:self.n_lr])
-                e.set_init(self.state[self.n_lr:])
+                if getattr(e, 'verify_matrix_mode', None) is not None:
+                    e.set_init(self.state[self.n_lr:], verify=False)      # one outer step away from a state the guard has seen
+                else:
+                    e.set_init(self.state[self.n_lr:])
 
     # ---- one task ---------------------------------------------------------------------
     def run_task(self, x_train, y_train, x_meta, y_meta, inner_steps=5, bptt_epochs=None, multi_step_bptt_loss=None):

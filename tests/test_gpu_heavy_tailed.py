@@ -105,3 +105,44 @@ def test_g19_heavy_tailed_norm_statistics_vs_reference(mode):
     assert m['mask_bits'] <= m['near_zero'], m                     # label bits exact outside the near-zero count
     assert m['meta_train_rel'] <= 1e-4 and m['meta_loss_rel'] <= 2e-4, m
     assert m['meta_lr_grad'] <= 2e-3 and m['meta_init_grad_dec1'] <= 2e-3 and m['meta_init_l2'] <= 2e-3, m
+
+
+def test_range_guard_falls_back_to_the_exact_split_mode():
+    """A state OUTSIDE the envelope of one power-of-two scale per tensor: one channel of an activation tensor is 2^40 times
+    the others (its BatchNorm scale x 2^40, the next conv's weights for it x 2^-40: the network function is unchanged in exact
+    arithmetic, fp32 and bf16x6 compute it to rounding), so in f16x3 the bulk of that tensor sits below the fp16 pieces'
+    range.  The guard (`Engine.verify_matrix_mode`, run at the first forward after a state load) detects the difference
+    against the exact-split mode, warns and switches the process to bf16x6; the result then matches the CPU oracle.  The
+    benign and the heavy-tailed (G19) states pass the same check and stay in f16x3."""
+    import warnings
+    from oracle import deeplab
+    H, W = SMALL
+    prev = engine_mod.get_matrix_mode()
+    if prev != 'f16x3':
+        pytest.skip('the guard only acts in the f16x3 mode')
+    lrs = synthetic.synthetic_lrs()
+    x, y = synthetic.synthetic_frames(1, H, W, seed=3)
+    try:
+        for state, expect in ((synthetic.synthetic_state(), 'f16x3'), (synthetic.heavy_tailed_state(), 'f16x3'), ('outlier', 'bf16x6')):
+            if state == 'outlier':
+                state = {k: v.clone() for k, v in synthetic.synthetic_state().items()}
+                f = 2.0 ** 40
+                state['backbone.layer2.1.bn1.weight'][5] *= f               # channel 5 of layer2.1's t1: x 2^40 ...
+                state['backbone.layer2.1.bn1.bias'][5] *= f
+                state['backbone.layer2.1.conv2.weight'][:, 5] /= f            # ... and read back with weights x 2^-40
+            engine_mod.set_matrix_mode('f16x3')
+            engine_mod.GUARD_LOG.clear()
+            e = Engine('resnet50', H, W, max_batch=1, device=DEV)
+            e.load_model_state(state, lrs)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter('always')
+                out = e.forward(x.to(DEV)).cpu()
+            assert engine_mod.get_matrix_mode() == expect, (expect, engine_mod.GUARD_LOG)
+            assert bool(w) == (expect == 'bf16x6') and bool(engine_mod.GUARD_LOG) == (expect == 'bf16x6')
+            ref = deeplab.forward(state, x)
+            assert float((out - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max())), float((out - ref).abs().max())
+            loss = e.finetune_step(x.to(DEV), y.to(DEV))                  # the step runs in the mode the guard left
+            assert np.isfinite(loss)
+            e.close()
+    finally:
+        engine_mod.set_matrix_mode(prev)
