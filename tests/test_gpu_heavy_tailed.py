@@ -127,6 +127,7 @@ def test_range_guard_falls_back_to_the_exact_split_mode():
             if state == 'outlier':
                 state = {k: v.clone() for k, v in synthetic.synthetic_state().items()}
                 f = 2.0 ** 40
+                state['backbone.layer2.1.bn1.bias'][5] = 1.0                  # (a channel that is alive after the ReLU)
                 state['backbone.layer2.1.bn1.weight'][5] *= f               # channel 5 of layer2.1's t1: x 2^40 ...
                 state['backbone.layer2.1.bn1.bias'][5] *= f
                 state['backbone.layer2.1.conv2.weight'][:, 5] /= f            # ... and read back with weights x 2^-40
