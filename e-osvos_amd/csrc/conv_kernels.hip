@@ -48,6 +48,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// streaming (non-temporal) forms for epilogue operands that are touched once per launch (experiment: -DEOSVOS_NT_EPILOGUE)
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4_stream(const float* p) {
+#ifdef EOSVOS_NT_EPILOGUE
+  const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return ldg4(p);
+#endif
+}
+__device__ __forceinline__ void stg4_stream(float* p, const float4& v) {
+#ifdef EOSVOS_NT_EPILOGUE
+  nt_f32x4 q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, reinterpret_cast<nt_f32x4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 // 16-byte buffer load; offsets past the descriptor's size return 0 (hardware range check)
 __device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
@@ -1124,7 +1142,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
             }
             if (p.res) {
 #pragma unroll
-              for (int j = 0; j < EB; ++j) rs[j] = ldg4(p.res + md[j] * p.ldres + n);
+              for (int j = 0; j < EB; ++j) rs[j] = ldg4_stream(p.res + md[j] * p.ldres + n);
             }
             if (p.accum) {
 #pragma unroll
@@ -1147,7 +1165,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
               if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
               if (use_mask8 || use_mask) relu_mask8(v, mk8[j]);
               if (ok[j]) {
-                *reinterpret_cast<float4*>(p.y + md[j] * p.ldy + n) = v;
+                stg4_stream(p.y + md[j] * p.ldy + n, v);
                 if (write_m8) p.mask8_out[md[j] * p.ldm8_out + (n >> 2)] = relu_bits(v);
                 if (NP == 2) ymax = amax_f4(ymax, v);
               }
