@@ -21,6 +21,7 @@ _SIGNATURES = {
     'eosvos_get_matrix_mode': (ctypes.c_int, []),
     'eosvos_set_wg_budget': (ctypes.c_int, [_E, ctypes.c_int]),
     'eosvos_set_side_stream': (ctypes.c_int, [_E, ctypes.c_int]),
+    'eosvos_set_launch_budget': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'eosvos_num_convs': (ctypes.c_int, [ctypes.c_int]),
     'eosvos_conv_info': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
     'eosvos_param_count': (ctypes.c_int64, [ctypes.c_int]),

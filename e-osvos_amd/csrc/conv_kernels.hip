@@ -1634,7 +1634,14 @@ int conv_plan(ConvArgs& a) {
     const long rem = tiles - q * nwg;
     if (rem > 0) {
       per = (rem * ksteps + nwg - 1) / nwg;
-      if (per < 2) { per = 0; q = (tiles + nwg - 1) / nwg; nwg = (tiles + q - 1) / q; }  // tiny K: whole tiles only
+      if (per < 2) {                                   // tiny K: whole tiles only
+        // EOSVOS_TUNE_TINYK_ONE_TILE: one workgroup per tile (more workgroups than resident slots: the dispatcher refills a
+        // slot the moment a workgroup retires) instead of <= one resident round of workgroups walking several tiles each
+        static const int one = env_int("EOSVOS_TUNE_TINYK_ONE_TILE", 0);
+        per = 0;
+        if (one) { q = 1; nwg = tiles; }
+        else { q = (tiles + nwg - 1) / nwg; nwg = (tiles + q - 1) / q; }
+      }
     }
   } else {
     const long U = a.total_units > 0 ? a.total_units : tiles * ksteps;

@@ -253,6 +253,14 @@ struct eosvos_engine {
   std::map<int, MultiTab> aspp_multi;
   OuterEnt* outer_tab = nullptr;      // eosvos_outer_step: device table of the trainable tensors
   int outer_blocks = 0;
+  // per-launch workgroup budgets found by Engine.autotune (eosvos_set_launch_budget): (conv, kind 0 fwd / 1 dgrad / 2 wgrad,
+  // batch) -> budget; consulted only while the engine plans for the whole chip (wg_budget == 0)
+  std::map<long, int> tuned_budget;
+  int budget_for(int ci, int kind, int B) const {
+    if (wg_budget != 0 || tuned_budget.empty()) return wg_budget;
+    auto it = tuned_budget.find(((long)ci * 4 + kind) * 64 + B);
+    return it == tuned_budget.end() ? wg_budget : it->second;
+  }
   int plan_mode = -1;                 // matrix mode the cached launch plans (wg_plans, upd_tab) were built for, see plans_match_mode()
 
   // f16x3 matrix mode: absmax slots (bit patterns of max|x|), kind-major [AM_KINDS][nconv]; see amax_get()
@@ -626,7 +634,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.wg_budget = e->wg_budget;
+  a.wg_budget = e->budget_for(ci, 0, B);
   hipStream_t st = side ? e->s2 : e->s;
   a.x = x; a.w = e->W_(ci); a.y = y; a.ws = side ? e->ws_conv2 : e->ws_conv;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.ldx = ldx; a.Kc = c.cin;
@@ -655,6 +663,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     else launch_wino_input(x, ldx, c.cin, B, Hi, Wi, th, tw, wg.d, prow, e->wino_V[ci], st, vslot);
     e->wino_v_batch[ci] = B;
     ConvArgs m = wino_fwd_gemm(e, ci, wg, a.ws);
+    m.wg_budget = a.wg_budget;
     if (vslot) { m.amax_x = vslot; m.amax_w = amax_slot(e, AM_U, ci); }
     // the output transform writes y (directly, or the raw conv output of the GroupNorm mode)
     unsigned* yslot = gn ? nullptr : twrite_fused(e, 0, ykey, ldy == c.cout);
@@ -703,7 +712,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
   const ConvL& c = e->t.convs[ci];
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.wg_budget = e->wg_budget;
+  a.wg_budget = e->budget_for(ci, 1, B);
   if (!gkey) gkey = g;
   if (!gxkey) gxkey = gx;
   if (e->gn() && c.norm) { g = e->zbuf[ci]; ldg = c.cout; gkey = g; }   // gradient w.r.t. the raw conv output (conv_wgrad made it)
@@ -747,7 +756,7 @@ void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int 
     }
     ConvArgs m;
     memset(&m, 0, sizeof(m));
-    m.wg_budget = e->wg_budget;
+    m.wg_budget = a.wg_budget;
     if (h3_mode() && !amax_init(e)) {
       m.amax_x = amax_get(e, AM_DM, ci, e->wino_dM[ci], (long)wg.np * prow, c.cout, c.cout, e->s);   // made by the transform
       m.amax_w = amax_slot(e, AM_US, ci);
@@ -983,7 +992,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
     // kernel re-reads: plan the splits for half the workgroup budget (tools/budget_sweep.py: decoder conv at batch 3 247 -> 198 us,
     // batch 1 90 -> 72 us)
     static const bool wino_half = getenv("EOSVOS_TUNE_WINO_WGRAD_FULL_BUDGET") == nullptr;
-    const int wbud = wino_half ? conv_wg_budget_of(e->wg_budget) / 2 : e->wg_budget;
+    const int wbud = wino_half ? conv_wg_budget_of(e->budget_for(ci, 2, B)) / 2 : e->budget_for(ci, 2, B);
     a.splits = wgrad_pick_splits((int)ntile, c.cout, c.cin, wg.np, wbud);
     trace("wgrad", ci, c.cout, (long)c.cin * wg.np, ntile, a.splits);
     const int cin = c.cin, cout = c.cout;
@@ -1026,7 +1035,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
       e->wg_pending.push_back({ci, a});
       return -1;
     }
-    a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T(), e->wg_budget);
+    a.splits = wgrad_pick_splits(B * a.Ho * a.Wo, c.cout, c.cin, c.T(), e->budget_for(ci, 2, B));
     trace("wgrad", ci, c.cout, (long)c.cin * c.T(), (long)B * a.Ho * a.Wo, a.splits, wgrad_exec_frac(a));
     go = [=](hipStream_t ws) { launch_wgrad(a, ws); };
     nslabs = a.splits;
@@ -1190,7 +1199,7 @@ int wgrad_max_splits(int P, int Cout, int Cin, int T, int wg_budget) {
 
 extern "C" {
 
-const char* eosvos_version(void) { return "eosvos-mi355x 0.5 (gfx950, fp32 implicit GEMM on the fp16 matrix cores: 2-way split, 3 partial products on v_mfma_f32_16x16x32_f16; bf16x6 and fp32-MFMA modes selectable)"; }
+const char* eosvos_version(void) { return "eosvos-mi355x 0.6 (gfx950, fp32 implicit GEMM on the fp16 matrix cores: 2-way split, 3 partial products on v_mfma_f32_16x16x32_f16; bf16x6 and fp32-MFMA modes selectable)"; }
 const char* eosvos_last_error(void) { return g_err.c_str(); }
 
 int eosvos_set_matrix_mode(int mode) {
@@ -1209,6 +1218,15 @@ int eosvos_set_wg_budget(eosvos_engine* e, int workgroups) {
   return e->wg_budget;
 }
 
+int eosvos_set_launch_budget(eosvos_engine* e, int conv_idx, int kind, int batch, int workgroups) {
+  if (!e) return fail("null engine");
+  if (conv_idx < 0 || conv_idx >= (int)e->t.convs.size() || kind < 0 || kind > 2 || batch < 1 || batch > e->maxB) return fail("bad launch key");
+  const long key = ((long)conv_idx * 4 + kind) * 64 + batch;
+  if (workgroups < 0) e->tuned_budget.erase(key);
+  else e->tuned_budget[key] = conv_clamp_wg_budget(workgroups);
+  for (auto& tab : e->upd_tab) tab = nullptr;      // weight-gradient split counts follow the budget
+  return 0;
+}
 int eosvos_set_side_stream(eosvos_engine* e, int on) {
   if (!e) { fail("null engine"); return -1; }
   if (hipSetDevice(e->dev) != hipSuccess) { fail("hipSetDevice"); return -1; }

@@ -385,6 +385,33 @@ class Engine:
             _ffi.check(1)
         return r
 
+    def autotune(self, batch, budgets=(0, 448, 384, 320, 256), reps=8, min_gain=0.04):
+        """Time the forward / data-gradient / weight-gradient launch of every conv at `batch` under each workgroup budget
+        (on the engine's own buffers: call it before real work, weights and activations are left as they are, gradients
+        are overwritten) and keep, per launch, the fastest one if it beats the whole-chip plan by `min_gain`
+        (`eosvos_set_launch_budget`).  Returns {(conv, kind): budget} of the overrides set."""
+        n = int(self.lib.eosvos_num_convs(self.arch))
+        chosen = {}
+        for ci in range(1, n):
+            for kind in (0, 1, 2):
+                ms = {}
+                for b in budgets:
+                    self.set_wg_budget(b)
+                    try:
+                        ms[b] = self.bench_conv(ci, kind, batch, reps=reps)[0]
+                    except _ffi.EosvosError:
+                        ms = None
+                        break
+                if not ms:
+                    continue
+                best = min(ms, key=ms.get)
+                if best != 0 and ms[best] < (1.0 - min_gain) * ms[0]:
+                    chosen[(ci, kind)] = best
+        self.set_wg_budget(0)
+        for (ci, kind), b in chosen.items():
+            _ffi.check(self.lib.eosvos_set_launch_budget(self.h, ci, kind, batch, b))
+        return chosen
+
     def set_side_stream(self, on):
         """`eosvos_set_side_stream`: False for engines that run side by side (one queue each); returns the state in effect."""
         r = self.lib.eosvos_set_side_stream(self.h, int(bool(on)))

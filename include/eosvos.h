@@ -83,6 +83,11 @@ int eosvos_get_matrix_mode(void);
  * No reference counterpart (the reference runs one task per process and lets cuDNN choose). */
 int eosvos_set_wg_budget(eosvos_engine* e, int workgroups);
 
+/* Per-launch override of the workgroup budget (see eosvos_set_wg_budget): the forward (kind 0), data-gradient (1) or
+ * weight-gradient (2) launch of conv `conv_idx` at batch size `batch` plans for `workgroups` workgroups (0 = the whole chip,
+ * < 0 removes the override) while the engine's own budget is 0.  `Engine.autotune` times every launch under a few budgets
+ * and keeps the fastest.  A budget only changes how a reduction is split, i.e. the fp32 summation order. */
+int eosvos_set_launch_budget(eosvos_engine* e, int conv_idx, int kind, int batch, int workgroups);
 /* An engine alone on the GPU runs its weight-gradient launches on a second (side) stream beside the data-gradient chain
  * (on = 1, the default).  Engines that run side by side -- the tasks of a meta-batch in flight on one GPU, the objects of
  * a sequence (evaluate.py:132) -- are better off with ONE queue each (on = 0): the other engines fill the chip, and the
