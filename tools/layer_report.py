@@ -28,10 +28,11 @@ def main(trace_csv, log, steps=3):
     assert len(launches) == len(mf), (len(launches), len(mf))
     # one step = from a conv=1 fwd launch to the next
     starts = [i for i, l in enumerate(launches) if l[0] == 'fwd' and l[1] == 1]
-    per = starts[1] - starts[0] if len(starts) > 1 else len(launches)
+    # (the first forwards of a run may be the range guard's: forward-only "steps"; the steady-state period is the last one)
+    per = starts[-1] - starts[-2] if len(starts) > 1 else len(launches)
     agg = defaultdict(lambda: [0.0, 0.0, 0, None])
     fixt = defaultdict(float)
-    full = [s for s in starts if s + per <= len(launches)][-steps:]
+    full = [s for i, s in enumerate(starts) if s + per <= len(launches) and (i + 1 == len(starts) or starts[i + 1] == s + per)][-steps:]
     for s in full:
         for i in range(s, s + per):
             k, ci, M, N, K, sp, fl = launches[i]
@@ -56,9 +57,14 @@ def main(trace_csv, log, steps=3):
     excess.sort(reverse=True)
     print('largest excess over a 200 TFLOP/s pace: ' + ', '.join(f'{k}{ci}:{ex:.0f}us' for ex, pos, k, ci in excess[:24]))
     print('total excess: %.2f ms' % (sum(e[0] for e in excess if e[0] > 0) / 1e3))
-    nsteps = max(1, len(starts))
+    # kernel totals over the time window of the averaged steps only
+    nsteps = max(1, len(full))
+    t_lo = int(mf[full[0]]['Start_Timestamp']) if full else 0
+    t_hi = int(mf[full[-1] + per]['Start_Timestamp']) if full and full[-1] + per < len(mf) else max(int(r['End_Timestamp']) for r in rows) + 1
     byname = defaultdict(lambda: [0, 0])
     for r in rows:
+        if not (t_lo <= int(r['Start_Timestamp']) < t_hi):
+            continue
         nm = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('eosvos::', '')
         byname[nm][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); byname[nm][1] += 1
     print(f'per-step kernel totals over {nsteps} traced steps (launches/step, us/step):')

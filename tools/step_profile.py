@@ -2,6 +2,8 @@
 import os
 import sys
 
+os.environ.setdefault('EOSVOS_MODE_GUARD', '0')      # profiling target: no range-guard forwards in the trace
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eosvos_amd import synthetic  # noqa: E402
 from eosvos_amd.engine import Engine  # noqa: E402
