@@ -1189,8 +1189,11 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[conv_xs_smem<BN, 3>()];
   conv_xs_body<BN, KMAJOR, 3>(p, smem);
 }
+#ifndef EOSVOS_H3_OCC64
+#define EOSVOS_H3_OCC64 2       // workgroups per CU the 64-wide f16x3 kernels are compiled for (experiment: 3 / 4 for short-K launches)
+#endif
 template <int BN, bool KMAJOR>
-__global__ __launch_bounds__(256, 2) void conv_h3_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, BN == 64 ? EOSVOS_H3_OCC64 : 2) void conv_h3_kernel(const ConvArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[conv_xs_smem<BN, 2>()];
   conv_xs_body<BN, KMAJOR, 2>(p, smem);
 }

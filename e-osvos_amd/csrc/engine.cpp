@@ -1883,11 +1883,17 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   }
   {
     int sp[4];
-    for (int i = 0; i < 4; ++i) sp[i] = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B, e->g_cat);
-    if (!aspp_dgrad_merged(e, B, g_l4, l4))
+    static const int wg_after = getenv("EOSVOS_TUNE_ASPP_WGRAD_AFTER") ? atoi(getenv("EOSVOS_TUNE_ASPP_WGRAD_AFTER")) : 0;
+    if (!wg_after)
+      for (int i = 0; i < 4; ++i) sp[i] = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B, e->g_cat);
+    if (!aspp_dgrad_merged(e, B, g_l4, l4)) {
+      if (wg_after) return fail("EOSVOS_TUNE_ASPP_WGRAD_AFTER needs the merged ASPP data gradient");
       for (int i = 0; i < 4; ++i)
         conv_dgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, e->h16, e->w16, g_l4, 2048, B, true, i == 3 ? l4 : nullptr, 2048, 0, nullptr, 0,
                    e->g_cat);
+    }
+    if (wg_after)
+      for (int i = 0; i < 4; ++i) sp[i] = conv_wgrad(e, t.aspp[i], e->g_cat + 256 * i, 1280, l4, 2048, e->h16, e->w16, B, e->g_cat);
     for (int i = 0; i < 4; ++i) apply_update(e, t.aspp[i], sp[i], update, accumulate);
   }
   // bottlenecks, last to first.  g_out of each block = dL/d(pre-ReLU block output).
