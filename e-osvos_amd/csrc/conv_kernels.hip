@@ -1127,12 +1127,20 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
       __syncthreads();
       if (full) {
         if (n < p.N) {
-          constexpr int NIT = BM / CROWS, EB = EOSVOS_EB;
+#ifndef EOSVOS_EB128
+#define EOSVOS_EB128 EOSVOS_EB      // rows per batch in the 128-wide kernels (their accumulators are dead here: registers to spare)
+#endif
+          constexpr int NIT = BM / CROWS, EB = BN == 128 ? EOSVOS_EB128 : EOSVOS_EB;
+          // the tensor added to the tile: the residual / skip gradient (res) or the destination's previous contents (accum).
+          // One register set serves both; a launch with both (none in the network) reads the second one row by row.
+          const float* const adp = p.res ? p.res : (p.accum ? p.y : nullptr);
+          const int adld = p.res ? p.ldres : p.ldy;
+          const bool both = p.res && p.accum;
 #pragma unroll
           for (int it0 = 0; it0 < NIT; it0 += EB) {
             size_t md[EB];
             bool ok[EB];
-            float4 rs[EB], ac[EB];
+            float4 ad[EB];
             unsigned mk8[EB];                 // ReLU mask bits of the row's 4 channels (from mask bytes, or from the fp32 activation)
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
@@ -1140,13 +1148,9 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
               ok[j] = m < p.M;
               md[j] = dst_pixel(p, ok[j] ? m : p.M - 1);
             }
-            if (p.res) {
+            if (adp) {
 #pragma unroll
-              for (int j = 0; j < EB; ++j) rs[j] = ldg4_stream(p.res + md[j] * p.ldres + n);
-            }
-            if (p.accum) {
-#pragma unroll
-              for (int j = 0; j < EB; ++j) ac[j] = ldg4(p.y + md[j] * p.ldy + n);
+              for (int j = 0; j < EB; ++j) ad[j] = ldg4_stream(adp + md[j] * adld + n);
             }
             if (use_mask8) {
 #pragma unroll
@@ -1160,8 +1164,8 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
               float4 v = *reinterpret_cast<const float4*>(Cs + (c_r + (it0 + j) * CROWS) * LDC + c_c4 * 4);
               if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
               if (p.bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
-              if (p.res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
-              if (p.accum) { v.x += ac[j].x; v.y += ac[j].y; v.z += ac[j].z; v.w += ac[j].w; }
+              if (adp) { v.x += ad[j].x; v.y += ad[j].y; v.z += ad[j].z; v.w += ad[j].w; }
+              if (both) { const float4 a2 = ldg4(p.y + md[j] * p.ldy + n); v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w; }
               if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
               if (use_mask8 || use_mask) relu_mask8(v, mk8[j]);
               if (ok[j]) {
