@@ -284,10 +284,13 @@ struct eosvos_engine {
   // forward epilogue that applies the ReLU (frozen-BN mode: every producer has the fused write; GroupNorm mode has none and
   // keeps reading the fp32 activation)
   std::map<const float*, uint8_t*> mask8;
+  bool fwd_masks = true;             // false during eosvos_infer: no backward pass will read the masks of this forward
+  bool masks_valid = false;          // the mask bytes belong to the activations of the last forward
   uint8_t* m8(const float* key) const {
     auto it = mask8.find(key);
     return it == mask8.end() ? nullptr : it->second;
   }
+  uint8_t* m8w(const float* key) const { return fwd_masks ? m8(key) : nullptr; }      // for the forward's writers
   int64_t max_alloc_floats = 0;      // largest single allocation (every conv operand is one of them)
   // EOSVOS_DEBUG_GUARD=1: every buffer sits between two 256 KB guard bands filled with a pattern;
   // eosvos_debug_check_guards reports bands a kernel wrote into (out-of-bounds writes)
@@ -668,7 +671,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     // the output transform writes y (directly, or the raw conv output of the GroupNorm mode)
     unsigned* yslot = gn ? nullptr : twrite_fused(e, 0, ykey, ldy == c.cout);
     if (gn) twrite_plain(e, 0, ykey);
-    uint8_t* ym8 = (gn || !e->m8(ykey)) ? nullptr : e->m8(ykey) + (y - ykey) / 4;
+    uint8_t* ym8 = (gn || !e->m8w(ykey)) ? nullptr : e->m8w(ykey) + (y - ykey) / 4;
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
     if (wg.tm == 4)
@@ -688,7 +691,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     a.scale = e->A_(ci); a.bias = e->B_(ci);
     a.res = res; a.ldres = ldres; a.relu = relu ? 1 : 0;
     if (relu)
-      if (uint8_t* m = e->m8(ykey)) { a.mask8_out = m + (y - ykey) / 4; a.ldm8_out = ldy / 4; }
+      if (uint8_t* m = e->m8w(ykey)) { a.mask8_out = m + (y - ykey) / 4; a.ldm8_out = ldy / 4; }
   }
   attach_tap_table(e, ci, 0, B, a);
   if (h3_mode() && !amax_init(e)) {
@@ -1778,7 +1781,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   } else {
     launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, s);
   }
-  launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s, e->m8(e->cat) ? e->m8(e->cat) + 1024 / 4 : nullptr, 1280 / 4);
+  launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s, e->m8w(e->cat) ? e->m8w(e->cat) + 1024 / 4 : nullptr, 1280 / 4);
   if (h3_mode() && !e->gn() && !amax_init(e)) {
     // cat = 4 conv outputs (their epilogues fed the tensor's slot) + the broadcast pooling branch (its B x 256 values here)
     if (unsigned* cs = tslot(e, 0, e->cat)) { launch_absmax(e->poolout, 1, B * 256, B * 256, cs, s); tmark_valid(e, 0, e->cat); }
@@ -1801,6 +1804,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   launch_resize_fwd(e->lowlog, 1, e->logits, 1, B, 1, e->fin_h, e->fin_w, s);
   e->lastB = B;
   e->have_loss_grad = false;
+  e->masks_valid = e->fwd_masks;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("forward launch: ") + hipGetErrorString(err));
   return 0;
@@ -1815,6 +1819,8 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   const int B = e->lastB;
   if (B < 1 || !e->have_loss_grad) return fail("backward without forward + loss");
   if (accumulate && !e->gsum) return fail("accumulate without eosvos_meta_task_begin");
+  if (!e->mask8.empty() && !e->masks_valid)
+    return fail("backward after eosvos_infer: an inference forward keeps no ReLU masks (run eosvos_forward / eosvos_finetune_step)");
   plans_match_mode(e);
   const int64_t P4 = (int64_t)B * e->h4 * e->w4;
   const int P16 = e->h16 * e->w16;
@@ -2060,7 +2066,10 @@ int eosvos_keep_grads(eosvos_engine* e, int on) {
 int eosvos_infer(eosvos_engine* e, const float* images, int batch, float* probs_out) {
   if (!e || !images || !probs_out) return fail("null argument");
   if (batch < 1 || batch > e->maxB) return fail("batch out of range");
-  if (forward_impl(e, images, batch)) return 1;
+  e->fwd_masks = false;                 // inference: nothing will differentiate through this forward
+  const int rc = forward_impl(e, images, batch);
+  e->fwd_masks = true;
+  if (rc) return 1;
   launch_sigmoid(e->logits, probs_out, (int64_t)batch * e->H * e->W, e->s);
   HIPOK(hipGetLastError());
   return 0;

@@ -195,7 +195,8 @@ int eosvos_keep_grads(eosvos_engine* e, int on);
 int eosvos_get_grads(eosvos_engine* e, float* flat_grads_out);
 
 /* ---- inference (helper_func.py:131-142, evaluate.py:322-326) ----------------------- */
-/* probs = sigmoid(model(images)[-1]); probs_out B x 1 x H x W. */
+/* probs = sigmoid(model(images)[-1]); probs_out B x 1 x H x W.  An inference forward keeps no ReLU masks: a loss +
+ * backward step must follow eosvos_forward / eosvos_finetune_step, not this call (eosvos_backward_step fails otherwise). */
 int eosvos_infer(eosvos_engine* e, const float* images, int batch, float* probs_out);
 /* labels[p] = 0 if max_o probs[o][p] < 0.5 else argmax_o + 1.  probs: n_obj x H*W. */
 int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t n_pix,

@@ -595,6 +595,16 @@ def test_edge_cases_and_error_behaviour(small_engine, weights):
     assert rc != 0 and len(lib.eosvos_last_error()) > 0
     rc = lib.eosvos_forward(eng.h, None, 1, None)
     assert rc != 0
+    # an inference forward keeps no ReLU masks: loss + backward after it is refused, after a forward it works
+    eng.infer(xg[:1].contiguous())
+    gt1 = torch.zeros(1, 1, *SMALL, device=DEV)
+    eng.loss('cross_entropy', gt1)
+    with pytest.raises(_ffi.EosvosError, match='eosvos_infer'):
+        eng.backward_step()
+    eng.forward(xg[:1].contiguous(), want_logits=False)
+    eng.loss('cross_entropy', gt1)
+    eng.backward_step()
+    eng.reset()
     eng.forward(xg[:1].contiguous(), want_logits=False)
     gt2 = torch.zeros(2, 1, *SMALL, device=DEV)
     with pytest.raises(_ffi.EosvosError):
