@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvArgs p) {
 }
 
 static int env_int(const char* name, int dflt);
+
 // Tile width in N.  128 x 64 tiles (half the bytes of every parked partial tile, twice the tiles, 1.5x the LDS reads per
 // MFMA) pay for launches that have few tiles AND a short K: per-layer A/B in the f16x3 mode (tools/layer_times.py,
 // profiles/r03_bn64_layer_times.txt) -- the 1x1 convs of layer2-4 / ASPP at batch 1 gain 5-30 %, long-K 3x3 convs and
@@ -1211,6 +1212,231 @@ __global__ __launch_bounds__(256, 2) void conv_x6_multi_kernel(const ConvArgs p)
   conv_xs_body<128, true, 3, true>(p, smem);
 }
 
+// ---------------------------------------------------------------------------------------
+// Streaming kernel for the SHORT-K 1x1 stride-1 convolutions on the large maps (layer1 / layer2: K = 64 ... 256 reduction
+// channels, tens of thousands of pixels), forward and data gradient, f16x3 mode.  These launches are HBM-bound -- a pixel's
+// output row (+ residual) is 4-16x its input row -- and ran at 2-3.5 TB/s in the tiled kernel above: a 128 x 128 tile with
+// 2-8 K steps spends most of its time in the fixed cost per tile (prologue, first operand latency, two barriers per K step,
+// the LDS-staged epilogue), and neither deeper epilogue batches, more workgroups per CU nor narrower tiles changed that
+// (DESIGN.md 5b, round 4).  Structure here (tools/probes/skinny_probe.cpp): a 512-thread workgroup keeps the WHOLE weight
+// matrix of its column range (NC output channels x K) in LDS, split once into the two fp16 pieces; after that single barrier
+// each wave streams strips of 16 pixels on its own: X fragments straight from global into registers (a lane's 8 k values are
+// 32 contiguous bytes), split per wave, D = W_frag * X_frag^T on v_mfma_f32_16x16x32_f16, so that a lane ends up with 4
+// CONSECUTIVE channels of one pixel: float4 residual / accumulate loads and output stores, one mask byte per lane, the next
+// strip's activations in flight behind the current strip's MFMAs.  Measured: layer1 conv3 (64 -> 256, + residual) 60 -> 41 us,
+// layer2 conv3 (128 -> 512) 43 -> 31 us, layer1 conv1 (256 -> 64) 35 -> 26 us.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void amax_block_commit8(unsigned m, unsigned* slot) {      // 8 waves per workgroup
+  __shared__ unsigned wmax8[8];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = m > t ? m : t;
+  }
+  if ((threadIdx.x & 63) == 0) wmax8[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned q = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q = q > wmax8[i] ? q : wmax8[i];
+    if (q) atomicMax(slot + (size_t)((blockIdx.x + blockIdx.y) & (AMAX_SUB - 1)) * AMAX_ROW, q);
+  }
+}
+__device__ __forceinline__ void s1_split8(const float4& lo, const float4& hi, float s, uint4& h0, uint4& h1) {
+  const float v[8] = {lo.x * s, lo.y * s, lo.z * s, lo.w * s, hi.x * s, hi.y * s, hi.z * s, hi.w * s};
+  unsigned a[4], b[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = h3_pack(v[2 * e], v[2 * e + 1]);
+    const f32x2v u = h3_unpack(a[e]);
+    b[e] = h3_pack(v[2 * e] - u.x, v[2 * e + 1] - u.y);
+  }
+  h0 = make_uint4(a[0], a[1], a[2], a[3]);
+  h1 = make_uint4(b[0], b[1], b[2], b[3]);
+}
+template <int K, int NC>
+__global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(const ConvArgs p) {
+  constexpr int WAVES = 8;
+  constexpr int KS = K / 32;                          // K steps of the 16x16x32 MFMA
+  constexpr int PITCH = K * 2 + 16;                   // bytes per weight row of one piece (pad: conflict-free fragment reads)
+  constexpr int NF = NC / 16;                         // 16-channel fragments of the column range
+  constexpr int FHM = K >= 256 ? 4 : 8;
+  constexpr int FH = NF < FHM ? NF : FHM;             // fragments per pass (4 accumulator registers each)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s1_smem[];      // [2 pieces][NC rows][PITCH] | scale[NC] bias[NC] kscale[K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * NC;
+  // per-channel epilogue / staging factors live in LDS: a global load per fragment and strip would stall every epilogue pass
+  float* const s_sc = reinterpret_cast<float*>(s1_smem + 2 * NC * PITCH);
+  float* const s_bi = s_sc + NC;
+  float* const s_ks = s_bi + NC;
+  for (int i = tid; i < NC; i += WAVES * 64) {
+    s_sc[i] = p.scale ? p.scale[n0 + i] : 1.f;
+    s_bi[i] = p.bias ? p.bias[n0 + i] : 0.f;
+  }
+  for (int i = tid; i < K; i += WAVES * 64) s_ks[i] = p.kscale ? p.kscale[i] : 1.f;
+  float ix, iw;
+  const float sx = h3_scale(p.amax_x, p.kmajor ? p.amax_ks : nullptr, ix);
+  const float sw = h3_scale(p.amax_w, nullptr, iw);
+  const float inv = ix * iw;
+  // ---- weights of this column range: fp32 -> the two fp16 pieces, once ----
+  if (!p.kmajor) {                                    // forward: W[n][K], a row's k contiguous
+    for (int i = tid; i < NC * (K / 8); i += WAVES * 64) {
+      const int r = i / (K / 8), c8 = i % (K / 8);
+      const float* src = p.w + (size_t)(n0 + r) * p.wK + c8 * 8;
+      uint4 h0, h1;
+      s1_split8(ldg4(src), ldg4(src + 4), sw, h0, h1);
+      *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
+      *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
+    }
+  } else {                                            // data gradient: W[k][N]: consecutive lanes read consecutive n of one k row
+    for (int i = tid; i < NC * (K / 8); i += WAVES * 64) {
+      const int c8 = i / NC, r = i % NC;
+      const float* src = p.w + (size_t)(c8 * 8) * p.wK + n0 + r;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * p.wK];
+      uint4 h0, h1;
+      s1_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, h0, h1);
+      *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
+      *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
+    }
+  }
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nstrips = (p.M + 15) / 16;
+  const int gw = blockIdx.x * WAVES + wave, gstride = gridDim.x * WAVES;
+  // the tensor added to the output: residual / skip gradient, or (accumulating data gradient) the destination's old contents
+  const float* const adp = p.res ? p.res : (p.accum ? p.y : nullptr);
+  const int adld = p.res ? p.ldres : p.ldy;
+  const bool both = p.res && p.accum;
+  float4 xr[KS][2];
+  auto load_x = [&](int strip) {
+    const int m = strip * 16 + fr;
+    const float* q = p.x + (size_t)(m < p.M ? m : p.M - 1) * p.ldx + fq * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      xr[ks][0] = ldg4(q + ks * 32);
+      xr[ks][1] = ldg4(q + ks * 32 + 4);
+    }
+  };
+  unsigned ymax = 0;
+  int strip = gw;
+  // With one pass over the column range (NF == FH) the addend rows and mask bytes of a strip are requested ONE STRIP AHEAD,
+  // together with its activations: an HBM round trip (1-2 us) is several times a strip's MFMA time.
+#ifndef EOSVOS_STREAM_AHEAD
+#define EOSVOS_STREAM_AHEAD 0      // measured: per launch +-10 % either way, the iteration 9.50 (ahead) vs 9.45 ms: off
+#endif
+  constexpr bool AHEAD = EOSVOS_STREAM_AHEAD && NF == FH;
+  float4 adn[FH];
+  unsigned mkn[FH];
+  auto load_ad = [&](int st, float4 (&ad)[FH], unsigned (&mk)[FH], int half) {
+    const int m = st * 16 + fr;
+    const size_t r = (size_t)(m < p.M ? m : p.M - 1);
+    if (adp) {
+#pragma unroll
+      for (int f = 0; f < FH; ++f) ad[f] = ldg4(adp + r * adld + n0 + (half + f) * 16 + 4 * fq);
+    }
+    if (p.mask8) {
+#pragma unroll
+      for (int f = 0; f < FH; ++f) mk[f] = p.mask8[r * p.ldm8 + ((n0 + (half + f) * 16) >> 2) + fq];
+    }
+  };
+  if (strip < nstrips) {
+    load_x(strip);
+    if (AHEAD) load_ad(strip, adn, mkn, 0);
+  }
+  for (; strip < nstrips; strip += gstride) {
+    uint4 x0[KS], x1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (p.kscale) {                                 // data gradient: the frozen-norm scale of the conv, per reduction channel
+        const float4 k0 = *reinterpret_cast<const float4*>(s_ks + ks * 32 + fq * 8), k1 = *reinterpret_cast<const float4*>(s_ks + ks * 32 + fq * 8 + 4);
+        xr[ks][0].x *= k0.x; xr[ks][0].y *= k0.y; xr[ks][0].z *= k0.z; xr[ks][0].w *= k0.w;
+        xr[ks][1].x *= k1.x; xr[ks][1].y *= k1.y; xr[ks][1].z *= k1.z; xr[ks][1].w *= k1.w;
+      }
+      s1_split8(xr[ks][0], xr[ks][1], sx, x0[ks], x1[ks]);
+    }
+    float4 ad[FH];
+    unsigned mk[FH];
+    if (AHEAD) {
+#pragma unroll
+      for (int f = 0; f < FH; ++f) { ad[f] = adn[f]; mk[f] = mkn[f]; }
+    }
+    const int nxt = strip + gstride;
+    if (nxt < nstrips) {                              // the next strip's operands in flight behind this strip's work
+      load_x(nxt);
+      if (AHEAD) load_ad(nxt, adn, mkn, 0);
+    }
+    const int m = strip * 16 + fr;
+    const bool ok = m < p.M;
+    const size_t row = (size_t)(ok ? m : p.M - 1);
+#pragma unroll 1
+    for (int half = 0; half < NF; half += FH) {
+      if (!AHEAD) load_ad(strip, ad, mk, half);
+      f32x4 acc[FH];
+#pragma unroll
+      for (int f = 0; f < FH; ++f) {
+        acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const unsigned char* wp = s1_smem + ((half + f) * 16 + fr) * PITCH + ks * 64 + fq * 16;
+          const uint4 w0 = *reinterpret_cast<const uint4*>(wp);
+          const uint4 w1 = *reinterpret_cast<const uint4*>(wp + NC * PITCH);
+          acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, x0[ks]), acc[f]);      // smallest terms first
+          acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, x1[ks]), acc[f]);
+          acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, x0[ks]), acc[f]);
+        }
+        __builtin_amdgcn_sched_barrier(0);            // (keeps later fragments' reads from being hoisted: register pressure)
+      }
+#pragma unroll
+      for (int f = 0; f < FH; ++f) {
+        const int n = n0 + (half + f) * 16 + 4 * fq;
+        float4 v = make_float4(acc[f][0] * inv, acc[f][1] * inv, acc[f][2] * inv, acc[f][3] * inv);
+        if (p.scale) { const float4 s4 = *reinterpret_cast<const float4*>(s_sc + (n - n0)); v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
+        if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(s_bi + (n - n0)); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (adp) { v.x += ad[f].x; v.y += ad[f].y; v.z += ad[f].z; v.w += ad[f].w; }
+        if (both) { const float4 a2 = ldg4(p.y + row * p.ldy + n); v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w; }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.mask8 && n >= p.mask_c0) relu_mask8(v, mk[f]);
+        if (ok) {
+          *reinterpret_cast<float4*>(p.y + row * p.ldy + n) = v;
+          if (p.mask8_out && p.relu) p.mask8_out[row * p.ldm8_out + (n >> 2)] = relu_bits(v);
+          ymax = amax_f4(ymax, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (p.amax_y) amax_block_commit8(ymax, p.amax_y);
+}
+// the launches the streaming kernel takes (f16x3 mode): 1x1, stride 1, K in {64, 128, 256}, whole column ranges, many pixels
+static int stream1x1_nc(const ConvArgs& a) {
+  static const int on = env_int("EOSVOS_TUNE_STREAM1X1", 1), min_m = env_int("EOSVOS_TUNE_STREAM1X1_MINM", 16384);
+  if (!on || conv_mfma_mode() != 2 || a.nseg > 0 || a.plane_rows || a.KH != 1 || a.KW != 1 || a.upshift || a.dst_up || a.par ||
+      a.tprefix || a.mul != 1 || a.off0 != 0 || a.M < min_m)
+    return 0;
+  if (a.Kc != 64 && a.Kc != 128 && a.Kc != 256) return 0;
+  if (a.mask && !a.mask8) return 0;                   // (the fp32-mask form stays with the tiled kernel)
+  if ((a.mask_c0 & 15) || (a.ldx & 3) || (a.ldy & 3) || (a.N & 15)) return 0;
+  if (a.Hi != a.Ho || a.Wi != a.Wo) return 0;
+  if (a.N % 128 == 0) return 128;
+  if (a.N == 64) return 64;
+  return 0;
+}
+template <int K, int NC>
+static void launch_stream1x1(const ConvArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * NC * (K * 2 + 16) + (2 * NC + K) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<K, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  // one workgroup per CU over all column ranges together (a workgroup's 8 waves take the strips of its range round-robin):
+  // measured per shape with 128 / 256 / 512 / 1024 workgroups per range, 256 in all is the fastest or within 2 % of it
+  static const int total = env_int("EOSVOS_TUNE_STREAM1X1_WGS", 256);
+  const int ranges = a.N / NC;
+  const int wgs = total / ranges > 0 ? total / ranges : 1;
+  hipLaunchKernelGGL((conv1x1_stream_kernel<K, NC>), dim3(wgs, ranges), dim3(512), lds, s, a);
+}
+
+
 // Weight gradient on the bf16 matrix cores: same split, both operands K-major (a pixel's channels are contiguous).
 template <int BMO, int BNI, int NP> constexpr int wgrad_xs_smem() { return xs_max(NP * (BMO + BNI) * X6_ROWB, BMO * (BNI + 4) * 4); }
 template <int BMO, int BNI, int NP = 3>
@@ -1526,7 +1752,7 @@ const char* const kProfNames[] = {
     "conv_h3_kernel<128, false>", "conv_h3_kernel<128, true>", "conv_h3_kernel<64, false>", "conv_h3_kernel<64, true>",
     "wgrad_h3_kernel<128, 128>", "wgrad_h3_kernel<128, 64>", "wgrad_h3_kernel<64, 128>", "wgrad_h3_kernel<64, 64>",
     "wgrad_h3_group_kernel<128, 128>", "wgrad_h3_group_kernel<128, 64>", "wgrad_h3_group_kernel<64, 128>", "wgrad_h3_group_kernel<64, 64>",
-    "conv_h3_multi_kernel", "conv_x6_multi_kernel"};
+    "conv_h3_multi_kernel", "conv_x6_multi_kernel", "conv1x1_stream_kernel<*, 128>", "conv1x1_stream_kernel<*, 64>"};
 constexpr int kProfKernels = sizeof(kProfNames) / sizeof(kProfNames[0]);
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -1704,6 +1930,20 @@ int conv_plan(ConvArgs& a) {
 }
 
 void launch_conv(ConvArgs& a, hipStream_t s) {
+  if (const int nc = stream1x1_nc(a)) {               // short-K 1x1 convs on the large maps: the streaming kernel
+    a.dp_q = 0; a.per = 0; a.nwg = 0; a.splitk = 0;
+    ProfScope ps(nc == 128 ? 35 : 36, 2.0 * a.M * a.N * a.Kc, s);
+    if (nc == 128) {
+      if (a.Kc == 64) launch_stream1x1<64, 128>(a, s);
+      else if (a.Kc == 128) launch_stream1x1<128, 128>(a, s);
+      else launch_stream1x1<256, 128>(a, s);
+    } else {
+      if (a.Kc == 64) launch_stream1x1<64, 64>(a, s);
+      else if (a.Kc == 128) launch_stream1x1<128, 64>(a, s);
+      else launch_stream1x1<256, 64>(a, s);
+    }
+    return;
+  }
   const int bn = conv_bn(a);
   const int nwg = conv_plan(a);
   const long tiles = (long)((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
