@@ -1254,13 +1254,16 @@ __device__ __forceinline__ void s1_split8(const float4& lo, const float4& hi, fl
   h0 = make_uint4(a[0], a[1], a[2], a[3]);
   h1 = make_uint4(b[0], b[1], b[2], b[3]);
 }
+#ifndef EOSVOS_STREAM_OCC
+#define EOSVOS_STREAM_OCC 1        // workgroups per CU the K <= 128 variants are compiled for (2: 128 VGPRs, 4 fragments per pass)
+#endif
 template <int K, int NC>
-__global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1x1_stream_kernel(const ConvArgs p) {
   constexpr int WAVES = 8;
   constexpr int KS = K / 32;                          // K steps of the 16x16x32 MFMA
   constexpr int PITCH = K * 2 + 16;                   // bytes per weight row of one piece (pad: conflict-free fragment reads)
   constexpr int NF = NC / 16;                         // 16-channel fragments of the column range
-  constexpr int FHM = K >= 256 ? 4 : 8;
+  constexpr int FHM = (K >= 256 || EOSVOS_STREAM_OCC > 1) ? 4 : 8;
   constexpr int FH = NF < FHM ? NF : FHM;             // fragments per pass (4 accumulator registers each)
   extern __shared__ __attribute__((aligned(16))) unsigned char s1_smem[];      // [2 pieces][NC rows][PITCH] | scale[NC] bias[NC] kscale[K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1419,6 +1422,8 @@ static int stream1x1_nc(const ConvArgs& a) {
   if (a.mask && !a.mask8) return 0;                   // (the fp32-mask form stays with the tiled kernel)
   if ((a.mask_c0 & 15) || (a.ldx & 3) || (a.ldy & 3) || (a.N & 15)) return 0;
   if (a.Hi != a.Ho || a.Wi != a.Wo) return 0;
+  static const int nc256 = env_int("EOSVOS_TUNE_STREAM1X1_NC256", 0);     // experiment: whole 256-channel rows per workgroup
+  if (nc256 && a.N % 256 == 0 && a.Kc <= 128) return 256;
   if (a.N % 128 == 0) return 128;
   if (a.N == 64) return 64;
   return 0;
@@ -1430,7 +1435,7 @@ static void launch_stream1x1(const ConvArgs& a, hipStream_t s) {
   if (!attr) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<K, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   // one workgroup per CU over all column ranges together (a workgroup's 8 waves take the strips of its range round-robin):
   // measured per shape with 128 / 256 / 512 / 1024 workgroups per range, 256 in all is the fastest or within 2 % of it
-  static const int total = env_int("EOSVOS_TUNE_STREAM1X1_WGS", 256);
+  static const int total = env_int("EOSVOS_TUNE_STREAM1X1_WGS", 256 * (K <= 128 ? EOSVOS_STREAM_OCC : 1));
   const int ranges = a.N / NC;
   const int wgs = total / ranges > 0 ? total / ranges : 1;
   hipLaunchKernelGGL((conv1x1_stream_kernel<K, NC>), dim3(wgs, ranges), dim3(512), lds, s, a);
@@ -1932,8 +1937,11 @@ int conv_plan(ConvArgs& a) {
 void launch_conv(ConvArgs& a, hipStream_t s) {
   if (const int nc = stream1x1_nc(a)) {               // short-K 1x1 convs on the large maps: the streaming kernel
     a.dp_q = 0; a.per = 0; a.nwg = 0; a.splitk = 0;
-    ProfScope ps(nc == 128 ? 35 : 36, 2.0 * a.M * a.N * a.Kc, s);
-    if (nc == 128) {
+    ProfScope ps(nc >= 128 ? 35 : 36, 2.0 * a.M * a.N * a.Kc, s);
+    if (nc == 256) {
+      if (a.Kc == 64) launch_stream1x1<64, 256>(a, s);
+      else launch_stream1x1<128, 256>(a, s);
+    } else if (nc == 128) {
       if (a.Kc == 64) launch_stream1x1<64, 128>(a, s);
       else if (a.Kc == 128) launch_stream1x1<128, 128>(a, s);
       else launch_stream1x1<256, 128>(a, s);

@@ -111,6 +111,13 @@ STRIDED_CASES = [          # (B, H, W, Cin, Cout, k, stride, dil, pad): the non-
     (3, 120, 214, 128, 128, 3, 2, 1, 1),          # layer2.0.conv2 at batch 3: 602 uneven tiles -> whole tiles, longest first
     (3, 30, 54, 256, 256, 3, 1, 1, 1),            # layer3 conv2 at batch 3: 76 tiles, K = 2304 -> chunk-major split-K (x6)
     (3, 30, 54, 2048, 512, 1, 1, 1, 0),           # layer4 conv1 at batch 3: 152 tiles, K = 2048 -> split-K (x3)
+    # short-K 1x1 convs on the large maps: the streaming kernel (conv1x1_stream_kernel, f16x3 mode), forward = K Cin, data
+    # gradient = K Cout
+    (3, 120, 214, 64, 256, 1, 1, 1, 0),           # layer1 conv3 / downsample (fwd K 64, N 256; dgrad K 256, N 64)
+    (3, 120, 214, 256, 64, 1, 1, 1, 0),           # layer1 conv1 of blocks 1, 2
+    (1, 120, 214, 64, 64, 1, 1, 1, 0),            # layer1.0.conv1 at batch 1 (25 680 pixels: a ragged last strip)
+    (3, 60, 107, 128, 512, 1, 1, 1, 0),           # layer2 conv3 (19 260 pixels, 4 column ranges)
+    (3, 120, 214, 256, 128, 1, 1, 1, 0),          # layer2.0.conv1
 ]
 
 
@@ -129,6 +136,29 @@ def test_strided_and_narrow_paths_elementwise_vs_fp64(eng, case):
     errs = (_maxrel(out.permute(0, 3, 1, 2), y.detach()), _maxrel(dx.permute(0, 3, 1, 2), xd.grad), _maxrel(dw, wd.grad))
     print(f'MARGIN auto {case} fwd {errs[0]:.2e} dx {errs[1]:.2e} dw {errs[2]:.2e}')
     assert max(errs) <= 2e-6, errs
+
+
+def test_streaming_1x1_kernel_fused_epilogue_vs_fp64(eng):
+    """The streaming kernel's fused forward epilogue -- norm scale + shift, residual, ReLU -- on layer1 conv3's shape at
+    batch 3 (77 040 pixels, 64 -> 256), elementwise against fp64; every matrix mode gives the same answer to rounding (the
+    other two run the tiled kernel)."""
+    B, H, W, Ci, Co = 3, 120, 214, 64, 256
+    g = torch.Generator().manual_seed(11)
+    x = torch.relu(torch.randn(B, Ci, H, W, generator=g))
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    a, b = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    res = torch.randn(B, Co, H, W, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double()) * a.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1) + res.double())
+    prev = engine_mod.get_matrix_mode()
+    try:
+        for mode in ('f16x3', 'bf16x6'):
+            engine_mod.set_matrix_mode(mode)
+            out = eng.test_conv_algo('direct', nhwc(x), w.to(DEV), a.to(DEV), b.to(DEV), nhwc(res), True, 1, 1, 0).permute(0, 3, 1, 2)
+            err = _maxrel(out, ref)
+            print(f'MARGIN streaming 1x1 fused epilogue {mode}: {err:.2e}')
+            assert err <= 2e-6, (mode, err)
+    finally:
+        engine_mod.set_matrix_mode(prev)
 
 
 def test_bf16x6_is_at_least_as_accurate_as_the_fp32_mfma(eng):
