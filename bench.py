@@ -156,10 +156,14 @@ def pmc_traffic(kernel, lib_version, batch):
             p = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if p.get('kernel') != kernel or p.get('lib_version') != lib_version or p.get('batch') != batch:
+        if p.get('lib_version') != lib_version or p.get('batch') != batch:
             why = f"PMC artifact is for {p.get('kernel')} / {p.get('lib_version')} / batch {p.get('batch')}"
             continue
-        return p['traffic_bytes_per_launch'], p.get('note', '')
+        # (three symbols take 20-24 % of the step each and which one leads flips between runs: the passes record all of them)
+        for q in [p] + list(p.get('others', [])):
+            if q.get('kernel') == kernel:
+                return q['traffic_bytes_per_launch'], p.get('note', '')
+        why = f"PMC artifact is for {p.get('kernel')} / {p.get('lib_version')} / batch {p.get('batch')}"
     return None, why
 
 

@@ -1265,6 +1265,10 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
   constexpr int NF = NC / 16;                         // 16-channel fragments of the column range
   constexpr int FHM = (K >= 256 || EOSVOS_STREAM_OCC > 1) ? 4 : 8;
   constexpr int FH = NF < FHM ? NF : FHM;             // fragments per pass (4 accumulator registers each)
+  // K = 512: a strip's activations are 128 registers per lane.  The K steps become the OUTER loop (all NF accumulators live),
+  // a K step's activations are split right before its MFMAs and its registers are refilled with the next strip's at once.
+  constexpr bool KOUT = K >= 512;
+  static_assert(!KOUT || NF == FH, "the K-outer form keeps every fragment's accumulator live");
   extern __shared__ __attribute__((aligned(16))) unsigned char s1_smem[];      // [2 pieces][NC rows][PITCH] | scale[NC] bias[NC] kscale[K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * NC;
@@ -1348,6 +1352,70 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
     load_x(strip);
     if (AHEAD) load_ad(strip, adn, mkn, 0);
   }
+  // epilogue of one 16-channel fragment: scale / shift / addend / ReLU / mask, float4 store + mask byte, absmax
+  auto finish = [&](const f32x4& a4, int f16, const float4& adv, unsigned mkv, size_t row, bool ok) {
+    const int n = n0 + f16 * 16 + 4 * fq;
+    float4 v = make_float4(a4[0] * inv, a4[1] * inv, a4[2] * inv, a4[3] * inv);
+    if (p.scale) { const float4 s4 = *reinterpret_cast<const float4*>(s_sc + (n - n0)); v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
+    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(s_bi + (n - n0)); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+    if (adp) { v.x += adv.x; v.y += adv.y; v.z += adv.z; v.w += adv.w; }
+    if (both) { const float4 a2 = ldg4(p.y + row * p.ldy + n); v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w; }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.mask8 && n >= p.mask_c0) relu_mask8(v, mkv);
+    if (ok) {
+      *reinterpret_cast<float4*>(p.y + row * p.ldy + n) = v;
+      if (p.mask8_out && p.relu) p.mask8_out[row * p.ldm8_out + (n >> 2)] = relu_bits(v);
+      ymax = amax_f4(ymax, v);
+    }
+  };
+  if constexpr (KOUT) {
+    for (; strip < nstrips; strip += gstride) {
+      const int nxt = strip + gstride;
+      const bool more = nxt < nstrips;
+      const int mn = nxt * 16 + fr;
+      const float* qn = p.x + (size_t)(mn < p.M ? mn : p.M - 1) * p.ldx + fq * 8;
+      const int m = strip * 16 + fr;
+      const bool ok = m < p.M;
+      const size_t row = (size_t)(ok ? m : p.M - 1);
+      float4 ad[FH];
+      unsigned mk[FH];
+      load_ad(strip, ad, mk, 0);
+      f32x4 acc[FH];
+#pragma unroll
+      for (int f = 0; f < FH; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float4 a = xr[ks][0], b = xr[ks][1];
+        if (more) {                                   // this K step's registers take the next strip's activations right away
+          xr[ks][0] = ldg4(qn + ks * 32);
+          xr[ks][1] = ldg4(qn + ks * 32 + 4);
+        }
+        if (p.kscale) {
+          const float4 k0 = *reinterpret_cast<const float4*>(s_ks + ks * 32 + fq * 8), k1 = *reinterpret_cast<const float4*>(s_ks + ks * 32 + fq * 8 + 4);
+          a.x *= k0.x; a.y *= k0.y; a.z *= k0.z; a.w *= k0.w;
+          b.x *= k1.x; b.y *= k1.y; b.z *= k1.z; b.w *= k1.w;
+        }
+        uint4 x0, x1;
+        s1_split8(a, b, sx, x0, x1);
+        uint4 w0[FH], w1[FH];
+#pragma unroll
+        for (int f = 0; f < FH; ++f) {
+          const unsigned char* wp = s1_smem + (f * 16 + fr) * PITCH + ks * 64 + fq * 16;
+          w0[f] = *reinterpret_cast<const uint4*>(wp);
+          w1[f] = *reinterpret_cast<const uint4*>(wp + NC * PITCH);
+        }
+#pragma unroll
+        for (int f = 0; f < FH; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w1[f]), __builtin_bit_cast(f16x8, x0), acc[f]);
+#pragma unroll
+        for (int f = 0; f < FH; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x1), acc[f]);
+#pragma unroll
+        for (int f = 0; f < FH; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x0), acc[f]);
+        __builtin_amdgcn_sched_barrier(0);            // (keeps later K steps' work from being hoisted: register pressure)
+      }
+#pragma unroll
+      for (int f = 0; f < FH; ++f) finish(acc[f], f, ad[f], mk[f], row, ok);
+    }
+  } else
   for (; strip < nstrips; strip += gstride) {
     uint4 x0[KS], x1[KS];
 #pragma unroll
@@ -1393,19 +1461,7 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
       }
 #pragma unroll
       for (int f = 0; f < FH; ++f) {
-        const int n = n0 + (half + f) * 16 + 4 * fq;
-        float4 v = make_float4(acc[f][0] * inv, acc[f][1] * inv, acc[f][2] * inv, acc[f][3] * inv);
-        if (p.scale) { const float4 s4 = *reinterpret_cast<const float4*>(s_sc + (n - n0)); v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
-        if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(s_bi + (n - n0)); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-        if (adp) { v.x += ad[f].x; v.y += ad[f].y; v.z += ad[f].z; v.w += ad[f].w; }
-        if (both) { const float4 a2 = ldg4(p.y + row * p.ldy + n); v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w; }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (p.mask8 && n >= p.mask_c0) relu_mask8(v, mk[f]);
-        if (ok) {
-          *reinterpret_cast<float4*>(p.y + row * p.ldy + n) = v;
-          if (p.mask8_out && p.relu) p.mask8_out[row * p.ldm8_out + (n >> 2)] = relu_bits(v);
-          ymax = amax_f4(ymax, v);
-        }
+        finish(acc[f], half + f, ad[f], mk[f], row, ok);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1418,14 +1474,17 @@ static int stream1x1_nc(const ConvArgs& a) {
   if (!on || conv_mfma_mode() != 2 || a.nseg > 0 || a.plane_rows || a.KH != 1 || a.KW != 1 || a.upshift || a.dst_up || a.par ||
       a.tprefix || a.mul != 1 || a.off0 != 0 || a.M < min_m)
     return 0;
-  if (a.Kc != 64 && a.Kc != 128 && a.Kc != 256) return 0;
+  static const int k512 = env_int("EOSVOS_TUNE_STREAM1X1_K512", 1), n48 = env_int("EOSVOS_TUNE_STREAM1X1_N48", 1);
+  if (a.Kc != 64 && a.Kc != 128 && a.Kc != 256 && !(a.Kc == 512 && k512)) return 0;
   if (a.mask && !a.mask8) return 0;                   // (the fp32-mask form stays with the tiled kernel)
   if ((a.mask_c0 & 15) || (a.ldx & 3) || (a.ldy & 3) || (a.N & 15)) return 0;
   if (a.Hi != a.Ho || a.Wi != a.Wo) return 0;
   static const int nc256 = env_int("EOSVOS_TUNE_STREAM1X1_NC256", 0);     // experiment: whole 256-channel rows per workgroup
+  if (a.Kc == 512) return a.N % 64 == 0 && a.N <= 128 ? 64 : 0;     // (weights of 64 channels x 512: 133 KB of LDS)
   if (nc256 && a.N % 256 == 0 && a.Kc <= 128) return 256;
   if (a.N % 128 == 0) return 128;
   if (a.N == 64) return 64;
+  if (a.N == 48 && n48 && a.Kc == 256) return 48;
   return 0;
 }
 template <int K, int NC>
@@ -1945,10 +2004,13 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
       if (a.Kc == 64) launch_stream1x1<64, 128>(a, s);
       else if (a.Kc == 128) launch_stream1x1<128, 128>(a, s);
       else launch_stream1x1<256, 128>(a, s);
+    } else if (nc == 48) {
+      launch_stream1x1<256, 48>(a, s);
     } else {
       if (a.Kc == 64) launch_stream1x1<64, 64>(a, s);
       else if (a.Kc == 128) launch_stream1x1<128, 64>(a, s);
-      else launch_stream1x1<256, 64>(a, s);
+      else if (a.Kc == 256) launch_stream1x1<256, 64>(a, s);
+      else launch_stream1x1<512, 64>(a, s);
     }
     return;
   }

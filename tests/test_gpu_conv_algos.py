@@ -116,8 +116,9 @@ STRIDED_CASES = [          # (B, H, W, Cin, Cout, k, stride, dil, pad): the non-
     (3, 120, 214, 64, 256, 1, 1, 1, 0),           # layer1 conv3 / downsample (fwd K 64, N 256; dgrad K 256, N 64)
     (3, 120, 214, 256, 64, 1, 1, 1, 0),           # layer1 conv1 of blocks 1, 2
     (1, 120, 214, 64, 64, 1, 1, 1, 0),            # layer1.0.conv1 at batch 1 (25 680 pixels: a ragged last strip)
-    (3, 60, 107, 128, 512, 1, 1, 1, 0),           # layer2 conv3 (19 260 pixels, 4 column ranges)
+    (3, 60, 107, 128, 512, 1, 1, 1, 0),           # layer2 conv3 (19 260 pixels, 4 column ranges; data gradient K = 512)
     (3, 120, 214, 256, 128, 1, 1, 1, 0),          # layer2.0.conv1
+    (3, 60, 107, 512, 128, 1, 1, 1, 0),           # layer2 conv1 of blocks 1-3: K = 512 (K-outer form, 64-channel ranges)
 ]
 
 

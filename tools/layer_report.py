@@ -12,7 +12,7 @@ from collections import defaultdict
 def main(trace_csv, log, steps=3):
     rows = [r for r in csv.DictReader(open(trace_csv))]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    is_conv = lambda n: any(k in n for k in ('conv_igemm_kernel', 'conv_x6_kernel', 'conv_h3_kernel', 'conv_h3_multi_kernel', 'conv_x6_multi_kernel'))
+    is_conv = lambda n: any(k in n for k in ('conv_igemm_kernel', 'conv_x6_kernel', 'conv_h3_kernel', 'conv_h3_multi_kernel', 'conv_x6_multi_kernel', 'conv1x1_stream_kernel'))
     mf = [r for r in rows if is_conv(r['Kernel_Name']) or 'wgrad_kernel<' in r['Kernel_Name'] or 'wgrad_x6_kernel<' in r['Kernel_Name'] or 'wgrad_x6_group_kernel<' in r['Kernel_Name'] or 'wgrad_h3_kernel<' in r['Kernel_Name'] or 'wgrad_h3_group_kernel<' in r['Kernel_Name']]
     # fix-up launch that follows a conv launch (same stream order)
     for i, r in enumerate(rows):
@@ -39,7 +39,7 @@ def main(trace_csv, log, steps=3):
             d = int(mf[i]['End_Timestamp']) - int(mf[i]['Start_Timestamp'])
             a = agg[(i - s, k, ci)]
             fixt[(i - s, k, ci)] += mf[i].get('fix_ns', 0)
-            a[0] += d; a[1] += fl; a[2] += 1; a[3] = (M, N, K, sp, int(mf[i]['Grid_Size_X']) // 256)
+            a[0] += d; a[1] += fl; a[2] += 1; a[3] = (M, N, K, sp, int(mf[i]['Grid_Size_X']) // int(mf[i].get('Workgroup_Size_X') or 256))
     tot_t = tot_f = 0
     by_kind = defaultdict(lambda: [0.0, 0.0])
     print(f'{"#":>3} {"kind":6} {"conv":>4} {"M":>7} {"N":>6} {"K":>6} {"spl":>3} {"WGs":>5} {"us":>8} {"TF/s":>6} {"excess_us@200":>13} {"fixup":>7}')

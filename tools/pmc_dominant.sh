@@ -17,6 +17,9 @@ sys.path.insert(0, '.')
 from eosvos_amd import _ffi
 tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
 dur = []
+# the other symbols that take a similar share of the step (which one is 'dominant' flips between runs): their traffic too
+OTHERS = [k for k in ('conv_h3_kernel<128, true>', 'conv_h3_kernel<128, false>', 'wgrad_h3_kernel<128, 128>') if k != K]
+otot = {k: collections.defaultdict(float) for k in OTHERS}; ocnt = {k: collections.defaultdict(int) for k in OTHERS}
 for p in ('fetch', 'write', 'sq1', 'sq2', 'grbm'):
     fs = glob.glob(f'{O}/pmc/{p}/**/*counter_collection.csv', recursive=True)
     if not fs:
@@ -24,6 +27,10 @@ for p in ('fetch', 'write', 'sq1', 'sq2', 'grbm'):
     for r in csv.DictReader(open(fs[0])):
         if K in r['Kernel_Name']:
             tot[r['Counter_Name']] += float(r['Counter_Value']); cnt[r['Counter_Name']] += 1
+        if p in ('fetch', 'write'):
+            for k in OTHERS:
+                if k in r['Kernel_Name']:
+                    otot[k][r['Counter_Name']] += float(r['Counter_Value']); ocnt[k][r['Counter_Name']] += 1
     if p == 'grbm':
         for r in csv.DictReader(open(glob.glob(f'{O}/pmc/{p}/**/*kernel_trace.csv', recursive=True)[0])):
             if K in r['Kernel_Name']:
@@ -38,6 +45,12 @@ out = {'kernel': K, 'batch': B, 'lib_version': _ffi.load().eosvos_version().deco
        'note': 'average over every launch of this kernel symbol in tools/step_profile.py (6 steps): 2 x FETCH_SIZE (gfx950 '
                'half-count correction) + WRITE_SIZE, separate rocprofv3 --pmc passes',
        'counters_avg_per_launch': avg,
+       'others': [{'kernel': k, 'launches_profiled': ocnt[k].get('FETCH_SIZE', 0),
+                   'fetch_kb_per_launch': otot[k]['FETCH_SIZE'] / max(1, ocnt[k]['FETCH_SIZE']),
+                   'write_kb_per_launch': otot[k]['WRITE_SIZE'] / max(1, ocnt[k]['WRITE_SIZE']),
+                   'traffic_bytes_per_launch': (2 * otot[k]['FETCH_SIZE'] / max(1, ocnt[k]['FETCH_SIZE'])
+                                                + otot[k]['WRITE_SIZE'] / max(1, ocnt[k]['WRITE_SIZE'])) * 1024}
+                  for k in OTHERS if ocnt[k].get('FETCH_SIZE', 0)],
        'avg_launch_us_under_pmc': (sum(dur) / len(dur) / 1e3) if dur else None}
 json.dump(out, open(f'{O}/pmc_dominant_kernel.json', 'w'), indent=1)
 with open(f'{O}/pmc_dominant_kernel.txt', 'w') as f:
@@ -49,6 +62,9 @@ with open(f'{O}/pmc_dominant_kernel.txt', 'w') as f:
         cyc = avg['GRBM_GUI_ACTIVE'] / 8
         f.write(f'  MFMA-busy: {avg["SQ_INSTS_MFMA"] * 16 / 1024 / cyc * 100:.1f} % of {cyc:.0f} cycles per launch (16 cycles per v_mfma_f32_16x16x32_f16 or _bf16, 1024 SIMDs) '
                 f'(effective clock {cyc / (sum(dur) / len(dur)) :.2f} GHz)\n')
+with open(f'{O}/pmc_dominant_kernel.txt', 'a') as f:
+    for o in out['others']:
+        f.write(f"  also: {o['kernel']!r}, {o['launches_profiled']} launches: 2*FETCH_SIZE + WRITE_SIZE = {o['traffic_bytes_per_launch'] / 1e6:.1f} MB per launch\n")
 print(open(f'{O}/pmc_dominant_kernel.txt').read())
 PY
 rm -rf $O/pmc

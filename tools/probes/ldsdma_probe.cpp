@@ -263,6 +263,197 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const float* __restric
       }
 }
 
+
+// ---- PRE-SPLIT operands: the two fp16 pieces already lie in global memory ([piece][row][K] halves), LDS-DMA staging, no VALU
+// work in the K loop at all.  LDS stage = per operand 2 pieces x 128 rows x 64 B = 16 KB.  A DMA instruction moves 16 rows x
+// 64 B of one piece (lane l -> row l / 4, LDS granule l % 4); LDS granule g' of row r holds k granule g' ^ ((r >> 2) & 3): the
+// 16 rows of a fragment read (same k granule) then cover 16 distinct 16-byte slots of a 256-byte bank row.
+__device__ __forceinline__ void glds16h(const _Float16* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int STAGES, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_pre_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B,
+                                                            float* __restrict__ C, int M, int N, int K, float inv) {
+  constexpr int BM = 128, BN = 128, BK = 32, ROWB = BK * 2;          // 64-byte rows per piece
+  constexpr int PIECE = BM * ROWB, OP = 2 * PIECE, STAGE = 2 * OP;    // 8 KB, 16 KB, 32 KB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  // DMA roles: instruction j (0..3) of this wave: piece j & 1, rows 64 * (j >> 1) + 16 * wave .. + 15 of each operand
+  const int drow = lane >> 2, dg = lane & 3;
+  const _Float16* asrc[4];
+  const _Float16* bsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 64 * (j >> 1) + 16 * wave + drow;
+    const int gk = dg ^ ((row >> 2) & 3);
+    asrc[j] = A + (size_t)(j & 1) * M * K + (size_t)(m0 + row) * K + gk * 8;
+    bsrc[j] = B + (size_t)(j & 1) * N * K + (size_t)(n0 + row) * K + gk * 8;
+  }
+  const unsigned lds0 = lds_addr(smem);
+  auto issue = [&](int ks, int buf) {
+    const unsigned sA = lds0 + buf * STAGE, sB = sA + OP;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned chunk = (unsigned)((j & 1) * PIECE + (64 * (j >> 1) + 16 * wave) * ROWB);
+      glds16h(asrc[j] + ks * BK, __builtin_amdgcn_readfirstlane(sA + chunk));
+      glds16h(bsrc[j] + ks * BK, __builtin_amdgcn_readfirstlane(sB + chunk));
+    }
+  };
+  const int nk = K / BK;
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ra_ = wm * 64 + t * 16 + r, rb_ = wn * 64 + t * 16 + r;
+    aoff[t] = ra_ * ROWB + ((q ^ ((ra_ >> 2) & 3)) << 4);
+    boff[t] = rb_ * ROWB + ((q ^ ((rb_ >> 2) & 3)) << 4);
+  }
+  for (int ks = 0; ks < nk; ++ks) {
+    if (ks + STAGES - 2 < nk) wait_vm<8 * (STAGES - 2)>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ks + STAGES - 1 < nk) issue(ks + STAGES - 1, (ks + STAGES - 1) % STAGES);
+    const unsigned char* sA = smem + (ks % STAGES) * STAGE;
+    const unsigned char* sB = sA + OP;
+    uint4 fa[4][2], fb[4][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t][p] = *reinterpret_cast<const uint4*>(sA + p * PIECE + aoff[t]);
+        fb[t][p] = *reinterpret_cast<const uint4*>(sB + p * PIECE + boff[t]);
+      }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        f32x4 c = acc[tm][tn];
+        MH(fa[tm][1], fb[tn][0], c); MH(fa[tm][0], fb[tn][1], c); MH(fa[tm][0], fb[tn][0], c);
+        acc[tm][tn] = c;
+      }
+    __builtin_amdgcn_s_setprio(0);
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + tm * 16 + 4 * q + e;
+        const int n = n0 + wn * 64 + tn * 16 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e] * inv;
+      }
+}
+// pre-split operands, register staging (global -> VGPR -> ds_write_b128 -> barrier): what the split itself costs
+__global__ __launch_bounds__(256, 2) void gemm_pre_reg_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B,
+                                                              float* __restrict__ C, int M, int N, int K, float inv) {
+  constexpr int BM = 128, BN = 128, BK = 32, PITCH = 96, NP = 2;
+  constexpr int OP_BYTES = NP * BM * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP_BYTES];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + OP_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  // a thread moves 16 bytes (8 k) of 2 rows x 2 pieces per operand: granule tid & 3, row (tid >> 2) + 64 i
+  const int g = tid & 3, row = tid >> 2;
+  uint4 ra[2][2], rb[2][2];
+  auto load = [&](int ks) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ra[p][i] = *reinterpret_cast<const uint4*>(A + (size_t)p * M * K + (size_t)(m0 + row + 64 * i) * K + ks * BK + g * 8);
+        rb[p][i] = *reinterpret_cast<const uint4*>(B + (size_t)p * N * K + (size_t)(n0 + row + 64 * i) * K + ks * BK + g * 8);
+      }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<uint4*>(As + p * BM * PITCH + (row + 64 * i) * PITCH + g * 16) = ra[p][i];
+        *reinterpret_cast<uint4*>(Bs + p * BM * PITCH + (row + 64 * i) * PITCH + g * 16) = rb[p][i];
+      }
+  };
+  const int nk = K / BK;
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+  load(0);
+  store();
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) load(ks + 1);
+    __builtin_amdgcn_s_setprio(1);
+    uint4 fa[4][NP], fb[4][NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t][p] = *reinterpret_cast<const uint4*>(As + p * BM * PITCH + (wm * 64 + t * 16 + r) * PITCH + q * 16);
+        fb[t][p] = *reinterpret_cast<const uint4*>(Bs + p * BM * PITCH + (wn * 64 + t * 16 + r) * PITCH + q * 16);
+      }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        f32x4 c = acc[tm][tn];
+        MH(fa[tm][1], fb[tn][0], c); MH(fa[tm][0], fb[tn][1], c); MH(fa[tm][0], fb[tn][0], c);
+        acc[tm][tn] = c;
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (more) store();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + tm * 16 + 4 * q + e;
+        const int n = n0 + wn * 64 + tn * 16 + r;
+        C[(size_t)m * N + n] = acc[tm][tn][e] * inv;
+      }
+}
+static void host_split(const std::vector<float>& v, float s, std::vector<_Float16>& out) {
+  const size_t n = v.size();
+  out.resize(2 * n);
+  for (size_t i = 0; i < n; ++i) {
+    const float x = v[i] * s;
+    const _Float16 h = (_Float16)x;
+    out[i] = h;
+    out[n + i] = (_Float16)(x - (float)h);
+  }
+}
+
 static float pow2_scale(const std::vector<float>& v) {
   float mx = 0.f;
   for (float x : v) mx = std::fmax(mx, std::fabs(x));
@@ -299,7 +490,7 @@ static void run(const char* name, F launch, float* dC, int M, int N, int K, cons
   float ms = 0.f;
   CK(hipEventElapsedTime(&ms, a, b));
   ms /= reps;
-  printf("  %-34s %8.1f us  %7.1f TFLOP/s   max err / sum|ab| %.2e  rms %.2e\n", name, 1e3 * ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, worst,
+  printf("  %-38s %8.1f us  %7.1f TFLOP/s   max err / sum|ab| %.2e  rms %.2e\n", name, 1e3 * ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, worst,
          std::sqrt(sq / cnt));
   CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
 }
@@ -324,6 +515,20 @@ int main() {
     run("LDS-DMA 2 stages, 2 WG/CU", [&] { hipLaunchKernelGGL((gemm_dma_kernel<2, 2>), grid, block, 0, 0, dA, dB, dC, M, N, K, sa, sb); }, dC, M, N, K, hA, hB);
     run("LDS-DMA 3 stages, 1 WG/CU", [&] { hipLaunchKernelGGL((gemm_dma_kernel<3, 1>), grid, block, 0, 0, dA, dB, dC, M, N, K, sa, sb); }, dC, M, N, K, hA, hB);
     run("LDS-DMA 4 stages, 1 WG/CU", [&] { hipLaunchKernelGGL((gemm_dma_kernel<4, 1>), grid, block, 0, 0, dA, dB, dC, M, N, K, sa, sb); }, dC, M, N, K, hA, hB);
+    {
+      std::vector<_Float16> pA, pB;
+      host_split(hA, sa, pA); host_split(hB, sb, pB);
+      _Float16 *dpA, *dpB;
+      CK(hipMalloc(&dpA, pA.size() * 2)); CK(hipMalloc(&dpB, pB.size() * 2));
+      CK(hipMemcpy(dpA, pA.data(), pA.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dpB, pB.data(), pB.size() * 2, hipMemcpyHostToDevice));
+      const float inv = 1.f / (sa * sb);
+      run("pre-split, register staging", [&] { hipLaunchKernelGGL(gemm_pre_reg_kernel, grid, block, 0, 0, dpA, dpB, dC, M, N, K, inv); }, dC, M, N, K, hA, hB);
+      run("pre-split, LDS-DMA 2 stages, 2 WG/CU", [&] { hipLaunchKernelGGL((gemm_pre_kernel<2, 2>), grid, block, 0, 0, dpA, dpB, dC, M, N, K, inv); }, dC, M, N, K, hA, hB);
+      run("pre-split, LDS-DMA 3 stages, 1 WG/CU", [&] { hipLaunchKernelGGL((gemm_pre_kernel<3, 1>), grid, block, 0, 0, dpA, dpB, dC, M, N, K, inv); }, dC, M, N, K, hA, hB);
+      run("pre-split, LDS-DMA 4 stages, 1 WG/CU", [&] { hipLaunchKernelGGL((gemm_pre_kernel<4, 1>), grid, block, 0, 0, dpA, dpB, dC, M, N, K, inv); }, dC, M, N, K, hA, hB);
+      CK(hipFree(dpA)); CK(hipFree(dpB));
+    }
     run("register staging (again)", [&] { hipLaunchKernelGGL(gemm_reg_kernel, grid, block, 0, 0, dA, dB, dC, M, N, K, sa, sb); }, dC, M, N, K, hA, hB);
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
   }
