@@ -91,6 +91,32 @@ def test_bench_gpus_flag_must_match_the_world_size(tmp_path):
     assert p.returncode != 0 and 'WORLD_SIZE=1' in p.stderr and p.stdout.strip() == ''
 
 
+def test_bench_traffic_lookup_covers_every_leading_kernel_symbol(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from the committed PMC passes; three kernel symbols take a similar share of the step and which
+    one leads flips between runs, so the artifact records all of them (`others`) and the lookup must find each -- and must
+    answer None with a reason for another library version, batch or symbol."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(os.path.dirname(HERE), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    art = {'kernel': 'wgrad_h3_kernel<128, 128>', 'batch': 3, 'lib_version': 'v', 'traffic_bytes_per_launch': 1.0, 'note': 'n',
+           'others': [{'kernel': 'conv_h3_kernel<128, true>', 'traffic_bytes_per_launch': 2.0},
+                      {'kernel': 'conv_h3_kernel<128, false>', 'traffic_bytes_per_launch': 3.0}]}
+    path = tmp_path / 'pmc.json'
+    path.write_text(json.dumps(art))
+    monkeypatch.setattr(bench, 'PMC_FILES', [str(tmp_path / 'missing.json'), str(path)])
+    assert bench.pmc_traffic('wgrad_h3_kernel<128, 128>', 'v', 3) == (1.0, 'n')
+    assert bench.pmc_traffic('conv_h3_kernel<128, true>', 'v', 3) == (2.0, 'n')
+    assert bench.pmc_traffic('conv_h3_kernel<128, false>', 'v', 3) == (3.0, 'n')
+    for args in (('conv_h3_kernel<64, true>', 'v', 3), ('wgrad_h3_kernel<128, 128>', 'w', 3), ('wgrad_h3_kernel<128, 128>', 'v', 1)):
+        t, why = bench.pmc_traffic(*args)
+        assert t is None and 'PMC artifact is for' in why
+    # the committed artifact of this round is well-formed
+    real = json.load(open(os.path.join(os.path.dirname(HERE), 'profiles', 'r04_pmc_dominant_kernel.json')))
+    assert real['traffic_bytes_per_launch'] > 0 and all(o['traffic_bytes_per_launch'] > 0 for o in real.get('others', []))
+
+
 def test_evaluation_sharded_over_ranks_equals_single_process(tmp_path):
     out2, out1 = str(tmp_path / 'e2'), str(tmp_path / 'e1')
     launch('eval_shard_worker.py', [out2, str(tmp_path / 's2')], 2, 29547)
