@@ -1929,7 +1929,14 @@ int conv_plan(ConvArgs& a) {
   } else if (tiles >= nwg && a.total_units <= 0) {
     q = tiles / nwg;
     const long rem = tiles - q * nwg;
-    if (rem > 0) {
+    // a leftover that nearly fills another round: whole tiles for it too (q + 1 per workgroup, fewer workgroups) -- the
+    // streamed form parks two slabs per workgroup and needs the fix-up pass (batch-1 decoder: 936 tiles = 512 + 424 streamed,
+    // fix-up 17 us; as 468 workgroups x 2 whole tiles none)
+    static const int rem_whole = env_int("EOSVOS_TUNE_REM_WHOLE", 1);      // percent of the budget from which on; 0 = never
+    if (rem > 0 && rem_whole > 0 && rem * 100 >= (long)rem_whole * nwg) {
+      q = q + 1; per = 0;
+      nwg = (tiles + q - 1) / q;
+    } else if (rem > 0) {
       per = (rem * ksteps + nwg - 1) / nwg;
       if (per < 2) {                                   // tiny K: whole tiles only
         // EOSVOS_TUNE_TINYK_ONE_TILE: one workgroup per tile (more workgroups than resident slots: the dispatcher refills a
