@@ -1501,6 +1501,256 @@ static void launch_stream1x1(const ConvArgs& a, hipStream_t s) {
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Stem (7x7 stride-2 conv, 3 -> 64, on the 3-pixel zero-padded NHWC3 frame) on the fp16 matrix cores, f16x3 mode.
+// Same structure as the streaming 1x1 kernel: the whole 64 x 147 weight panel lives in LDS as its two fp16 pieces (split
+// once per workgroup; its absmax is taken while it is staged), each wave streams strips of 16 output pixels, D = W_frag *
+// patch_frag^T, so a lane ends with 4 consecutive channels of one pixel.  K order: 24 slots of 8 values, slot s = 3 ky + part
+// holds floats [8 part, 8 part + 8) of the 21-float patch row ky (floats 21 ... 23 of a row belong to the next pixel and meet
+// zero weights; slots 21 ... 23 are not loaded): a lane's 8 k values are 32 contiguous, 8-byte aligned bytes of the frame.
+// The VALU kernel (misc_kernels.hip) took 93 us at batch 3 -- 5.8 GFLOP of fp32 FMAs; the output (79 MB) bounds this one.
+// ---------------------------------------------------------------------------------------
+#define STEM_SLOTS 24
+#define STEM_PITCH (STEM_SLOTS * 16 + 16)
+__global__ __launch_bounds__(512) void stem_fwd_h3_kernel(const float* __restrict__ xpad, const float* __restrict__ w,
+                                                          const float* __restrict__ a, const float* __restrict__ bb,
+                                                          float* __restrict__ y, int B, int H, int W, int Ho, int Wo,
+                                                          const unsigned* __restrict__ amax_x) {
+  __shared__ __attribute__((aligned(16))) unsigned char sw_[2 * 64 * STEM_PITCH];
+  __shared__ float s_a[64], s_b[64];
+  __shared__ unsigned s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- weights: 64 rows x 24 slots, three slots per thread; absmax, then the split ----
+  float wv[3][8];
+  unsigned wm = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int i = tid + q * 512, r = i / STEM_SLOTS, sl = i % STEM_SLOTS;
+    const int ky = sl / 3, part = sl % 3;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int j = part * 8 + t;
+      const float v = (sl < 21 && j < 21) ? w[r * 147 + ky * 21 + j] : 0.f;
+      wv[q][t] = v;
+      const unsigned b = amax_f1(v);
+      wm = wm > b ? wm : b;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)wm, o);
+    wm = wm > t ? wm : t;
+  }
+  if (lane == 0) s_red[wave] = wm;
+  if (tid < 64) { s_a[tid] = a ? a[tid] : 1.f; s_b[tid] = bb ? bb[tid] : 0.f; }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wm = wm > s_red[i] ? wm : s_red[i];
+  float sw, iw;
+  {
+    const int e = (int)((wm >> 23) & 0xffu);
+    int f = 268 - e;
+    f = f < 1 ? 1 : (f > 254 ? 254 : f);
+    iw = __uint_as_float((unsigned)(254 - f) << 23);
+    sw = __uint_as_float((unsigned)f << 23);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int i = tid + q * 512, r = i / STEM_SLOTS, sl = i % STEM_SLOTS;
+    uint4 h0, h1;
+    s1_split8(make_float4(wv[q][0], wv[q][1], wv[q][2], wv[q][3]), make_float4(wv[q][4], wv[q][5], wv[q][6], wv[q][7]), sw, h0, h1);
+    *reinterpret_cast<uint4*>(sw_ + r * STEM_PITCH + sl * 16) = h0;
+    *reinterpret_cast<uint4*>(sw_ + 64 * STEM_PITCH + r * STEM_PITCH + sl * 16) = h1;
+  }
+  float ix;
+  const float sx = h3_scale(amax_x, nullptr, ix);
+  const float inv = ix * iw;
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  const int Wp = W + 6, Hp = H + 6;
+  const long P = (long)B * Ho * Wo;
+  const long nstrips = (P + 15) / 16;
+  // this lane's slot of each K step: offset inside the frame relative to the pixel's patch origin; < 0: an empty slot
+  int koff[6];
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) {
+    const int sl = ks * 4 + fq;
+    koff[ks] = sl < 21 ? (sl / 3) * Wp * 3 + (sl % 3) * 8 : -1;
+  }
+  float2 xr[6][4];
+  auto load_x = [&](long strip) {
+    long pp = strip * 16 + fr;
+    pp = pp < P ? pp : P - 1;
+    const int ox = (int)(pp % Wo), oy = (int)((pp / Wo) % Ho), b = (int)(pp / ((long)Wo * Ho));
+    const float* base = xpad + (((long)b * Hp + oy * 2) * Wp + ox * 2) * 3;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      if (koff[ks] >= 0) {
+        const float2* q = reinterpret_cast<const float2*>(base + koff[ks]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xr[ks][t] = q[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xr[ks][t] = make_float2(0.f, 0.f);
+      }
+    }
+  };
+  const long gw = (long)blockIdx.x * 8 + wave, gstride = (long)gridDim.x * 8;
+  long strip = gw;
+  if (strip < nstrips) load_x(strip);
+  for (; strip < nstrips; strip += gstride) {
+    uint4 x0[6], x1[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+      s1_split8(make_float4(xr[ks][0].x, xr[ks][0].y, xr[ks][1].x, xr[ks][1].y), make_float4(xr[ks][2].x, xr[ks][2].y, xr[ks][3].x, xr[ks][3].y),
+                sx, x0[ks], x1[ks]);
+    if (strip + gstride < nstrips) load_x(strip + gstride);
+    const long pp = strip * 16 + fr;
+    const bool ok = pp < P;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const unsigned char* wp = sw_ + (f * 16 + fr) * STEM_PITCH + ks * 64 + fq * 16;
+        const uint4 w0 = *reinterpret_cast<const uint4*>(wp);
+        const uint4 w1 = *reinterpret_cast<const uint4*>(wp + 64 * STEM_PITCH);
+        acc = MFMA_F16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, x0[ks]), acc);
+        acc = MFMA_F16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, x1[ks]), acc);
+        acc = MFMA_F16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, x0[ks]), acc);
+      }
+      const int n = f * 16 + 4 * fq;
+      float4 v = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+      if (a) {
+        const float4 a4 = *reinterpret_cast<const float4*>(s_a + n), b4 = *reinterpret_cast<const float4*>(s_b + n);
+        v.x = fmaxf(v.x * a4.x + b4.x, 0.f); v.y = fmaxf(v.y * a4.y + b4.y, 0.f);
+        v.z = fmaxf(v.z * a4.z + b4.z, 0.f); v.w = fmaxf(v.w * a4.w + b4.w, 0.f);
+      }
+      if (ok) *reinterpret_cast<float4*>(y + pp * 64 + n) = v;
+      __builtin_amdgcn_sched_barrier(0);            // (keeps the next fragments' weight reads from being hoisted: registers)
+    }
+  }
+}
+void launch_stem_fwd_h3(const float* xpad, const float* w, const float* a, const float* b, float* y, int B, int H, int W, int Ho,
+                        int Wo, const unsigned* amax_x, hipStream_t s) {
+  hipLaunchKernelGGL(stem_fwd_h3_kernel, dim3(256), dim3(512), 0, s, xpad, w, a, b, y, B, H, W, Ho, Wo, amax_x);
+}
+
+// Stem weight gradient on the fp16 matrix cores (f16x3): dW[64][147] = sum_p G[p][64]^T * patch[p][147], one [64][147] slab
+// per workgroup (a chunk of the output pixels), summed by the update kernel like every other layer's slabs.  Per 32-pixel K
+// step: G rows come in as float4 (a thread owns 2 pixels x 4 channels and packs along the pixels), the 7 x 21 patch of every
+// pixel by one thread per patch element, which walks the 32 pixels with scalar loads and owns their 64 contiguous bytes of
+// its LDS row; wave w multiplies channels [16 w, 16 w + 16) with all ten 16-wide fragments of the (147 -> 160) patch rows.
+__global__ __launch_bounds__(256, 2) void stem_wgrad_h3_kernel(const float* __restrict__ xpad, const float* __restrict__ g,
+                                                               float* __restrict__ ws, int B, int H, int W, int Ho, int Wo,
+                                                               int chunks, const unsigned* __restrict__ amax_g,
+                                                               const unsigned* __restrict__ amax_x) {
+  constexpr int KR = 160;                               // patch rows (147 padded to ten fragments)
+  __shared__ __attribute__((aligned(16))) unsigned char As[2 * 64 * X6_ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * KR * X6_ROWB];
+  const long P = (long)B * Ho * Wo;
+  const long per = ((P + chunks - 1) / chunks + 31) / 32 * 32;
+  const long p0 = (long)blockIdx.x * per;
+  long p1 = p0 + per;
+  if (p1 > P) p1 = P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int Wp = W + 6, Hp = H + 6;
+  const int k = tid;                                    // B staging: one thread per patch element k
+  const int koff = k < 147 ? (k / 21) * Wp * 3 + (k % 21) : 0;
+  const int a_cg = tid & 15, a_pg = tid >> 4;           // A staging: channels [4 a_cg, + 4) of pixels 2 a_pg, 2 a_pg + 1
+  float ig, ix;
+  const float sg = h3_scale(amax_g, nullptr, ig), sx = h3_scale(amax_x, nullptr, ix);
+  f32x4 acc[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // rows 147 ... 159 of both pieces stay zero
+  for (int i = tid; i < 2 * (KR - 147) * (X6_ROWB / 4); i += 256) {
+    const int pc = i / ((KR - 147) * (X6_ROWB / 4)), rem = i % ((KR - 147) * (X6_ROWB / 4));
+    *reinterpret_cast<unsigned*>(Bs + (pc * KR + 147) * X6_ROWB + rem * 4) = 0u;
+  }
+  const int nsteps = p1 > p0 ? (int)((p1 - p0 + 31) / 32) : 0;
+  float4 ra[2];
+  float rb[32];
+  auto load_step = [&](int st) {
+    const long ps = p0 + (long)st * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long px = ps + a_pg * 2 + i;
+      ra[i] = px < p1 ? ldg4(g + px * 64 + a_cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (k < 147) {
+      int ox = (int)(ps % Wo), oy = (int)((ps / Wo) % Ho), b = (int)(ps / ((long)Wo * Ho));
+      long base = (((long)b * Hp + oy * 2) * Wp + ox * 2) * 3 + koff;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        rb[i] = (ps + i) < p1 ? xpad[base] : 0.f;
+        base += 6;
+        if (++ox == Wo) {
+          ox = 0;
+          base += (long)(2 * Wp - 2 * Wo) * 3;
+          if (++oy == Ho) { oy = 0; base += (long)(Hp - 2 * Ho) * Wp * 3; }
+        }
+      }
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // channel 4 a_cg + j: the two pixels' values as one fp16 pair per piece
+      unsigned pc[2];
+      xs_split2<2>(f4c(ra[0], j), f4c(ra[1], j), sg, pc);
+      *reinterpret_cast<unsigned*>(As + (a_cg * 4 + j) * X6_ROWB + a_pg * 4) = pc[0];
+      *reinterpret_cast<unsigned*>(As + (64 + a_cg * 4 + j) * X6_ROWB + a_pg * 4) = pc[1];
+    }
+    if (k < 147) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint4 h0, h1;
+        s1_split8(make_float4(rb[8 * q], rb[8 * q + 1], rb[8 * q + 2], rb[8 * q + 3]),
+                  make_float4(rb[8 * q + 4], rb[8 * q + 5], rb[8 * q + 6], rb[8 * q + 7]), sx, h0, h1);
+        *reinterpret_cast<uint4*>(Bs + k * X6_ROWB + q * 16) = h0;
+        *reinterpret_cast<uint4*>(Bs + (KR + k) * X6_ROWB + q * 16) = h1;
+      }
+    }
+  };
+  if (nsteps > 0) load_step(0);
+  __syncthreads();
+  if (nsteps > 0) store_step();
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const bool more = st + 1 < nsteps;
+    if (more) load_step(st + 1);
+    const uint4 a0 = *reinterpret_cast<const uint4*>(As + (wave * 16 + fr) * X6_ROWB + fq * 16);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(As + (64 + wave * 16 + fr) * X6_ROWB + fq * 16);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const uint4 b0 = *reinterpret_cast<const uint4*>(Bs + (j * 16 + fr) * X6_ROWB + fq * 16);
+      const uint4 b1 = *reinterpret_cast<const uint4*>(Bs + (KR + j * 16 + fr) * X6_ROWB + fq * 16);
+      acc[j] = MFMA_F16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0), acc[j]);
+      acc[j] = MFMA_F16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1), acc[j]);
+      acc[j] = MFMA_F16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[j]);
+    }
+    __syncthreads();
+    if (more) store_step();
+    __syncthreads();
+  }
+  const float inv = ig * ix;
+  float* out = ws + (long)blockIdx.x * (64 * 147);
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const int kk = j * 16 + fr;
+    if (kk < 147) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[(wave * 16 + 4 * fq + e) * 147 + kk] = acc[j][e] * inv;
+    }
+  }
+}
+void launch_stem_wgrad_h3(const float* xpad, const float* g, float* ws, int B, int H, int W, int Ho, int Wo, int chunks,
+                          const unsigned* amax_g, const unsigned* amax_x, hipStream_t s) {
+  hipLaunchKernelGGL(stem_wgrad_h3_kernel, dim3(chunks), dim3(256), 0, s, xpad, g, ws, B, H, W, Ho, Wo, chunks, amax_g, amax_x);
+}
+
+
 // Weight gradient on the bf16 matrix cores: same split, both operands K-major (a pixel's channels are contiguous).
 template <int BMO, int BNI, int NP> constexpr int wgrad_xs_smem() { return xs_max(NP * (BMO + BNI) * X6_ROWB, BMO * (BNI + 4) * 4); }
 template <int BMO, int BNI, int NP = 3>

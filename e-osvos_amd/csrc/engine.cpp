@@ -1318,7 +1318,7 @@ int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, i
   ALLOC(e->Wp, t.nparam); ALLOC(e->Winit, t.nparam); ALLOC(e->Wsnap, t.nparam);
   ALLOC(e->gout, t.nparam); ALLOC(e->stage, t.nparam);
   ALLOC(e->lr, t.nlr); ALLOC(e->na, t.nnorm); ALLOC(e->nb, t.nnorm);
-  ALLOC(e->xpad, (int64_t)B * (H + 6) * (W + 6) * 3);
+  ALLOC(e->xpad, (int64_t)B * (H + 6) * (W + 6) * 3 + 8);      // + 8: the matrix-core stem reads whole 8-float slots (odd widths: 2 floats past a row)
   HIPOK(hipMemset(e->xpad, 0, (size_t)B * (H + 6) * (W + 6) * 3 * 4));
   HIPOK(hipMemset(e->Wp, 0, (size_t)t.nparam * 4));
   HIPOK(hipMemset(e->Winit, 0, (size_t)t.nparam * 4));
@@ -1709,13 +1709,20 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
       e->us_zero_epoch = e->fwd_epoch;
     }
   }
-  launch_nchw_to_nhwc_pad(images, e->xpad, B, 3, e->H, e->W, 3, s);
+  // f16x3 mode: the stem runs on the fp16 matrix cores too (the frame's absmax comes from the layout pass)
+  static const bool stem_h3_off = getenv("EOSVOS_TUNE_NO_STEM_H3") != nullptr;
+  unsigned* ax = (h3_mode() && !stem_h3_off) ? amax_fused_slot(e, AM_X, 0, e->xpad, s) : nullptr;
+  launch_nchw_to_nhwc_pad(images, e->xpad, B, 3, e->H, e->W, 3, s, ax);
+  auto stem_fwd = [&](const float* a, const float* b, float* y) {
+    if (ax) launch_stem_fwd_h3(e->xpad, e->W_(0), a, b, y, B, e->H, e->W, e->h2, e->w2, ax, s);
+    else launch_stem_fwd(e->xpad, e->W_(0), a, b, y, B, e->H, e->W, e->h2, e->w2, s);
+  };
   if (e->gn()) {
-    launch_stem_fwd(e->xpad, e->W_(0), nullptr, nullptr, e->zbuf[0], B, e->H, e->W, e->h2, e->w2, s);
+    stem_fwd(nullptr, nullptr, e->zbuf[0]);
     launch_gn_forward(e->zbuf[0], 64, e->G_(0), e->nb, nullptr, 0, e->c1, 64, e->gn_stats[0], e->gn_partial, B, e->h2 * e->w2, 64,
                       1e-5f, 1, s);
   } else {
-    launch_stem_fwd(e->xpad, e->W_(0), e->A_(0), e->B_(0), e->c1, B, e->H, e->W, e->h2, e->w2, s);
+    stem_fwd(e->A_(0), e->B_(0), e->c1);
   }
   launch_maxpool_fwd(e->c1, e->p1, e->p1idx, B, e->h2, e->w2, 64, e->h4, e->w4, s, twrite_fused(e, 0, e->p1, true));
   // independent forward branches go to the side stream (frozen-BN mode; the GroupNorm kernels share scratch)
@@ -1949,7 +1956,13 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     if (b.ds >= 0 && flush_wgrad_group(e, t.stage[b.c1], B)) return 1;
   }
   // stem
-  launch_maxpool_bwd(e->g_p1, e->p1idx, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s);
+  // f16x3 mode (frozen norm): the stem's weight gradient on the fp16 matrix cores; the absmax of its gradient operand comes
+  // from the pooling backward, the frame's from this iteration's forward (slot (X, conv 0))
+  static const bool stem_h3_off = getenv("EOSVOS_TUNE_NO_STEM_H3") != nullptr;
+  const auto& xrec = amax_rec_of(e, AM_X, 0);
+  const bool stem_h3 = h3_mode() && !stem_h3_off && !e->gn() && e->amax && xrec.epoch == e->fwd_epoch && xrec.ptr == e->xpad;
+  unsigned* ag = stem_h3 ? amax_fused_slot(e, AM_G, 0, e->g_c1, s) : nullptr;
+  launch_maxpool_bwd(e->g_p1, e->p1idx, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s, ag);
   {
     const int chunks = stem_wgrad_chunks(B, e->h2, e->w2);
     const float* gc1 = e->g_c1;
@@ -1957,7 +1970,8 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
       launch_gn_backward(e->zbuf[0], 64, e->g_c1, 64, e->G_(0), e->gn_stats[0], e->gn_sums, e->gn_partial, B, e->h2 * e->w2, 64, s);
       gc1 = e->zbuf[0];
     }
-    launch_stem_wgrad(e->xpad, gc1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, s);
+    if (ag) launch_stem_wgrad_h3(e->xpad, gc1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, ag, amax_slot(e, AM_X, 0), s);
+    else launch_stem_wgrad(e->xpad, gc1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, s);
     apply_update(e, 0, chunks, update, accumulate);
   }
   if (e->s2) side_flush(e);

@@ -252,7 +252,7 @@ void launch_wino_wgrad_finish(const float* ws, int splits, int Cout, int Cin, fl
 // misc_kernels.hip
 // ---------------------------------------------------------------------------------
 void launch_nchw_to_nhwc_pad(const float* src, float* dst, int B, int C, int H, int W, int pad,
-                             hipStream_t s);
+                             hipStream_t s, unsigned* amax = nullptr);      // amax: absmax slot of the frame (f16x3 mode)
 void launch_fill(float* p, int64_t n, float v, hipStream_t s);
 // OIHW <-> engine layout O,(kh,kw),I for one tensor
 void launch_oihw_to_ohwi(const float* src, float* dst, int O, int I, int T, hipStream_t s);
@@ -267,13 +267,18 @@ void launch_stem_fwd(const float* xpad, const float* w /*[64][49][3]*/, const fl
 void launch_stem_wgrad(const float* xpad, const float* g, float* ws /*[chunks][64*147]*/, int B,
                        int H, int W, int Ho, int Wo, int chunks, hipStream_t s);
 int stem_wgrad_chunks(int B, int Ho, int Wo);
+// f16x3 mode: the stem on the fp16 matrix cores (conv_kernels.hip); amax_x = absmax slot of the padded frame
+void launch_stem_fwd_h3(const float* xpad, const float* w /*[64][49][3]*/, const float* a, const float* b, float* y, int B,
+                        int H, int W, int Ho, int Wo, const unsigned* amax_x, hipStream_t s);
+void launch_stem_wgrad_h3(const float* xpad, const float* g, float* ws /*[chunks][64*147]*/, int B, int H, int W, int Ho,
+                          int Wo, int chunks, const unsigned* amax_g, const unsigned* amax_x, hipStream_t s);
 
 void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int Ho,
                         int Wo, hipStream_t s, unsigned* amax = nullptr);      // amax: absmax slot of y (f16x3 mode)
 // g_x = relu_mask(x) * scatter(g_y)   (x = the ReLU output that was pooled: bit 7 of idx = "the window's maximum is > 0",
 // i.e. the ReLU mask of the one input pixel the gradient goes to -- the backward pass does not read x)
 void launch_maxpool_bwd(const float* gy, const uint8_t* idx, float* gx, int B, int H,
-                        int W, int C, int Ho, int Wo, hipStream_t s);
+                        int W, int C, int Ho, int Wo, hipStream_t s, unsigned* amax = nullptr);      // amax: absmax slot of gx
 
 // Bilinear resize tables (host-built, PyTorch's index/weight rule) live in device memory:
 struct ResizeTab {

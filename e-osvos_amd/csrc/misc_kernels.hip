@@ -32,23 +32,30 @@ static inline int grid_for(long n, int per_block, int cap = 4096) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
 // ---- layout ---------------------------------------------------------------------------
-__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
-                                        int C, int H, int W, int pad) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                               int C, int H, int W, int pad, unsigned* __restrict__ amax) {
   const long n = (long)B * H * W;
   const int Wp = W + 2 * pad, Hp = H + 2 * pad;
+  unsigned am = 0;
   GRID_STRIDE(i, n) {
     const int x = (int)(i % W);
     const int y = (int)((i / W) % H);
     const int b = (int)(i / ((long)W * H));
     float* d = dst + (((long)b * Hp + y + pad) * Wp + x + pad) * C;
-    for (int c = 0; c < C; ++c) d[c] = src[(((long)b * C + c) * H + y) * W + x];
+    for (int c = 0; c < C; ++c) {
+      const float v = src[(((long)b * C + c) * H + y) * W + x];
+      d[c] = v;
+      const unsigned ab = amax_f1(v);
+      am = am > ab ? am : ab;
+    }
   }
+  if (amax) amax_block_commit(am, amax);            // f16x3 mode: absmax of the frame for the stem on the matrix cores
 }
 void launch_nchw_to_nhwc_pad(const float* src, float* dst, int B, int C, int H, int W, int pad,
-                             hipStream_t s) {
+                             hipStream_t s, unsigned* amax) {
   const long n = (long)B * H * W;
   hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, B, C, H,
-                     W, pad);
+                     W, pad, amax);
 }
 
 __global__ void fill_kernel(float* p, long n, float v) { GRID_STRIDE(i, n) p[i] = v; }
@@ -359,11 +366,12 @@ void launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int H, in
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, y, idx, B, H, W, C, Ho,
                      Wo, amax);
 }
-__global__ void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
                                    float* __restrict__ gx, int B, int H, int W,
-                                   int C, int Ho, int Wo) {
+                                   int C, int Ho, int Wo, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const long n = (long)B * H * W * C4;
+  unsigned am = 0;
   GRID_STRIDE(e, n) {
     const int c4 = (int)(e % C4);
     const long pix = e / C4;
@@ -387,14 +395,17 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* 
         if (id.w == k) s[3] += g.w;
       }
     }
-    *reinterpret_cast<float4*>(gx + pix * C + c4 * 4) = make_float4(s[0], s[1], s[2], s[3]);
+    const float4 o = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(gx + pix * C + c4 * 4) = o;
+    am = amax_f4(am, o);
   }
+  if (amax) amax_block_commit(am, amax);            // f16x3 mode: the stem's weight gradient runs on the matrix cores
 }
 void launch_maxpool_bwd(const float* gy, const uint8_t* idx, float* gx, int B, int H, int W,
-                        int C, int Ho, int Wo, hipStream_t s) {
+                        int C, int Ho, int Wo, hipStream_t s, unsigned* amax) {
   const long n = (long)B * H * W * (C >> 2);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, gy, idx, gx, B, H, W, C,
-                     Ho, Wo);
+                     Ho, Wo, amax);
 }
 
 // ---- bilinear resize ----------------------------------------------------------------------

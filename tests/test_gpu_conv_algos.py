@@ -162,6 +162,70 @@ def test_streaming_1x1_kernel_fused_epilogue_vs_fp64(eng):
         engine_mod.set_matrix_mode(prev)
 
 
+@pytest.mark.parametrize('shape', [(2, 480, 854), (1, 97, 163), (3, 96, 160)], ids=lambda s: 'x'.join(map(str, s)))
+def test_stem_on_the_matrix_cores_vs_fp64(shape):
+    """f16x3 mode: the 7x7 stride-2 stem runs on the fp16 matrix cores (`stem_fwd_h3_kernel`; 8-float slots of the padded
+    NHWC3 frame, the weight panel's absmax taken in the kernel, the frame's in the layout pass).  Its output (conv + frozen
+    norm + ReLU, the engine's `c1`) elementwise against fp64, on the full frame, an odd-sized one (slots run 2 floats past a
+    padded row) and a small batch-3 one; the bf16x6 mode (VALU kernel) gives the same answer to rounding."""
+    from eosvos_amd import synthetic
+    B, H, W = shape
+    sd = synthetic.synthetic_state('resnet50')
+    lrs = synthetic.synthetic_lrs('resnet50')
+    x, _ = synthetic.synthetic_frames(B, H, W, seed=5)
+    w = sd['backbone.conv1.weight'].double()
+    g, be = sd['backbone.bn1.weight'].double(), sd['backbone.bn1.bias'].double()
+    mu, var = sd['backbone.bn1.running_mean'].double(), sd['backbone.bn1.running_var'].double()
+    a = g / torch.sqrt(var + 1e-5)
+    ref = F.relu(F.conv2d(x.double(), w, None, 2, 3) * a.view(1, -1, 1, 1) + (be - mu * a).view(1, -1, 1, 1))
+    prev = engine_mod.get_matrix_mode()
+    try:
+        for mode in ('f16x3', 'bf16x6'):
+            engine_mod.set_matrix_mode(mode)
+            e = Engine('resnet50', H, W, max_batch=B, device=DEV)
+            e.load_model_state(sd, lrs)
+            e.forward(x.to(DEV), want_logits=False)
+            c1 = e.debug_tensor('c1').cpu()[:B]
+            e.close()
+            err = _maxrel(c1, ref)
+            print(f'MARGIN stem {shape} {mode}: {err:.2e}')
+            assert err <= 2e-6, (mode, err)
+    finally:
+        engine_mod.set_matrix_mode(prev)
+
+
+@pytest.mark.parametrize('shape', [(2, 480, 854), (1, 97, 163)], ids=lambda s: 'x'.join(map(str, s)))
+def test_stem_weight_gradient_on_the_matrix_cores_vs_fp64(shape):
+    """f16x3 mode: the stem's weight gradient (`stem_wgrad_h3_kernel`: 307 440 pixels at batch 3 reduced in 512 slabs) against
+    an fp64 weight gradient of the same operands -- the engine's own d(loss)/d(stem output) and the frame --, elementwise; the
+    bf16x6 mode (fp32-MFMA stem kernel) for comparison.  The parameter gradient the engine exports carries the frozen-norm
+    scale of the stem's BatchNorm."""
+    from eosvos_amd import synthetic
+    B, H, W = shape
+    sd = synthetic.synthetic_state('resnet50')
+    lrs = synthetic.synthetic_lrs('resnet50')
+    x, y = synthetic.synthetic_frames(B, H, W, seed=9)
+    a = (sd['backbone.bn1.weight'].double() / torch.sqrt(sd['backbone.bn1.running_var'].double() + 1e-5)).view(1, -1, 1, 1)
+    wshape = sd['backbone.conv1.weight'].shape
+    prev = engine_mod.get_matrix_mode()
+    try:
+        for mode in ('f16x3', 'bf16x6'):
+            engine_mod.set_matrix_mode(mode)
+            e = Engine('resnet50', H, W, max_batch=B, device=DEV)
+            e.load_model_state(sd, lrs)
+            e.keep_grads(True)
+            e.finetune_step(x.to(DEV), y.to(DEV))
+            g = e.get_grads().cpu()[:wshape.numel()].view(wshape)          # conv 0 is the first tensor of the flat vector
+            gc1 = e.debug_tensor('g_c1').cpu()[:B].double()
+            e.close()
+            ref = torch.nn.grad.conv2d_weight(x.double(), wshape, gc1 * a, stride=2, padding=3)
+            err = _maxrel(g, ref)
+            print(f'MARGIN stem wgrad {shape} {mode}: {err:.2e}')
+            assert err <= 3e-6, (mode, err)
+    finally:
+        engine_mod.set_matrix_mode(prev)
+
+
 def test_bf16x6_is_at_least_as_accurate_as_the_fp32_mfma(eng):
     """The default matrix mode splits every fp32 operand exactly into 3 bf16 pieces and sums the 6 leading partial
     products in fp32; its error against fp64 must not exceed the fp32 MFMA's (both ~1e-7 of sum|a*b|)."""

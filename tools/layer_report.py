@@ -68,7 +68,7 @@ def main(trace_csv, log, steps=3):
         nm = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('eosvos::', '')
         byname[nm][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); byname[nm][1] += 1
     print(f'per-step kernel totals over {nsteps} traced steps (launches/step, us/step):')
-    for nm, (t, c) in sorted(byname.items(), key=lambda kv: -kv[1][0])[:22]:
+    for nm, (t, c) in sorted(byname.items(), key=lambda kv: -kv[1][0])[:48]:
         print(f'  {nm[:60]:60s} {c / nsteps:7.1f} {t / nsteps / 1e3:9.1f}')
     upd = [r for r in rows if 'sgd_update_all' in r['Kernel_Name']][-4:]
     print('last update launches (us, workgroups):', [(round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, 1),
