@@ -1267,11 +1267,34 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
   constexpr int FH = NF < FHM ? NF : FHM;             // fragments per pass (4 accumulator registers each)
   // K = 512: a strip's activations are 128 registers per lane.  The K steps become the OUTER loop (all NF accumulators live),
   // a K step's activations are split right before its MFMAs and its registers are refilled with the next strip's at once.
-  constexpr bool KOUT = K >= 512;
+  constexpr bool KOUT = K >= 320;
   static_assert(!KOUT || NF == FH, "the K-outer form keeps every fragment's accumulator live");
+  // K = 320 serves Kc = 304 (the decoder's concatenated input): reduction channels >= Kc are zero weights / not loaded
+  constexpr bool KTAIL = K == 320;
   extern __shared__ __attribute__((aligned(16))) unsigned char s1_smem[];      // [2 pieces][NC rows][PITCH] | scale[NC] bias[NC] kscale[K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.y * NC;
+  // Column range and rows of this workgroup.  Plain conv: blockIdx.y = range, the strips of all rows go round-robin over the
+  // waves of the range's workgroups.  Batched GEMM (plane_rows != 0: the Winograd-domain products): a workgroup belongs to one
+  // (plane, row chunk) group and one column range; the groups' workgroups of all ranges get ids 8 apart, i.e. the same XCD at
+  // the same time, so that the rows they all read meet in that XCD's L2.
+  int n0 = blockIdx.y * NC;
+  long rbase = 0, rend = p.M;
+  int sbeg = blockIdx.x * WAVES + wave, sstride = gridDim.x * WAVES;
+  const float* wsrc = p.w;
+  if (p.plane_rows) {
+    const int ranges = p.N / NC, chunks = p.row_chunks;
+    const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+    const int g = (j / ranges) * 8 + xcd;
+    if (g >= p.nplanes * chunks) return;
+    const int plane = g / chunks, chunk = g % chunks;
+    const long per = (((long)p.plane_rows + chunks - 1) / chunks + 15) / 16 * 16;
+    n0 = (j % ranges) * NC;
+    rbase = (long)plane * p.plane_rows + chunk * per;
+    rend = rbase + per;
+    if (rend > (long)(plane + 1) * p.plane_rows) rend = (long)(plane + 1) * p.plane_rows;
+    sbeg = wave; sstride = WAVES;
+    wsrc = p.w + (size_t)plane * p.w_plane;
+  }
   // per-channel epilogue / staging factors live in LDS: a global load per fragment and strip would stall every epilogue pass
   float* const s_sc = reinterpret_cast<float*>(s1_smem + 2 * NC * PITCH);
   float* const s_bi = s_sc + NC;
@@ -1289,19 +1312,22 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
   if (!p.kmajor) {                                    // forward: W[n][K], a row's k contiguous
     for (int i = tid; i < NC * (K / 8); i += WAVES * 64) {
       const int r = i / (K / 8), c8 = i % (K / 8);
-      const float* src = p.w + (size_t)(n0 + r) * p.wK + c8 * 8;
+      const float* src = wsrc + (size_t)(n0 + r) * p.wK + c8 * 8;
       uint4 h0, h1;
-      s1_split8(ldg4(src), ldg4(src + 4), sw, h0, h1);
+      const bool kin = !KTAIL || c8 * 8 < p.Kc;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      s1_split8(kin ? ldg4(src) : z4, kin ? ldg4(src + 4) : z4, sw, h0, h1);
       *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
       *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
     }
   } else {                                            // data gradient: W[k][N]: consecutive lanes read consecutive n of one k row
     for (int i = tid; i < NC * (K / 8); i += WAVES * 64) {
       const int c8 = i / NC, r = i % NC;
-      const float* src = p.w + (size_t)(c8 * 8) * p.wK + n0 + r;
+      const float* src = wsrc + (size_t)(c8 * 8) * p.wK + n0 + r;
       float v[8];
+      const bool kin = !KTAIL || c8 * 8 < p.Kc;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * p.wK];
+      for (int j = 0; j < 8; ++j) v[j] = kin ? src[(size_t)j * p.wK] : 0.f;
       uint4 h0, h1;
       s1_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, h0, h1);
       *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
@@ -1310,20 +1336,24 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
   }
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  const int nstrips = (p.M + 15) / 16;
-  const int gw = blockIdx.x * WAVES + wave, gstride = gridDim.x * WAVES;
+  const int nstrips = (int)((rend - rbase + 15) / 16);
+  const int gw = sbeg, gstride = sstride;
   // the tensor added to the output: residual / skip gradient, or (accumulating data gradient) the destination's old contents
   const float* const adp = p.res ? p.res : (p.accum ? p.y : nullptr);
   const int adld = p.res ? p.ldres : p.ldy;
   const bool both = p.res && p.accum;
   float4 xr[KS][2];
   auto load_x = [&](int strip) {
-    const int m = strip * 16 + fr;
-    const float* q = p.x + (size_t)(m < p.M ? m : p.M - 1) * p.ldx + fq * 8;
+    const long m = rbase + (long)strip * 16 + fr;
+    const float* q = p.x + (size_t)(m < rend ? m : rend - 1) * p.ldx + fq * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      xr[ks][0] = ldg4(q + ks * 32);
-      xr[ks][1] = ldg4(q + ks * 32 + 4);
+      if (!KTAIL || ks * 32 + fq * 8 < p.Kc) {
+        xr[ks][0] = ldg4(q + ks * 32);
+        xr[ks][1] = ldg4(q + ks * 32 + 4);
+      } else {
+        xr[ks][0] = xr[ks][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   unsigned ymax = 0;
@@ -1337,8 +1367,8 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
   float4 adn[FH];
   unsigned mkn[FH];
   auto load_ad = [&](int st, float4 (&ad)[FH], unsigned (&mk)[FH], int half) {
-    const int m = st * 16 + fr;
-    const size_t r = (size_t)(m < p.M ? m : p.M - 1);
+    const long m = rbase + (long)st * 16 + fr;
+    const size_t r = (size_t)(m < rend ? m : rend - 1);
     if (adp) {
 #pragma unroll
       for (int f = 0; f < FH; ++f) ad[f] = ldg4(adp + r * adld + n0 + (half + f) * 16 + 4 * fq);
@@ -1372,11 +1402,11 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
     for (; strip < nstrips; strip += gstride) {
       const int nxt = strip + gstride;
       const bool more = nxt < nstrips;
-      const int mn = nxt * 16 + fr;
-      const float* qn = p.x + (size_t)(mn < p.M ? mn : p.M - 1) * p.ldx + fq * 8;
-      const int m = strip * 16 + fr;
-      const bool ok = m < p.M;
-      const size_t row = (size_t)(ok ? m : p.M - 1);
+      const long mn = rbase + (long)nxt * 16 + fr;
+      const float* qn = p.x + (size_t)(mn < rend ? mn : rend - 1) * p.ldx + fq * 8;
+      const long m = rbase + (long)strip * 16 + fr;
+      const bool ok = m < rend;
+      const size_t row = (size_t)(ok ? m : rend - 1);
       float4 ad[FH];
       unsigned mk[FH];
       load_ad(strip, ad, mk, 0);
@@ -1386,7 +1416,7 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         float4 a = xr[ks][0], b = xr[ks][1];
-        if (more) {                                   // this K step's registers take the next strip's activations right away
+        if (more && (!KTAIL || ks * 32 + fq * 8 < p.Kc)) {      // this K step's registers take the next strip's activations right away
           xr[ks][0] = ldg4(qn + ks * 32);
           xr[ks][1] = ldg4(qn + ks * 32 + 4);
         }
@@ -1438,9 +1468,9 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
       load_x(nxt);
       if (AHEAD) load_ad(nxt, adn, mkn, 0);
     }
-    const int m = strip * 16 + fr;
-    const bool ok = m < p.M;
-    const size_t row = (size_t)(ok ? m : p.M - 1);
+    const long m = rbase + (long)strip * 16 + fr;
+    const bool ok = m < rend;
+    const size_t row = (size_t)(ok ? m : rend - 1);
 #pragma unroll 1
     for (int half = 0; half < NF; half += FH) {
       if (!AHEAD) load_ad(strip, ad, mk, half);
@@ -1471,9 +1501,26 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
 // the launches the streaming kernel takes (f16x3 mode): 1x1, stride 1, K in {64, 128, 256}, whole column ranges, many pixels
 static int stream1x1_nc(const ConvArgs& a) {
   static const int on = env_int("EOSVOS_TUNE_STREAM1X1", 1), min_m = env_int("EOSVOS_TUNE_STREAM1X1_MINM", 16384);
-  if (!on || conv_mfma_mode() != 2 || a.nseg > 0 || a.plane_rows || a.KH != 1 || a.KW != 1 || a.upshift || a.dst_up || a.par ||
+  if (!on || conv_mfma_mode() != 2 || a.nseg > 0 || a.KH != 1 || a.KW != 1 || a.upshift || a.dst_up || a.par ||
       a.tprefix || a.mul != 1 || a.off0 != 0 || a.M < min_m)
     return 0;
+  if (a.plane_rows) {
+    // batched GEMMs of the Winograd-domain convs (decoder), K = 256: 128-channel column ranges (the rows are re-read by the
+    // two ranges of a group from one XCD's L2), or the 48-channel tail of the 304-wide data gradient.  Measured at batch 3
+    // (one stream): 139 -> 122 us forward, 149 / 153 -> 110 / 113 us data gradients, tail 64 -> 46 us; iteration 9.20 -> 9.07 ms.
+    // 64-channel ranges (EOSVOS_TUNE_STREAM1X1_PLANE_NC=64; they also take K = 304 in the 320 variant) are slower than the
+    // tiled kernel: 4 x 36 workgroups per row chunk leave either 56 % of the CUs busy or a second round (195 / 232 us).
+    static const int planes_on = env_int("EOSVOS_TUNE_STREAM1X1_PLANES", 1);
+    if (!planes_on || a.mask || a.mask8 || a.res || a.accum || a.scale || a.bias || a.relu || a.kscale || a.amax_y) return 0;
+    if ((a.ldx & 3) || (a.ldy & 3) || (a.plane_rows & 15)) return 0;
+    if (a.Kc != 256 && !(a.Kc == 304 && !a.kmajor)) return 0;
+    static const int plane_nc = env_int("EOSVOS_TUNE_STREAM1X1_PLANE_NC", 128);
+    if (plane_nc == 128 && a.N % 128 == 0 && a.Kc == 256) return 128;
+    if (plane_nc == 128 && a.Kc == 304) return 0;
+    if (a.N % 64 == 0) return 64;
+    if (a.N == 48 && a.Kc == 256) return 48;
+    return 0;
+  }
   static const int k512 = env_int("EOSVOS_TUNE_STREAM1X1_K512", 1), n48 = env_int("EOSVOS_TUNE_STREAM1X1_N48", 1);
   if (a.Kc != 64 && a.Kc != 128 && a.Kc != 256 && !(a.Kc == 512 && k512)) return 0;
   if (a.mask && !a.mask8) return 0;                   // (the fp32-mask form stays with the tiled kernel)
@@ -1488,10 +1535,22 @@ static int stream1x1_nc(const ConvArgs& a) {
   return 0;
 }
 template <int K, int NC>
-static void launch_stream1x1(const ConvArgs& a, hipStream_t s) {
+static void launch_stream1x1(ConvArgs& a, hipStream_t s) {
   constexpr int lds = 2 * NC * (K * 2 + 16) + (2 * NC + K) * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<K, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  if (a.plane_rows) {
+    // groups = planes x row chunks, each with one workgroup per column range; about `target` workgroups in all
+    static const int target = env_int("EOSVOS_TUNE_STREAM1X1_PLANE_WGS", 216);      // measured: 144 / 216 / 256
+    const int ranges = a.N / NC;
+    int chunks = (target + a.nplanes * ranges - 1) / (a.nplanes * ranges);
+    const int max_chunks = a.plane_rows / 128 > 0 ? a.plane_rows / 128 : 1;      // >= one strip per wave
+    chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);
+    a.row_chunks = chunks;
+    const int groups8 = (a.nplanes * chunks + 7) / 8 * 8;
+    hipLaunchKernelGGL((conv1x1_stream_kernel<K, NC>), dim3(groups8 * ranges), dim3(512), lds, s, a);
+    return;
+  }
   // one workgroup per CU over all column ranges together (a workgroup's 8 waves take the strips of its range round-robin):
   // measured per shape with 128 / 256 / 512 / 1024 workgroups per range, 256 in all is the fastest or within 2 % of it
   static const int total = env_int("EOSVOS_TUNE_STREAM1X1_WGS", 256 * (K <= 128 ? EOSVOS_STREAM_OCC : 1));
@@ -2267,6 +2326,7 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
       if (a.Kc == 64) launch_stream1x1<64, 64>(a, s);
       else if (a.Kc == 128) launch_stream1x1<128, 64>(a, s);
       else if (a.Kc == 256) launch_stream1x1<256, 64>(a, s);
+      else if (a.Kc == 304) launch_stream1x1<320, 64>(a, s);
       else launch_stream1x1<512, 64>(a, s);
     }
     return;

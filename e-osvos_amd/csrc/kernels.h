@@ -108,6 +108,7 @@ struct ConvArgs {
   int plane_rows;       // != 0: batched GEMM -- rows [k*plane_rows, (k+1)*plane_rows) use the weights w + k*w_plane
   long w_plane;
   int nplanes;          // planes of a batched GEMM (16: Winograd F(2,3); 36: F(4,3))
+  int row_chunks;       // streaming kernel, batched GEMM: workgroups (row chunks) per plane and column range (set by the launcher)
   int par;              // 1: GEMM rows enumerate the Ho x Wo grid parity class by parity class (stride-2 3x3 dgrad)
   int dst_up, Hf, Wf;   // dst_up=1: GEMM row (b,oy,ox) is written to pixel (b,2oy,2ox) of an Hf x Wf grid
   const int* tprefix;   // optional (device): compacted K-step prefix per tile (tiles+1), see conv_build_tap_table

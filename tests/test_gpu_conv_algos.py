@@ -58,7 +58,8 @@ nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
 
 # (B, H, W, Cin, Cout, dilation)  -- shapes of the network's Winograd layers and awkward borders
 WINO_CASES = [
-    ('wino_f4', (1, 120, 214, 304, 256, 1)),      # decoder.last_conv.0 at 480x854 (tail launch for the 304 input channels)
+    ('wino_f4', (1, 120, 214, 304, 256, 1)),      # decoder.last_conv.0 at 480x854 (tail launch for the 304 input channels; data-gradient GEMMs streamed)
+    ('wino_f4', (1, 120, 214, 256, 256, 1)),      # decoder.last_conv.1: all three plane GEMMs on the streaming kernel (128-channel ranges)
     ('wino_f4', (3, 30, 54, 256, 256, 1)),        # batch 3
     ('wino_f4', (1, 30, 54, 512, 512, 2)),        # layer4 conv2, d = 2, 4, 8: F(4,3) on the d*d sub-grids
     ('wino_f4', (1, 30, 54, 512, 512, 4)),
