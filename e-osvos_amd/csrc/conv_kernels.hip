@@ -1260,17 +1260,17 @@ __device__ __forceinline__ void s1_split8(const float4& lo, const float4& hi, fl
 template <int K, int NC>
 __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1x1_stream_kernel(const ConvArgs p) {
   constexpr int WAVES = 8;
-  constexpr int KS = K / 32;                          // K steps of the 16x16x32 MFMA
+  constexpr int KS = (K + 31) / 32;                   // K steps of the 16x16x32 MFMA (K = 304: the last one is half empty)
   constexpr int PITCH = K * 2 + 16;                   // bytes per weight row of one piece (pad: conflict-free fragment reads)
   constexpr int NF = NC / 16;                         // 16-channel fragments of the column range
   constexpr int FHM = (K >= 256 || EOSVOS_STREAM_OCC > 1) ? 4 : 8;
   constexpr int FH = NF < FHM ? NF : FHM;             // fragments per pass (4 accumulator registers each)
   // K = 512: a strip's activations are 128 registers per lane.  The K steps become the OUTER loop (all NF accumulators live),
   // a K step's activations are split right before its MFMAs and its registers are refilled with the next strip's at once.
-  constexpr bool KOUT = K >= 320;
-  static_assert(!KOUT || NF == FH, "the K-outer form keeps every fragment's accumulator live");
-  // K = 320 serves Kc = 304 (the decoder's concatenated input): reduction channels >= Kc are zero weights / not loaded
-  constexpr bool KTAIL = K == 320;
+  constexpr bool KOUT = K >= 304;
+  // K = 304 (the decoder's concatenated input): the lanes of the last K step whose 8 values lie past K carry zero
+  // activations and read their weights from the start of the row instead (finite values: 0 * w = 0)
+  constexpr bool KTAIL = (K % 32) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char s1_smem[];      // [2 pieces][NC rows][PITCH] | scale[NC] bias[NC] kscale[K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Column range and rows of this workgroup.  Plain conv: blockIdx.y = range, the strips of all rows go round-robin over the
@@ -1314,9 +1314,7 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
       const int r = i / (K / 8), c8 = i % (K / 8);
       const float* src = wsrc + (size_t)(n0 + r) * p.wK + c8 * 8;
       uint4 h0, h1;
-      const bool kin = !KTAIL || c8 * 8 < p.Kc;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      s1_split8(kin ? ldg4(src) : z4, kin ? ldg4(src + 4) : z4, sw, h0, h1);
+      s1_split8(ldg4(src), ldg4(src + 4), sw, h0, h1);
       *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
       *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
     }
@@ -1325,9 +1323,8 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
       const int c8 = i / NC, r = i % NC;
       const float* src = wsrc + (size_t)(c8 * 8) * p.wK + n0 + r;
       float v[8];
-      const bool kin = !KTAIL || c8 * 8 < p.Kc;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = kin ? src[(size_t)j * p.wK] : 0.f;
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * p.wK];
       uint4 h0, h1;
       s1_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, h0, h1);
       *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
@@ -1348,7 +1345,7 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
     const float* q = p.x + (size_t)(m < rend ? m : rend - 1) * p.ldx + fq * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (!KTAIL || ks * 32 + fq * 8 < p.Kc) {
+      if (!KTAIL || ks * 32 + fq * 8 < K) {
         xr[ks][0] = ldg4(q + ks * 32);
         xr[ks][1] = ldg4(q + ks * 32 + 4);
       } else {
@@ -1407,16 +1404,13 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
       const long m = rbase + (long)strip * 16 + fr;
       const bool ok = m < rend;
       const size_t row = (size_t)(ok ? m : rend - 1);
-      float4 ad[FH];
-      unsigned mk[FH];
-      load_ad(strip, ad, mk, 0);
-      f32x4 acc[FH];
+      f32x4 acc[NF];
 #pragma unroll
-      for (int f = 0; f < FH; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         float4 a = xr[ks][0], b = xr[ks][1];
-        if (more && (!KTAIL || ks * 32 + fq * 8 < p.Kc)) {      // this K step's registers take the next strip's activations right away
+        if (more && (!KTAIL || ks * 32 + fq * 8 < K)) {      // this K step's registers take the next strip's activations right away
           xr[ks][0] = ldg4(qn + ks * 32);
           xr[ks][1] = ldg4(qn + ks * 32 + 4);
         }
@@ -1427,23 +1421,33 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
         }
         uint4 x0, x1;
         s1_split8(a, b, sx, x0, x1);
-        uint4 w0[FH], w1[FH];
+        const int koffs = (!KTAIL || ks * 32 + fq * 8 < K) ? ks * 64 + fq * 16 : 0;
 #pragma unroll
-        for (int f = 0; f < FH; ++f) {
-          const unsigned char* wp = s1_smem + (f * 16 + fr) * PITCH + ks * 64 + fq * 16;
-          w0[f] = *reinterpret_cast<const uint4*>(wp);
-          w1[f] = *reinterpret_cast<const uint4*>(wp + NC * PITCH);
+        for (int h0 = 0; h0 < NF; h0 += FH) {
+          uint4 w0[FH], w1[FH];
+#pragma unroll
+          for (int f = 0; f < FH; ++f) {
+            const unsigned char* wp = s1_smem + ((h0 + f) * 16 + fr) * PITCH + koffs;
+            w0[f] = *reinterpret_cast<const uint4*>(wp);
+            w1[f] = *reinterpret_cast<const uint4*>(wp + NC * PITCH);
+          }
+#pragma unroll
+          for (int f = 0; f < FH; ++f) acc[h0 + f] = MFMA_F16(__builtin_bit_cast(f16x8, w1[f]), __builtin_bit_cast(f16x8, x0), acc[h0 + f]);
+#pragma unroll
+          for (int f = 0; f < FH; ++f) acc[h0 + f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x1), acc[h0 + f]);
+#pragma unroll
+          for (int f = 0; f < FH; ++f) acc[h0 + f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x0), acc[h0 + f]);
+          __builtin_amdgcn_sched_barrier(0);          // (keeps later work from being hoisted: register pressure)
         }
-#pragma unroll
-        for (int f = 0; f < FH; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w1[f]), __builtin_bit_cast(f16x8, x0), acc[f]);
-#pragma unroll
-        for (int f = 0; f < FH; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x1), acc[f]);
-#pragma unroll
-        for (int f = 0; f < FH; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x0), acc[f]);
-        __builtin_amdgcn_sched_barrier(0);            // (keeps later K steps' work from being hoisted: register pressure)
       }
+#pragma unroll 1
+      for (int h0 = 0; h0 < NF; h0 += FH) {
+        float4 ad[FH];
+        unsigned mk[FH];
+        load_ad(strip, ad, mk, h0);
 #pragma unroll
-      for (int f = 0; f < FH; ++f) finish(acc[f], f, ad[f], mk[f], row, ok);
+        for (int f = 0; f < FH; ++f) finish(acc[h0 + f], h0 + f, ad[f], mk[f], row, ok);
+      }
     }
   } else
   for (; strip < nstrips; strip += gstride) {
@@ -1514,9 +1518,9 @@ static int stream1x1_nc(const ConvArgs& a) {
     if (!planes_on || a.mask || a.mask8 || a.res || a.accum || a.scale || a.bias || a.relu || a.kscale || a.amax_y) return 0;
     if ((a.ldx & 3) || (a.ldy & 3) || (a.plane_rows & 15)) return 0;
     if (a.Kc != 256 && !(a.Kc == 304 && !a.kmajor)) return 0;
-    static const int plane_nc = env_int("EOSVOS_TUNE_STREAM1X1_PLANE_NC", 128);
-    if (plane_nc == 128 && a.N % 128 == 0 && a.Kc == 256) return 128;
-    if (plane_nc == 128 && a.Kc == 304) return 0;
+    static const int plane_nc = env_int("EOSVOS_TUNE_STREAM1X1_PLANE_NC", 128), k304 = env_int("EOSVOS_TUNE_STREAM1X1_K304", 1);
+    if (a.Kc == 304 && !k304) return 0;
+    if (plane_nc == 128 && a.N % 128 == 0) return 128;
     if (a.N % 64 == 0) return 64;
     if (a.N == 48 && a.Kc == 256) return 48;
     return 0;
@@ -1536,7 +1540,7 @@ static int stream1x1_nc(const ConvArgs& a) {
 }
 template <int K, int NC>
 static void launch_stream1x1(ConvArgs& a, hipStream_t s) {
-  constexpr int lds = 2 * NC * (K * 2 + 16) + (2 * NC + K) * 4;
+  constexpr int lds = 2 * NC * (K * 2 + 16) + (2 * NC + (K + 31) / 32 * 32) * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<K, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   if (a.plane_rows) {
@@ -2319,6 +2323,7 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
     } else if (nc == 128) {
       if (a.Kc == 64) launch_stream1x1<64, 128>(a, s);
       else if (a.Kc == 128) launch_stream1x1<128, 128>(a, s);
+      else if (a.Kc == 304) launch_stream1x1<304, 128>(a, s);
       else launch_stream1x1<256, 128>(a, s);
     } else if (nc == 48) {
       launch_stream1x1<256, 48>(a, s);
@@ -2326,7 +2331,7 @@ void launch_conv(ConvArgs& a, hipStream_t s) {
       if (a.Kc == 64) launch_stream1x1<64, 64>(a, s);
       else if (a.Kc == 128) launch_stream1x1<128, 64>(a, s);
       else if (a.Kc == 256) launch_stream1x1<256, 64>(a, s);
-      else if (a.Kc == 304) launch_stream1x1<320, 64>(a, s);
+      else if (a.Kc == 304) launch_stream1x1<304, 64>(a, s);
       else launch_stream1x1<512, 64>(a, s);
     }
     return;
