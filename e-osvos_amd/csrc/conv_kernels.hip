@@ -719,6 +719,51 @@ __device__ __forceinline__ float h3_scale(const unsigned* amax, const unsigned* 
   inv = __uint_as_float((unsigned)(254 - f) << 23);
   return __uint_as_float((unsigned)f << 23);
 }
+// the same from slot words already in registers (one word per lane < AMAX_SUB, 0 elsewhere): lets a kernel issue the slot
+// loads together with its other prologue loads instead of one memory round trip per h3_scale call
+__device__ __forceinline__ unsigned amax_issue(const unsigned* slot) {
+  const int lane = threadIdx.x & 63;
+  return (slot && lane < AMAX_SUB) ? slot[(size_t)lane * AMAX_ROW] : 0u;
+}
+__device__ __forceinline__ unsigned amax_wave_max(unsigned m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = m > t ? m : t;
+  }
+  return m;
+}
+__device__ __forceinline__ float h3_scale_bits(unsigned w1, bool two, unsigned w2, float& inv) {
+  float m = __uint_as_float(amax_wave_max(w1));
+  if (two) m *= __uint_as_float(amax_wave_max(w2));
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  int f = 268 - e;
+  f = f < 1 ? 1 : (f > 254 ? 254 : f);
+  inv = __uint_as_float((unsigned)(254 - f) << 23);
+  return __uint_as_float((unsigned)f << 23);
+}
+// The 2-way fp16 split of two values.  Experiment (EOSVOS_MIX_SPLIT=1): both halves of each piece register written in place
+// by v_fma_mixlo / mixhi_f16 -- hi = f16(x * s), lo = f16(fma(x, s, -hi)), 2 VALU instructions per value against 4 for
+// multiply / v_cvt_pk_f16_f32 / convert back / subtract / v_cvt_pk_f16_f32.  Bit-identical pieces (tools/probes/
+// mixsplit_probe.cpp: 2^24 values at four scales; only x = -0 differs, hi = +0 / lo = -0 instead of -0 / +0) -- and SLOWER:
+// iteration 9.07 against 8.87 ms, batch 1 4.80 against 4.71 (same box).  Half the instructions is not half the issue time:
+// the mix forms run at a lower rate than the conversions they replace.
+#ifndef EOSVOS_MIX_SPLIT
+#define EOSVOS_MIX_SPLIT 0
+#endif
+__device__ __forceinline__ void h3_split_pair(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+#if EOSVOS_MIX_SPLIT
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hi) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hi) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(s), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(s), "v"(hi));
+#else
+  const float a = x0 * s, b = x1 * s;
+  hi = h3_pack(a, b);
+  const f32x2v u = h3_unpack(hi);
+  lo = h3_pack(a - u.x, b - u.y);
+#endif
+}
 // four consecutive-k values -> NP pieces of 4 x 16 bit (8 bytes) each.  NP = 3: exact bf16 split (s unused); NP = 2: fp16.
 template <int NP>
 __device__ __forceinline__ void xs_split4(float a, float b, float c, float d, float s, uint2 (&out)[NP]) {
@@ -728,12 +773,8 @@ __device__ __forceinline__ void xs_split4(float a, float b, float c, float d, fl
 #pragma unroll
     for (int p = 0; p < NP; ++p) out[p] = t[p];
   } else {
-    a *= s; b *= s; c *= s; d *= s;
-    out[0].x = h3_pack(a, b);
-    out[0].y = h3_pack(c, d);
-    const f32x2v u0 = h3_unpack(out[0].x), u1 = h3_unpack(out[0].y);
-    out[NP - 1].x = h3_pack(a - u0.x, b - u0.y);
-    out[NP - 1].y = h3_pack(c - u1.x, d - u1.y);
+    h3_split_pair(a, b, s, out[0].x, out[NP - 1].x);
+    h3_split_pair(c, d, s, out[0].y, out[NP - 1].y);
   }
 }
 template <int NP>
@@ -744,10 +785,7 @@ __device__ __forceinline__ void xs_split2(float a, float b, float s, unsigned (&
 #pragma unroll
     for (int p = 0; p < NP; ++p) out[p] = t[p];
   } else {
-    a *= s; b *= s;
-    out[0] = h3_pack(a, b);
-    const f32x2v u = h3_unpack(out[0]);
-    out[NP - 1] = h3_pack(a - u.x, b - u.y);
+    h3_split_pair(a, b, s, out[0], out[NP - 1]);
   }
 }
 __device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
@@ -1243,17 +1281,20 @@ __device__ __forceinline__ void amax_block_commit8(unsigned m, unsigned* slot) {
   }
 }
 __device__ __forceinline__ void s1_split8(const float4& lo, const float4& hi, float s, uint4& h0, uint4& h1) {
-  const float v[8] = {lo.x * s, lo.y * s, lo.z * s, lo.w * s, hi.x * s, hi.y * s, hi.z * s, hi.w * s};
   unsigned a[4], b[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    a[e] = h3_pack(v[2 * e], v[2 * e + 1]);
-    const f32x2v u = h3_unpack(a[e]);
-    b[e] = h3_pack(v[2 * e] - u.x, v[2 * e + 1] - u.y);
-  }
+  h3_split_pair(lo.x, lo.y, s, a[0], b[0]);
+  h3_split_pair(lo.z, lo.w, s, a[1], b[1]);
+  h3_split_pair(hi.x, hi.y, s, a[2], b[2]);
+  h3_split_pair(hi.z, hi.w, s, a[3], b[3]);
   h0 = make_uint4(a[0], a[1], a[2], a[3]);
   h1 = make_uint4(b[0], b[1], b[2], b[3]);
 }
+#ifndef EOSVOS_STREAM3X3_WPRE
+#define EOSVOS_STREAM3X3_WPRE 0       // weight fragments one K step ahead of their MFMAs: measured, no difference (9.00 vs 9.01 ms)
+#endif
+#ifndef EOSVOS_STREAM3X3_D
+#define EOSVOS_STREAM3X3_D 6       // K steps the activation ring of the 3x3 streaming kernel runs ahead (a divisor of 18)
+#endif
 #ifndef EOSVOS_STREAM_OCC
 #define EOSVOS_STREAM_OCC 1        // workgroups per CU the K <= 128 variants are compiled for (2: 128 VGPRs, 4 fragments per pass)
 #endif
@@ -1299,36 +1340,72 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
   float* const s_sc = reinterpret_cast<float*>(s1_smem + 2 * NC * PITCH);
   float* const s_bi = s_sc + NC;
   float* const s_ks = s_bi + NC;
-  for (int i = tid; i < NC; i += WAVES * 64) {
-    s_sc[i] = p.scale ? p.scale[n0 + i] : 1.f;
-    s_bi[i] = p.bias ? p.bias[n0 + i] : 0.f;
-  }
-  for (int i = tid; i < K; i += WAVES * 64) s_ks[i] = p.kscale ? p.kscale[i] : 1.f;
-  float ix, iw;
-  const float sx = h3_scale(p.amax_x, p.kmajor ? p.amax_ks : nullptr, ix);
-  const float sw = h3_scale(p.amax_w, nullptr, iw);
-  const float inv = ix * iw;
-  // ---- weights of this column range: fp32 -> the two fp16 pieces, once ----
-  if (!p.kmajor) {                                    // forward: W[n][K], a row's k contiguous
-    for (int i = tid; i < NC * (K / 8); i += WAVES * 64) {
-      const int r = i / (K / 8), c8 = i % (K / 8);
-      const float* src = wsrc + (size_t)(n0 + r) * p.wK + c8 * 8;
-      uint4 h0, h1;
-      s1_split8(ldg4(src), ldg4(src + 4), sw, h0, h1);
-      *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
-      *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
-    }
-  } else {                                            // data gradient: W[k][N]: consecutive lanes read consecutive n of one k row
-    for (int i = tid; i < NC * (K / 8); i += WAVES * 64) {
-      const int c8 = i / NC, r = i % NC;
-      const float* src = wsrc + (size_t)(c8 * 8) * p.wK + n0 + r;
-      float v[8];
+  // Prologue: EVERY global load -- this thread's weights, the per-channel factors, the absmax slot words -- is issued before
+  // the first one is consumed.  Written statement by statement (load, use, load, use ...) the compiler waits for each load
+  // where it is used: six serial memory round trips in front of the weight pass, and one per granule inside it (15 us of
+  // a 39 us launch, measured on a 16 x 16 map where the launch is nothing but its prologue).  The two weight layouts' passes
+  // are kept apart down to their stores: sharing the split / store code lets the compiler merge the forward pass's float4
+  // loads into the data gradient's eight strided scalar loads per granule.
+  static_assert(NC <= WAVES * 64 && K <= WAVES * 64, "one factor per thread");
+  const float f_sc = (p.scale && tid < NC) ? p.scale[n0 + tid] : 1.f;
+  const float f_bi = (p.bias && tid < NC) ? p.bias[n0 + tid] : 0.f;
+  const float f_ks = (p.kscale && tid < K) ? p.kscale[tid] : 1.f;
+  const unsigned ax = amax_issue(p.amax_x), aks = amax_issue(p.kmajor ? p.amax_ks : nullptr), aw = amax_issue(p.amax_w);
+  float sx = 1.f, sw = 1.f, inv = 1.f;
+  auto scales = [&]() {                               // first consumer: called once the weight loads are in flight too
+    if (tid < NC) { s_sc[tid] = f_sc; s_bi[tid] = f_bi; }
+    if (tid < KS * 32) s_ks[tid] = f_ks;
+    float ix, iw;
+    sx = h3_scale_bits(ax, p.kmajor && p.amax_ks, aks, ix);
+    sw = h3_scale_bits(aw, false, 0u, iw);
+    inv = ix * iw;
+  };
+  {
+    constexpr int GR = NC * (K / 8), IT = (GR + WAVES * 64 - 1) / (WAVES * 64);
+    if (!p.kmajor) {                                  // forward: W[n][K], a row's k contiguous
+      float4 raw[IT][2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * p.wK];
-      uint4 h0, h1;
-      s1_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, h0, h1);
-      *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
-      *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
+      for (int it = 0; it < IT; ++it) {
+        const int i = tid + it * WAVES * 64;
+        const int r = (i < GR ? i : 0) / (K / 8), c8 = i % (K / 8);
+        const float* src = wsrc + (size_t)(n0 + r) * p.wK + c8 * 8;
+        raw[it][0] = ldg4(src);
+        raw[it][1] = ldg4(src + 4);
+      }
+      scales();
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int i = tid + it * WAVES * 64;
+        if (i < GR) {
+          const int r = i / (K / 8), c8 = i % (K / 8);
+          uint4 h0, h1;
+          s1_split8(raw[it][0], raw[it][1], sw, h0, h1);
+          *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
+          *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
+        }
+      }
+    } else {                                          // data gradient: W[k][N]: consecutive lanes read consecutive n of one k row
+      float raw[IT][8];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int i = tid + it * WAVES * 64;
+        const int c8 = (i < GR ? i : 0) / NC, r = i % NC;
+        const float* src = wsrc + (size_t)(c8 * 8) * p.wK + n0 + r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[it][j] = src[(size_t)j * p.wK];
+      }
+      scales();
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int i = tid + it * WAVES * 64;
+        if (i < GR) {
+          const int c8 = i / NC, r = i % NC;
+          uint4 h0, h1;
+          s1_split8(make_float4(raw[it][0], raw[it][1], raw[it][2], raw[it][3]), make_float4(raw[it][4], raw[it][5], raw[it][6], raw[it][7]), sw, h0, h1);
+          *reinterpret_cast<uint4*>(s1_smem + r * PITCH + c8 * 16) = h0;
+          *reinterpret_cast<uint4*>(s1_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
+        }
+      }
     }
   }
   __syncthreads();
@@ -1501,6 +1578,247 @@ __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1
     }
   }
   if (p.amax_y) amax_block_commit8(ymax, p.amax_y);
+}
+// ---------------------------------------------------------------------------------------
+// The same structure for layer1's 3x3 convs (64 -> 64 channels, stride 1, 77 040 pixels at batch 3), forward and data gradient:
+// all 9 x 64 x 64 weights live in LDS as their two fp16 pieces (147 KB), a wave streams strips of 16 output pixels through
+// the 18 K steps (tap-major: K step = tap x 32 channels), the activations of the (dy, dx)-shifted pixel come straight from
+// global memory (zero outside the map) through a ring of D K steps that runs ahead across strip boundaries.  In the tiled
+// kernel these launches ran at 85-100 TFLOP/s (57 / 65 us): 64-wide tiles with 18 K steps, half the MFMA work per staged
+// operand byte.
+// ---------------------------------------------------------------------------------------
+template <int KC, int NC, int D>
+__global__ __launch_bounds__(512, 1) void conv3x3_stream_kernel(const ConvArgs p) {
+  constexpr int WAVES = 8, T = 9;
+  constexpr int K = T * KC, KS = K / 32, KPT = KC / 32;        // K steps per tap
+  constexpr int PITCH = K * 2 + 16;
+  constexpr int NF = NC / 16;
+  static_assert(KS % D == 0 && NF <= 4, "ring depth must divide the K steps; every fragment's accumulator stays live");
+  extern __shared__ __attribute__((aligned(16))) unsigned char s3_smem[];      // [2 pieces][NC rows][PITCH] | scale[NC] bias[NC] kscale[KC]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* const s_sc = reinterpret_cast<float*>(s3_smem + 2 * NC * PITCH);
+  float* const s_bi = s_sc + NC;
+  float* const s_ks = s_bi + NC;
+  // Prologue: EVERY global load -- the nine taps' weights of this thread, the per-channel factors, the absmax slot words --
+  // is issued before the first one is consumed.  Written statement by statement (load, use, load, use ...) the compiler
+  // waits for each load where it is used: six to fifteen serial memory round trips, 12-15 us of a 39 us launch.
+  constexpr int GR = NC * (K / 8), IT = (GR + WAVES * 64 - 1) / (WAVES * 64);
+  static_assert(NC <= WAVES * 64 && KC <= WAVES * 64, "one factor per thread");
+  // (the two layouts' passes are kept apart down to their stores: sharing the split / store code let the compiler merge the
+  // forward pass's float4 loads into the data gradient's eight strided scalar loads per granule -- 17 us instead of 3)
+  const float f_sc = (p.scale && tid < NC) ? p.scale[tid] : 1.f;
+  const float f_bi = (p.bias && tid < NC) ? p.bias[tid] : 0.f;
+  const float f_ks = (p.kscale && tid < KC) ? p.kscale[tid] : 1.f;
+  const unsigned ax = amax_issue(p.amax_x), aks = amax_issue(p.kmajor ? p.amax_ks : nullptr), aw = amax_issue(p.amax_w);
+  float sx = 1.f, sw = 1.f, inv = 1.f;
+  auto scales = [&]() {                               // first consumer of the prologue's loads: called once the weights' are in flight too
+    if (tid < NC) { s_sc[tid] = f_sc; s_bi[tid] = f_bi; }
+    if (tid < KC) s_ks[tid] = f_ks;
+    float ix, iw;
+    sx = h3_scale_bits(ax, p.kmajor && p.amax_ks, aks, ix);
+    sw = h3_scale_bits(aw, false, 0u, iw);
+    inv = ix * iw;
+  };
+  if (!p.kmajor) {                                    // forward: W[n][tap][c], a row's 9 * KC values contiguous; LDS row n holds k = tap * KC + c
+    float4 raw[IT][2];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WAVES * 64;
+      const int r = i / (K / 8), c8 = i % (K / 8);
+      const float* src = p.w + (size_t)(i < GR ? r : 0) * T * p.wK + c8 * 8;
+      raw[it][0] = ldg4(src);
+      raw[it][1] = ldg4(src + 4);
+    }
+    scales();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WAVES * 64;
+      if (i < GR) {
+        const int r = i / (K / 8), c8 = i % (K / 8);
+        uint4 h0, h1;
+        s1_split8(raw[it][0], raw[it][1], sw, h0, h1);
+        *reinterpret_cast<uint4*>(s3_smem + r * PITCH + c8 * 16) = h0;
+        *reinterpret_cast<uint4*>(s3_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
+      }
+    }
+  } else {                                            // data gradient: W[c][tap][n]: consecutive lanes read consecutive n
+    float raw[IT][8];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WAVES * 64;
+      const int c8 = (i < GR ? i : 0) / NC, r = i % NC;
+      const int tap = (c8 * 8) / KC, c0 = (c8 * 8) % KC;
+      const float* src = p.w + ((size_t)c0 * T + tap) * p.wK + r;
+      const size_t st = (size_t)T * p.wK;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[it][j] = src[j * st];
+    }
+    scales();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WAVES * 64;
+      if (i < GR) {
+        const int c8 = i / NC, r = i % NC;
+        uint4 h0, h1;
+        s1_split8(make_float4(raw[it][0], raw[it][1], raw[it][2], raw[it][3]), make_float4(raw[it][4], raw[it][5], raw[it][6], raw[it][7]), sw, h0, h1);
+        *reinterpret_cast<uint4*>(s3_smem + r * PITCH + c8 * 16) = h0;
+        *reinterpret_cast<uint4*>(s3_smem + NC * PITCH + r * PITCH + c8 * 16) = h1;
+      }
+    }
+  }
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nstrips = (p.M + 15) / 16;
+  const int gstride = gridDim.x * WAVES;
+  const float* const adp = p.res ? p.res : (p.accum ? p.y : nullptr);
+  const int adld = p.res ? p.ldres : p.ldy;
+  const bool both = p.res && p.accum;
+  const int hw = p.Ho * p.Wo;
+  // a strip's lane state: source offset of the unshifted pixel and the validity of the three row / column shifts
+  struct Pix { long base, centre; unsigned ok; };    // ok: bit ky = row shift ky valid, bit 3 + kx = column shift kx valid
+  auto pix_of = [&](int strip) {
+    int m = strip * 16 + fr;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / hw, rem = m - b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    Pix q;
+    q.base = (((long)b * p.Hi + oy + p.off0) * p.Wi + ox + p.off0) * p.ldx + fq * 8;
+    q.centre = (((long)b * p.Hi + oy) * p.Wi + ox) * p.ldx + fq * 8;
+    q.ok = 0;
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      const int sy = oy + p.off0 + k3 * p.kstep, sx2 = ox + p.off0 + k3 * p.kstep;
+      if (sy >= 0 && sy < p.Hi) q.ok |= 1u << k3;
+      if (sx2 >= 0 && sx2 < p.Wi) q.ok |= 8u << k3;
+    }
+    return q;
+  };
+  float4 ring[D][2];
+  // Straight-line code: a shifted pixel outside the map is loaded from the unshifted one instead and zeroed where the ring
+  // slot is consumed.  With a branch around the loads the compiler can no longer count the loads in flight and drains them
+  // all (s_waitcnt vmcnt(0)) at every wrap of the ring: three exposed memory round trips per strip.
+  auto tap_ok = [&](const Pix& q, int ks) {
+    const int tap = ks / KPT, ky = tap / 3, kx = tap % 3;
+    return ((q.ok >> ky) & (q.ok >> (3 + kx)) & 1u) != 0;
+  };
+  auto load_k = [&](const Pix& q, int ks, float4 (&dst)[2]) {      // ks: compile-time constant at every call site
+    const int tap = ks / KPT, kin = ks % KPT, ky = tap / 3, kx = tap % 3;
+    const long off = tap_ok(q, ks) ? q.base + ((long)ky * p.kstep * p.Wi + kx * p.kstep) * p.ldx : q.centre;
+    const float* src = p.x + off + kin * 32;
+    dst[0] = ldg4(src);
+    dst[1] = ldg4(src + 4);
+  };
+  unsigned ymax = 0;
+  int strip = blockIdx.x * WAVES + wave;
+  Pix cur = pix_of(strip < nstrips ? strip : 0);
+  if (strip < nstrips) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_k(cur, d, ring[d]);
+  }
+  for (; strip < nstrips; strip += gstride) {
+    const int nxt = strip + gstride;
+    const bool more = nxt < nstrips;
+    const Pix nx = pix_of(more ? nxt : strip);
+    const int m = strip * 16 + fr;
+    const bool ok = m < p.M;
+    const size_t row = (size_t)(ok ? m : p.M - 1);
+    f32x4 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if EOSVOS_STREAM3X3_WPRE
+    // weight fragments one K step ahead of the MFMAs that use them (a K step's ds_reads would otherwise sit exposed in front
+    // of its MFMAs: two waves per SIMD do not cover an LDS round trip)
+    uint4 wn0[NF], wn1[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const unsigned char* wp = s3_smem + (f * 16 + fr) * PITCH + fq * 16;
+      wn0[f] = *reinterpret_cast<const uint4*>(wp);
+      wn1[f] = *reinterpret_cast<const uint4*>(wp + NC * PITCH);
+    }
+#endif
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float4 a = ring[ks % D][0], b = ring[ks % D][1];
+      if (!tap_ok(cur, ks)) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ks + D < KS) load_k(cur, ks + D, ring[ks % D]);          // the ring runs D K steps ahead, across the strip boundary
+      else load_k(nx, ks + D - KS, ring[ks % D]);                  // (past the last strip: the strip's own pixels once more)
+      if (p.kscale) {
+        const int kin = ks % KPT;
+        const float4 k0 = *reinterpret_cast<const float4*>(s_ks + kin * 32 + fq * 8), k1 = *reinterpret_cast<const float4*>(s_ks + kin * 32 + fq * 8 + 4);
+        a.x *= k0.x; a.y *= k0.y; a.z *= k0.z; a.w *= k0.w;
+        b.x *= k1.x; b.y *= k1.y; b.z *= k1.z; b.w *= k1.w;
+      }
+      uint4 x0, x1;
+      s1_split8(a, b, sx, x0, x1);
+      uint4 w0[NF], w1[NF];
+#if EOSVOS_STREAM3X3_WPRE
+#pragma unroll
+      for (int f = 0; f < NF; ++f) { w0[f] = wn0[f]; w1[f] = wn1[f]; }
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const unsigned char* wp = s3_smem + (f * 16 + fr) * PITCH + (ks + 1) * 64 + fq * 16;
+          wn0[f] = *reinterpret_cast<const uint4*>(wp);
+          wn1[f] = *reinterpret_cast<const uint4*>(wp + NC * PITCH);
+        }
+      }
+#else
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const unsigned char* wp = s3_smem + (f * 16 + fr) * PITCH + ks * 64 + fq * 16;
+        w0[f] = *reinterpret_cast<const uint4*>(wp);
+        w1[f] = *reinterpret_cast<const uint4*>(wp + NC * PITCH);
+      }
+#endif
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w1[f]), __builtin_bit_cast(f16x8, x0), acc[f]);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x1), acc[f]);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = MFMA_F16(__builtin_bit_cast(f16x8, w0[f]), __builtin_bit_cast(f16x8, x0), acc[f]);
+#ifndef EOSVOS_STREAM3X3_NOSB
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int n = f * 16 + 4 * fq;
+      float4 v = make_float4(acc[f][0] * inv, acc[f][1] * inv, acc[f][2] * inv, acc[f][3] * inv);
+      if (p.scale) { const float4 s4 = *reinterpret_cast<const float4*>(s_sc + n); v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
+      if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(s_bi + n); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+      if (adp) { const float4 a4 = ldg4(adp + row * adld + n); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
+      if (both) { const float4 a2 = ldg4(p.y + row * p.ldy + n); v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w; }
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.mask8 && n >= p.mask_c0) relu_mask8(v, p.mask8[row * p.ldm8 + (n >> 2)]);
+      if (ok) {
+        *reinterpret_cast<float4*>(p.y + row * p.ldy + n) = v;
+        if (p.mask8_out && p.relu) p.mask8_out[row * p.ldm8_out + (n >> 2)] = relu_bits(v);
+        ymax = amax_f4(ymax, v);
+      }
+    }
+    cur = nx;
+  }
+  if (p.amax_y) amax_block_commit8(ymax, p.amax_y);
+}
+static bool stream3x3_ok(const ConvArgs& a) {
+  static const int on = env_int("EOSVOS_TUNE_STREAM3X3", 1), min_m = env_int("EOSVOS_TUNE_STREAM3X3_MINM", 16384);
+  if (!on || conv_mfma_mode() != 2 || a.nseg > 0 || a.plane_rows || a.KH != 3 || a.KW != 3 || a.upshift || a.dst_up || a.par ||
+      a.tprefix || a.mul != 1 || a.M < min_m)
+    return false;
+  if (a.Kc != 64 || a.N != 64 || a.wK != 64) return false;
+  if (a.mask && !a.mask8) return false;
+  if ((a.mask_c0 & 15) || (a.ldx & 3) || (a.ldy & 3)) return false;
+  if (a.Hi != a.Ho || a.Wi != a.Wo) return false;
+  if (!(a.kstep == 1 || a.kstep == -1) || a.off0 != -a.kstep) return false;      // pad 1, dilation 1 (forward: -1 / +1, data gradient: +1 / -1)
+  return true;
+}
+static void launch_stream3x3(const ConvArgs& a, hipStream_t s) {
+  constexpr int KC = 64, NC = 64, D = EOSVOS_STREAM3X3_D;
+  constexpr int lds = 2 * NC * (9 * KC * 2 + 16) + (2 * NC + KC) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<KC, NC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  static const int wgs = env_int("EOSVOS_TUNE_STREAM3X3_WGS", 256);
+  hipLaunchKernelGGL((conv3x3_stream_kernel<KC, NC, D>), dim3(wgs), dim3(512), lds, s, a);
 }
 // the launches the streaming kernel takes (f16x3 mode): 1x1, stride 1, K in {64, 128, 256}, whole column ranges, many pixels
 static int stream1x1_nc(const ConvArgs& a) {
@@ -2129,7 +2447,8 @@ const char* const kProfNames[] = {
     "conv_h3_kernel<128, false>", "conv_h3_kernel<128, true>", "conv_h3_kernel<64, false>", "conv_h3_kernel<64, true>",
     "wgrad_h3_kernel<128, 128>", "wgrad_h3_kernel<128, 64>", "wgrad_h3_kernel<64, 128>", "wgrad_h3_kernel<64, 64>",
     "wgrad_h3_group_kernel<128, 128>", "wgrad_h3_group_kernel<128, 64>", "wgrad_h3_group_kernel<64, 128>", "wgrad_h3_group_kernel<64, 64>",
-    "conv_h3_multi_kernel", "conv_x6_multi_kernel", "conv1x1_stream_kernel<*, 128>", "conv1x1_stream_kernel<*, 64>"};
+    "conv_h3_multi_kernel", "conv_x6_multi_kernel", "conv1x1_stream_kernel<*, 128>", "conv1x1_stream_kernel<*, 64>",
+    "conv3x3_stream_kernel"};
 constexpr int kProfKernels = sizeof(kProfNames) / sizeof(kProfNames[0]);
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -2314,6 +2633,12 @@ int conv_plan(ConvArgs& a) {
 }
 
 void launch_conv(ConvArgs& a, hipStream_t s) {
+  if (stream3x3_ok(a)) {                              // layer1's 64 -> 64 3x3 convs: all nine taps' weights resident in LDS
+    a.dp_q = 0; a.per = 0; a.nwg = 0; a.splitk = 0;
+    ProfScope ps(37, 2.0 * a.M * a.N * a.Kc * 9, s);
+    launch_stream3x3(a, s);
+    return;
+  }
   if (const int nc = stream1x1_nc(a)) {               // short-K 1x1 convs on the large maps: the streaming kernel
     a.dp_q = 0; a.per = 0; a.nwg = 0; a.splitk = 0;
     ProfScope ps(nc >= 128 ? 35 : 36, 2.0 * a.M * a.N * a.Kc, s);

@@ -120,6 +120,9 @@ STRIDED_CASES = [          # (B, H, W, Cin, Cout, k, stride, dil, pad): the non-
     (3, 60, 107, 128, 512, 1, 1, 1, 0),           # layer2 conv3 (19 260 pixels, 4 column ranges; data gradient K = 512)
     (3, 120, 214, 256, 128, 1, 1, 1, 0),          # layer2.0.conv1
     (3, 60, 107, 512, 128, 1, 1, 1, 0),           # layer2 conv1 of blocks 1-3: K = 512 (K-outer form, 64-channel ranges)
+    # layer1's 3x3 convs: conv3x3_stream_kernel (nine taps' weights resident in LDS, shifted activations from global memory)
+    (3, 120, 214, 64, 64, 3, 1, 1, 1),
+    (1, 120, 214, 64, 64, 3, 1, 1, 1),            # 25 680 pixels: a ragged last strip, image borders inside strips
 ]
 
 
