@@ -901,20 +901,30 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
   float sa = 1.f, sb = 1.f, inv_ab = 1.f;
   if (NP == 2 && !MULTI) {
     float ia, ib;
-    sa = h3_scale(p.amax_x, KMAJOR ? p.amax_ks : nullptr, ia);
-    sb = h3_scale(p.amax_w, nullptr, ib);
+    // (the slot words of all operands are requested together: one memory round trip in front of the first tile instead of
+    // one per slot -- statement by statement the compiler waits for each load where its reduction starts)
+    const unsigned ax = amax_issue(p.amax_x), ak = amax_issue(KMAJOR ? p.amax_ks : nullptr), aw = amax_issue(p.amax_w);
+    sa = h3_scale_bits(ax, KMAJOR && p.amax_ks, ak, ia);
+    sb = h3_scale_bits(aw, false, 0u, ib);
     inv_ab = ia * ib;
   }
   // K-concatenated launch: operand scales per segment (f16x3); the accumulators live in units of 1 / inv_ab of the segment
   // they were last added to and are rescaled (exact: powers of two) where the K loop enters the next one
   float seg_sa[4] = {1.f, 1.f, 1.f, 1.f}, seg_sb[4] = {1.f, 1.f, 1.f, 1.f}, seg_inv[4] = {1.f, 1.f, 1.f, 1.f};
   if (MULTI && NP == 2) {
+    const unsigned ax = amax_issue(p.amax_x);
+    unsigned ak[4], aw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                     // all slot words in flight together (else 8 serial round trips)
+      ak[g] = amax_issue(g < p.nseg ? p.seg_amax_ks[g] : nullptr);
+      aw[g] = amax_issue(g < p.nseg ? p.seg_amax_w[g] : nullptr);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (g >= p.nseg) break;
       float ia, ib;
-      seg_sa[g] = h3_scale(p.amax_x, p.seg_amax_ks[g], ia);
-      seg_sb[g] = h3_scale(p.seg_amax_w[g], nullptr, ib);
+      seg_sa[g] = h3_scale_bits(ax, p.seg_amax_ks[g] != nullptr, ak[g], ia);
+      seg_sb[g] = h3_scale_bits(aw[g], false, 0u, ib);
       seg_inv[g] = ia * ib;
     }
   }
@@ -2041,7 +2051,8 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_h3_kernel(const float* __re
   const int koff = k < 147 ? (k / 21) * Wp * 3 + (k % 21) : 0;
   const int a_cg = tid & 15, a_pg = tid >> 4;           // A staging: channels [4 a_cg, + 4) of pixels 2 a_pg, 2 a_pg + 1
   float ig, ix;
-  const float sg = h3_scale(amax_g, nullptr, ig), sx = h3_scale(amax_x, nullptr, ix);
+  const unsigned ag_w = amax_issue(amax_g), ax_w = amax_issue(amax_x);
+  const float sg = h3_scale_bits(ag_w, false, 0u, ig), sx = h3_scale_bits(ax_w, false, 0u, ix);
   f32x4 acc[10];
 #pragma unroll
   for (int j = 0; j < 10; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2184,8 +2195,9 @@ __device__ __forceinline__ void wgrad_x6_body(const WgradArgs& p, const int bid,
   float sa = 1.f, sb = 1.f, inv_ab = 1.f;
   if (NP == 2) {
     float ia, ib;
-    sa = h3_scale(p.amax_g, nullptr, ia);
-    sb = h3_scale(p.amax_x, nullptr, ib);
+    const unsigned ag_w = amax_issue(p.amax_g), ax_w = amax_issue(p.amax_x);      // both slots' words in one round trip
+    sa = h3_scale_bits(ag_w, false, 0u, ia);
+    sb = h3_scale_bits(ax_w, false, 0u, ib);
     inv_ab = ia * ib;
   }
   const int hw = hv * wv > 0 ? hv * wv : 1, wv1 = wv > 0 ? wv : 1;
