@@ -748,6 +748,9 @@ __device__ __forceinline__ float h3_scale_bits(unsigned w1, bool two, unsigned w
 // mixsplit_probe.cpp: 2^24 values at four scales; only x = -0 differs, hi = +0 / lo = -0 instead of -0 / +0) -- and SLOWER:
 // iteration 9.07 against 8.87 ms, batch 1 4.80 against 4.71 (same box).  Half the instructions is not half the issue time:
 // the mix forms run at a lower rate than the conversions they replace.
+#ifndef EOSVOS_LATE_SCALES
+#define EOSVOS_LATE_SCALES 1
+#endif
 #ifndef EOSVOS_MIX_SPLIT
 #define EOSVOS_MIX_SPLIT 0
 #endif
@@ -899,15 +902,31 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long)p.B * p.Hi * p.Wi * p.ldx * 4);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, MULTI ? p.w_floats * 4 : (p.plane_rows ? (long)p.nplanes : 1L) * p.wN * T * p.wK * 4);
   float sa = 1.f, sb = 1.f, inv_ab = 1.f;
+  // The slot words of all operands are requested together -- statement by statement the compiler waits for each load where
+  // its reduction starts: one memory round trip per slot in front of the first tile -- and reduced only when the first tile's
+  // operand loads are in flight as well (scales_late()).
+  unsigned h3_ax = 0, h3_ak = 0, h3_aw = 0;
+  bool h3_pending = false;
   if (NP == 2 && !MULTI) {
+    h3_ax = amax_issue(p.amax_x); h3_ak = amax_issue(KMAJOR ? p.amax_ks : nullptr); h3_aw = amax_issue(p.amax_w);
+    h3_pending = true;
+#if !EOSVOS_LATE_SCALES
     float ia, ib;
-    // (the slot words of all operands are requested together: one memory round trip in front of the first tile instead of
-    // one per slot -- statement by statement the compiler waits for each load where its reduction starts)
-    const unsigned ax = amax_issue(p.amax_x), ak = amax_issue(KMAJOR ? p.amax_ks : nullptr), aw = amax_issue(p.amax_w);
-    sa = h3_scale_bits(ax, KMAJOR && p.amax_ks, ak, ia);
-    sb = h3_scale_bits(aw, false, 0u, ib);
+    sa = h3_scale_bits(h3_ax, KMAJOR && p.amax_ks, h3_ak, ia);
+    sb = h3_scale_bits(h3_aw, false, 0u, ib);
     inv_ab = ia * ib;
+    h3_pending = false;
+#endif
   }
+  auto scales_late = [&]() {
+    if (h3_pending) {                                 // wave-uniform; true once per workgroup
+      float ia, ib;
+      sa = h3_scale_bits(h3_ax, KMAJOR && p.amax_ks, h3_ak, ia);
+      sb = h3_scale_bits(h3_aw, false, 0u, ib);
+      inv_ab = ia * ib;
+      h3_pending = false;
+    }
+  };
   // K-concatenated launch: operand scales per segment (f16x3); the accumulators live in units of 1 / inv_ab of the segment
   // they were last added to and are rescaled (exact: powers of two) where the K loop enters the next one
   float seg_sa[4] = {1.f, 1.f, 1.f, 1.f}, seg_sb[4] = {1.f, 1.f, 1.f, 1.f}, seg_inv[4] = {1.f, 1.f, 1.f, 1.f};
@@ -1120,6 +1139,7 @@ __device__ __forceinline__ void conv_xs_body(const ConvArgs& p, unsigned char* s
         for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
     load_tiles(ks_begin);
+    scales_late();
     __syncthreads();            // previous segment's epilogue reads of smem are done
     store_tiles();
     __syncthreads();
