@@ -1319,6 +1319,13 @@ __device__ __forceinline__ void s1_split8(const float4& lo, const float4& hi, fl
   h0 = make_uint4(a[0], a[1], a[2], a[3]);
   h1 = make_uint4(b[0], b[1], b[2], b[3]);
 }
+// Row pitch (bytes) of a weight image whose rows are read as 16x16x32 fragments by ds_read_b128 (lane -> row fr = lane % 16,
+// 16-byte slot fq = lane / 16): the instruction's four 16-lane groups mix slots -- {fr 0-3, 12-15 of slot 2g} with {fr 4-11
+// of slot 2g + 1} and the reverse (MI355X_MICROARCH.md, LDS) --, so the pitch in 16-byte units must be 2 mod 4 for the 16
+// lanes of a group to cover all 64 banks: pitch = 32 bytes mod 64.  With K * 2 + 16 (round-4 first version: 16 mod 64) every
+// fragment read was a 2-way conflict (SQ_LDS_BANK_CONFLICT 42 % of the LDS cycles of conv3x3_stream_kernel) and the LDS, not
+// the matrix cores, paced the K loop.
+constexpr int frag_pitch(int row_bytes) { return row_bytes % 64 == 32 ? row_bytes : row_bytes + (96 - row_bytes % 64) % 64; }
 #ifndef EOSVOS_STREAM3X3_WPRE
 #define EOSVOS_STREAM3X3_WPRE 0       // weight fragments one K step ahead of their MFMAs: measured, no difference (9.00 vs 9.01 ms)
 #endif
@@ -1332,7 +1339,7 @@ template <int K, int NC>
 __global__ __launch_bounds__(512, (K <= 128 ? EOSVOS_STREAM_OCC : 1)) void conv1x1_stream_kernel(const ConvArgs p) {
   constexpr int WAVES = 8;
   constexpr int KS = (K + 31) / 32;                   // K steps of the 16x16x32 MFMA (K = 304: the last one is half empty)
-  constexpr int PITCH = K * 2 + 16;                   // bytes per weight row of one piece (pad: conflict-free fragment reads)
+  constexpr int PITCH = frag_pitch(K * 2);            // bytes per weight row of one piece (conflict-free fragment reads)
   constexpr int NF = NC / 16;                         // 16-channel fragments of the column range
   constexpr int FHM = (K >= 256 || EOSVOS_STREAM_OCC > 1) ? 4 : 8;
   constexpr int FH = NF < FHM ? NF : FHM;             // fragments per pass (4 accumulator registers each)
@@ -1621,7 +1628,7 @@ template <int KC, int NC, int D>
 __global__ __launch_bounds__(512, 1) void conv3x3_stream_kernel(const ConvArgs p) {
   constexpr int WAVES = 8, T = 9;
   constexpr int K = T * KC, KS = K / 32, KPT = KC / 32;        // K steps per tap
-  constexpr int PITCH = K * 2 + 16;
+  constexpr int PITCH = frag_pitch(K * 2);
   constexpr int NF = NC / 16;
   static_assert(KS % D == 0 && NF <= 4, "ring depth must divide the K steps; every fragment's accumulator stays live");
   extern __shared__ __attribute__((aligned(16))) unsigned char s3_smem[];      // [2 pieces][NC rows][PITCH] | scale[NC] bias[NC] kscale[KC]
@@ -1844,7 +1851,7 @@ static bool stream3x3_ok(const ConvArgs& a) {
 }
 static void launch_stream3x3(const ConvArgs& a, hipStream_t s) {
   constexpr int KC = 64, NC = 64, D = EOSVOS_STREAM3X3_D;
-  constexpr int lds = 2 * NC * (9 * KC * 2 + 16) + (2 * NC + KC) * 4;
+  constexpr int lds = 2 * NC * frag_pitch(9 * KC * 2) + (2 * NC + KC) * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<KC, NC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   static const int wgs = env_int("EOSVOS_TUNE_STREAM3X3_WGS", 256);
@@ -1888,7 +1895,7 @@ static int stream1x1_nc(const ConvArgs& a) {
 }
 template <int K, int NC>
 static void launch_stream1x1(ConvArgs& a, hipStream_t s) {
-  constexpr int lds = 2 * NC * (K * 2 + 16) + (2 * NC + (K + 31) / 32 * 32) * 4;
+  constexpr int lds = 2 * NC * frag_pitch(K * 2) + (2 * NC + (K + 31) / 32 * 32) * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<K, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   if (a.plane_rows) {
@@ -1922,7 +1929,7 @@ static void launch_stream1x1(ConvArgs& a, hipStream_t s) {
 // The VALU kernel (misc_kernels.hip) took 93 us at batch 3 -- 5.8 GFLOP of fp32 FMAs; the output (79 MB) bounds this one.
 // ---------------------------------------------------------------------------------------
 #define STEM_SLOTS 24
-#define STEM_PITCH (STEM_SLOTS * 16 + 16)
+#define STEM_PITCH (STEM_SLOTS * 16 + 32)       // 32 mod 64: see frag_pitch
 __global__ __launch_bounds__(512) void stem_fwd_h3_kernel(const float* __restrict__ xpad, const float* __restrict__ w,
                                                           const float* __restrict__ a, const float* __restrict__ bb,
                                                           float* __restrict__ y, int B, int H, int W, int Ho, int Wo,
