@@ -1762,6 +1762,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream_kernel(const ConvArgs p
     f32x4 acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool border = __any(cur.ok != 0x3fu);          // wave-uniform
 #if EOSVOS_STREAM3X3_WPRE
     // weight fragments one K step ahead of the MFMAs that use them (a K step's ds_reads would otherwise sit exposed in front
     // of its MFMAs: two waves per SIMD do not cover an LDS round trip)
@@ -1775,10 +1776,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream_kernel(const ConvArgs p
 #endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      float4 a = ring[ks % D][0], b = ring[ks % D][1];
-      if (!tap_ok(cur, ks)) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ks + D < KS) load_k(cur, ks + D, ring[ks % D]);          // the ring runs D K steps ahead, across the strip boundary
-      else load_k(nx, ks + D - KS, ring[ks % D]);                  // (past the last strip: the strip's own pixels once more)
+      // the slot is split in place and refilled afterwards (a copy of its 8 registers per K step otherwise); only strips that
+      // touch the border of the map pay for zeroing their outside taps
+      float4& a = ring[ks % D][0];
+      float4& b = ring[ks % D][1];
+      if (border && !tap_ok(cur, ks)) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.kscale) {
         const int kin = ks % KPT;
         const float4 k0 = *reinterpret_cast<const float4*>(s_ks + kin * 32 + fq * 8), k1 = *reinterpret_cast<const float4*>(s_ks + kin * 32 + fq * 8 + 4);
@@ -1787,6 +1789,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream_kernel(const ConvArgs p
       }
       uint4 x0, x1;
       s1_split8(a, b, sx, x0, x1);
+      if (ks + D < KS) load_k(cur, ks + D, ring[ks % D]);          // the ring runs D K steps ahead, across the strip boundary
+      else load_k(nx, ks + D - KS, ring[ks % D]);                  // (past the last strip: the strip's own pixels once more)
       uint4 w0[NF], w1[NF];
 #if EOSVOS_STREAM3X3_WPRE
 #pragma unroll
