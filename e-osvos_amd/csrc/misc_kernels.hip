@@ -463,16 +463,47 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
     const float* gb = gy + (long)b * th.out * tw.out * ldgy + cv * V;
+    // the column weights of this pixel once, not once per source row (three dependent table loads per element otherwise:
+    // the 1-channel logits gradient took 35 us for 5 MB); same products, same order of accumulation
+    constexpr int MAXW = 12;
+    const int dx0 = tw.lo[ix], dx1 = tw.hi[ix];
+    float wxs[MAXW];
+    const bool pre = V == 1 && dx1 - dx0 < MAXW;          // (the 4-channel form gains nothing: 47 -> 49 us)
+    if (pre) {
+#pragma unroll
+      for (int t = 0; t < MAXW; ++t) {
+        const int dx = dx0 + t;
+        if (dx <= dx1) {
+          const float lx = tw.lam[dx];
+          wxs[t] = (tw.i0[dx] == ix ? 1.f - lx : 0.f) + (tw.i1[dx] == ix ? lx : 0.f);
+        } else {
+          wxs[t] = 0.f;
+        }
+      }
+    }
     for (int dy = th.lo[iy]; dy <= th.hi[iy]; ++dy) {
       const float ly = th.lam[dy];
       const float wy = (th.i0[dy] == iy ? 1.f - ly : 0.f) + (th.i1[dy] == iy ? ly : 0.f);
-      for (int dx = tw.lo[ix]; dx <= tw.hi[ix]; ++dx) {
-        const float lx = tw.lam[dx];
-        const float wx = (tw.i0[dx] == ix ? 1.f - lx : 0.f) + (tw.i1[dx] == ix ? lx : 0.f);
-        const float wgt = wy * wx;
-        const float* gp = gb + ((long)dy * tw.out + dx) * ldgy;
+      if (pre) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = fmaf(wgt, gp[j], acc[j]);
+        for (int t = 0; t < MAXW; ++t) {
+          const int dx = dx0 + t;
+          if (dx <= dx1) {
+            const float wgt = wy * wxs[t];
+            const float* gp = gb + ((long)dy * tw.out + dx) * ldgy;
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = fmaf(wgt, gp[j], acc[j]);
+          }
+        }
+      } else {
+        for (int dx = dx0; dx <= dx1; ++dx) {
+          const float lx = tw.lam[dx];
+          const float wx = (tw.i0[dx] == ix ? 1.f - lx : 0.f) + (tw.i1[dx] == ix ? lx : 0.f);
+          const float wgt = wy * wx;
+          const float* gp = gb + ((long)dy * tw.out + dx) * ldgy;
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] = fmaf(wgt, gp[j], acc[j]);
+        }
       }
     }
     float* d = gx + pix * ldgx + cv * V;
