@@ -1863,7 +1863,10 @@ static void launch_stream3x3(const ConvArgs& a, hipStream_t s) {
 }
 // the launches the streaming kernel takes (f16x3 mode): 1x1, stride 1, K in {64, 128, 256}, whole column ranges, many pixels
 static int stream1x1_nc(const ConvArgs& a) {
-  static const int on = env_int("EOSVOS_TUNE_STREAM1X1", 1), min_m = env_int("EOSVOS_TUNE_STREAM1X1_MINM", 16384);
+  // pixels from which on: 16 384 at batch 3 (below: +-0 in the iteration), 1 024 at batch 1 (layer2's 6 420 and layer3 / 4's
+  // 1 620 pixels: 4.68 -> 4.65 ms; batch 3 8.86 -> 8.88 with the same rule)
+  static const int on = env_int("EOSVOS_TUNE_STREAM1X1", 1), min_m_env = env_int("EOSVOS_TUNE_STREAM1X1_MINM", 0);
+  const int min_m = min_m_env > 0 ? min_m_env : (a.B == 1 && !a.plane_rows ? 1024 : 16384);
   if (!on || conv_mfma_mode() != 2 || a.nseg > 0 || a.KH != 1 || a.KW != 1 || a.upshift || a.dst_up || a.par ||
       a.tprefix || a.mul != 1 || a.off0 != 0 || a.M < min_m)
     return 0;
