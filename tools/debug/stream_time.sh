@@ -1,5 +1,5 @@
 #!/bin/bash
-export TMPDIR=/tmp EOSVOS_TUNE_STREAM3X3_MINM=0 EOSVOS_TUNE_STREAM1X1_MINM=0
+export TMPDIR=/tmp EOSVOS_TUNE_STREAM3X3_MINM=0 EOSVOS_TUNE_STREAM1X1_MINM=1
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/s3 -- python3 tools/debug/stream_time.py > /dev/null 2>&1
 python3 - <<PY
 import csv,glob,collections
