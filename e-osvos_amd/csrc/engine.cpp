@@ -881,16 +881,18 @@ std::vector<int> plan_wgrad_splits(const std::vector<WgGroupItem>& items, int wg
     }
   return splits;
 }
-bool wgrad_groupable(const eosvos_engine* e, int ci) {
+bool wgrad_groupable(const eosvos_engine* e, int ci, int B) {
   static const bool off = getenv("EOSVOS_NO_WGRAD_GROUP") != nullptr;
   // Measured at batch 3 (profiles/r03_ab_wgrad_group.txt): grouping layer3 (30 / 14 splits per conv -> 2, 578 -> 57 MB of
   // slabs) leaves the two-stream step time unchanged; grouping layer2 / layer1 as well makes it 1 % LONGER although the
   // summed kernel time drops by 0.3 ms -- their grouped launches start only after the stage's data-gradient chain and
-  // the last one runs with nothing beside it.  Default with a side stream: layer3 only.
+  // the last one runs with nothing beside it.  Round 3's default with a side stream: layer3 only.  Re-measured in round 4
+  // (streaming kernels in layer1 / layer2, whole-tile plans: profiles/r04_ab_log.txt): layer2 + layer3 at batch 3 (8.88 ->
+  // 8.82 ms; with layer1 as well 8.91), every stage at batch 1 (4.65 -> 4.60 ms; layer2 + layer3 4.62).
   // An engine WITHOUT a side stream (it runs beside other engines, eosvos_set_side_stream) has no such overlap to lose:
   // every stage is grouped (4 tasks in flight at batch 1: 41.0 -> 41.9 meta-tasks/s).
   static const int env_stage = getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE") ? atoi(getenv("EOSVOS_TUNE_WGRAD_GROUP_MINSTAGE")) : -1;
-  const int min_stage = env_stage >= 0 ? env_stage : (e->s2 ? 2 : 0);
+  const int min_stage = env_stage >= 0 ? env_stage : (e->s2 ? (B == 1 ? 0 : 1) : 0);
   return !off && e->wg_group_on && conv_mfma_mode() >= 1 && e->force_algo == 0 && ci < (int)e->t.stage.size() &&
          e->t.stage[ci] >= min_stage && e->t.stage[ci] <= 2 && !e->conv_hin.empty();
 }
@@ -1034,7 +1036,7 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
         a.amax_x = (r.epoch == e->fwd_epoch && r.ptr == x) ? xs : amax_get(e, AM_X, ci, x, (long)B * Hin * Win, c.cin, ldx, e->s);
       }
     }
-    if (wgrad_groupable(e, ci)) {
+    if (wgrad_groupable(e, ci, B)) {
       e->wg_pending.push_back({ci, a});
       return -1;
     }
