@@ -1780,21 +1780,32 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   }
   const float* l4 = e->bb.back().out;
   const int P16 = e->h16 * e->w16;
+  // The image-pooling branch (column sums, GEMV, broadcast, absmax: five small latency-bound launches) reads layer4's output
+  // only: with a side stream it runs there, beside the four ASPP convs, and joins in front of the projection.
+  static const bool pool_side_off = getenv("EOSVOS_TUNE_NO_POOL_SIDE") != nullptr;
+  const bool pside = fside && !pool_side_off;
+  hipStream_t ps = pside ? e->s2 : s;
+  if (pside) fork(t.pool);
+  auto pool_branch = [&]() {
+    launch_colsum(l4, 2048, e->vec, B, P16, 2048, 1.0f / (float)P16, e->colscratch, ps);
+    if (e->gn()) {
+      launch_gemv_fwd(e->W_(t.pool), e->vec, nullptr, nullptr, e->zbuf[t.pool], B, 256, 2048, ps);
+      launch_gn_forward(e->zbuf[t.pool], 256, e->G_(t.pool), e->nb + t.convs[t.pool].noff, nullptr, 0, e->poolout, 256,
+                        e->gn_stats[t.pool], e->gn_partial, B, 1, 256, 1e-5f, 1, ps);
+    } else {
+      launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, ps);
+    }
+    launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, ps, e->m8w(e->cat) ? e->m8w(e->cat) + 1024 / 4 : nullptr, 1280 / 4);
+  };
+  if (pside) pool_branch();
   for (int i = 0; i < 4; ++i)
     conv_fwd(e, t.aspp[i], l4, 2048, e->h16, e->w16, e->cat + 256 * i, 1280, B, nullptr, 0, true, false, nullptr, e->cat);
-  launch_colsum(l4, 2048, e->vec, B, P16, 2048, 1.0f / (float)P16, e->colscratch, s);
-  if (e->gn()) {
-    launch_gemv_fwd(e->W_(t.pool), e->vec, nullptr, nullptr, e->zbuf[t.pool], B, 256, 2048, s);
-    launch_gn_forward(e->zbuf[t.pool], 256, e->G_(t.pool), e->nb + t.convs[t.pool].noff, nullptr, 0, e->poolout, 256,
-                      e->gn_stats[t.pool], e->gn_partial, B, 1, 256, 1e-5f, 1, s);
-  } else {
-    launch_gemv_fwd(e->W_(t.pool), e->vec, e->A_(t.pool), e->B_(t.pool), e->poolout, B, 256, 2048, s);
-  }
-  launch_bcast_pixels(e->poolout, e->cat + 1024, 1280, B, P16, 256, 1.f, s, e->m8w(e->cat) ? e->m8w(e->cat) + 1024 / 4 : nullptr, 1280 / 4);
+  if (!pside) pool_branch();
   if (h3_mode() && !e->gn() && !amax_init(e)) {
     // cat = 4 conv outputs (their epilogues fed the tensor's slot) + the broadcast pooling branch (its B x 256 values here)
-    if (unsigned* cs = tslot(e, 0, e->cat)) { launch_absmax(e->poolout, 1, B * 256, B * 256, cs, s); tmark_valid(e, 0, e->cat); }
+    if (unsigned* cs = tslot(e, 0, e->cat)) { launch_absmax(e->poolout, 1, B * 256, B * 256, cs, ps); tmark_valid(e, 0, e->cat); }
   }
+  if (pside) { (void)hipEventRecord(e->ev[t.pool], e->s2); (void)hipStreamWaitEvent(s, e->ev[t.pool], 0); }
   conv_fwd(e, t.project, e->cat, 1280, e->h16, e->w16, e->proj, 256, B, nullptr, 0, true);
   const ConvL& lc = t.convs[t.last];
   if (t.v3) {
