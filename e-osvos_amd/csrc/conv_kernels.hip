@@ -2953,7 +2953,7 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget, int mode) 
   const int RES = conv_wg_budget(wg_budget) * EOSVOS_WG_OCC / EOSVOS_OCC;
   int best = 1;
   double best_eff = 0.0;
-  static const int minsteps = env_int("EOSVOS_TUNE_WG_MINSTEPS", 256 / EOSVOS_WG_BKP);   // 8 steps = 256 pixels per split (4: batch 1 +1.3 %)
+  static const int minsteps = env_int("EOSVOS_TUNE_WG_MINSTEPS", 384 / EOSVOS_WG_BKP);   // 12 steps = 384 pixels per split (round 4: batch 1 4.57 -> 4.54 ms, batch 3 +-0; 8 before; 4 / 6: batch 1 +1.3 ... 2 %)
   for (int s = 1; s <= 512 && steps / s >= minsteps; ++s) {
     const long wgs = (long)tiles * s;
     const long rounds = (wgs + RES - 1) / RES;
