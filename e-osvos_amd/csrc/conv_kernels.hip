@@ -534,7 +534,7 @@ static int env_int(const char* name, int dflt);
 int conv_bn(const ConvArgs& a) {
   if (a.nseg > 0) return 128;                     // the K-concatenated kernel exists for 128-wide tiles only
   if (a.N <= 64) return 64;
-  static const int thr = env_int("EOSVOS_TUNE_BN64_TILES", 256), kthr = env_int("EOSVOS_TUNE_BN64_KSTEPS", 40);
+  static const int thr = env_int("EOSVOS_TUNE_BN64_TILES", 256), kthr = env_int("EOSVOS_TUNE_BN64_KSTEPS", 16);      // (40 until the streaming kernels took the short-K launches; re-measured: 4.55 -> 4.50 ms)
   static const int kthr_anyb = env_int("EOSVOS_TUNE_BN64_ANYB_KSTEPS", 0);     // experiment: the rule at any batch for K steps <= this
   if (thr > 0 && conv_mfma_mode() == 2 && !a.plane_rows) {
     const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
