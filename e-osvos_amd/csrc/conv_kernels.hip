@@ -2657,7 +2657,7 @@ int conv_plan(ConvArgs& a) {
     // K = 2048 1x1 convs - 5...10 %, the d = 6 ASPP conv 187 -> 140 us; tap-table launches whose tiles keep very different
     // numbers of taps (d = 18: 100 -> 135 us) stay with stream-K, which balances them exactly.
     static const int on = env_int("EOSVOS_TUNE_SPLITK", 1), min_avg = env_int("EOSVOS_TUNE_SPLITK_MINK", 16);
-    static const int min_chunk = env_int("EOSVOS_TUNE_SPLITK_MINCHUNK", 12), min_fill = env_int("EOSVOS_TUNE_SPLITK_MINFILL", 85);
+    static const int min_chunk = env_int("EOSVOS_TUNE_SPLITK_MINCHUNK", 12), min_fill = env_int("EOSVOS_TUNE_SPLITK_MINFILL", 60);      // (85 in round 3; re-measured in round 4: batch 1 4.50 -> 4.46 ms, batch 3 +-0)
     const bool even_taps = a.total_units <= 0 || a.total_units * 100 >= 85L * tiles * ksteps;
     const long budget = conv_wg_budget(a.wg_budget);
     const long avg = a.total_units > 0 ? a.total_units / tiles : ksteps;
