@@ -270,6 +270,7 @@ struct eosvos_engine {
   long fwd_epoch = 0, bwd_epoch = 0;
   bool w_amax_valid = false;         // W slots match the current weights
   long us_zero_epoch = -1;           // forward epoch whose start zeroed the U / US slots of the stale Winograd weights
+  long* mt_rbase = nullptr; int* mt_rlen = nullptr; long* mt_toff = nullptr; int2* mt_tit = nullptr; int mt_nent = 0;   // ensure_meta_tabs
   long* amax_w_off = nullptr;        // device tables of launch_absmax_segments over the parameter arena
   int* amax_w_n = nullptr;
   std::vector<char> ks_amax_valid;   // KS slots match the current norm scales
@@ -1566,7 +1567,41 @@ static void import_params(eosvos_engine* e, const float* flat, float* dst) {
     if (c.bias) (void)hipMemcpyAsync(dst + c.poff + c.wsize(), flat + c.poff + c.wsize(), c.cout * 4, hipMemcpyDeviceToDevice, e->s);
   }
 }
+// device tables of the one-launch forms (meta path): per lr row its element range in the arena, per tensor its offset / shape
+static int ensure_meta_tabs(eosvos_engine* e) {
+  if (e->mt_rbase) return 0;
+  const Topo& t = e->t;
+  std::vector<long> rbase((size_t)t.nlr), toff;
+  std::vector<int> rlen((size_t)t.nlr);
+  std::vector<int2> tit;
+  for (const ConvL& c : t.convs) {
+    const long rowlen = (long)c.T() * c.cin;
+    for (int r = 0; r < c.cout; ++r) { rbase[c.lroff + r] = (long)c.poff + r * rowlen; rlen[c.lroff + r] = (int)rowlen; }
+    toff.push_back((long)c.poff); tit.push_back(make_int2(c.cin, c.T()));
+    if (c.bias) {
+      for (int r = 0; r < c.cout; ++r) { rbase[c.lroff + c.cout + r] = (long)c.poff + c.wsize() + r; rlen[c.lroff + c.cout + r] = 1; }
+      toff.push_back((long)c.poff + c.wsize()); tit.push_back(make_int2(1, 1));
+    }
+  }
+  if (toff.size() > 160) return fail("internal: more than 160 trainable tensors");
+  e->mt_nent = (int)toff.size();
+  e->mt_rbase = (long*)e->falloc((int64_t)t.nlr * 2);
+  e->mt_rlen = (int*)e->falloc(t.nlr);
+  e->mt_toff = (long*)e->falloc((int64_t)toff.size() * 2);
+  e->mt_tit = (int2*)e->falloc((int64_t)tit.size() * 2);
+  if (!e->mt_rbase || !e->mt_rlen || !e->mt_toff || !e->mt_tit) return fail("hipMalloc meta tables");
+  HIPOK(hipMemcpy(e->mt_rbase, rbase.data(), rbase.size() * sizeof(long), hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->mt_rlen, rlen.data(), rlen.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->mt_toff, toff.data(), toff.size() * sizeof(long), hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->mt_tit, tit.data(), tit.size() * sizeof(int2), hipMemcpyHostToDevice));
+  return 0;
+}
 static void export_params(eosvos_engine* e, const float* src, float* flat, float alpha, int add) {
+  static const bool one = getenv("EOSVOS_TUNE_NO_META_BATCHED") == nullptr;
+  if (one && !ensure_meta_tabs(e)) {                  // one launch for the whole arena (64 before)
+    launch_ohwi_to_oihw_all(src, flat, e->mt_toff, e->mt_tit, e->mt_nent, e->t.nparam, alpha, add, e->s);
+    return;
+  }
   for (const ConvL& c : e->t.convs) {
     launch_ohwi_to_oihw(src + c.poff, flat + c.poff, c.cout, c.cin, c.T(), alpha, add, e->s);
     if (c.bias) launch_ohwi_to_oihw(src + c.poff + c.wsize(), flat + c.poff + c.wsize(), c.cout, 1, 1, alpha, add, e->s);
@@ -2194,11 +2229,16 @@ int eosvos_meta_grad_ex(eosvos_engine* e, const float* images, const float* mask
       if (ensure_lr_maps(e)) return 1;
       HIPOK(hipMemsetAsync(e->glr_tmp, 0, (size_t)t.nlr * 4, e->s));
     }
-    for (const ConvL& c : t.convs) {
-      launch_meta_lr_grad(e->gsum + c.poff, e->gout + c.poff, gl + c.lroff, c.cout, (int64_t)c.T() * c.cin, weight, e->s);
-      if (c.bias)
-        launch_meta_lr_grad(e->gsum + c.poff + c.wsize(), e->gout + c.poff + c.wsize(), gl + c.lroff + c.cout,
-                            c.cout, 1, weight, e->s);
+    static const bool one = getenv("EOSVOS_TUNE_NO_META_BATCHED") == nullptr;
+    if (one && !ensure_meta_tabs(e)) {                // every tensor's rows in one launch (64 before)
+      launch_meta_lr_grad_all(e->gsum, e->gout, gl, e->mt_rbase, e->mt_rlen, (int)t.nlr, weight, e->s);
+    } else {
+      for (const ConvL& c : t.convs) {
+        launch_meta_lr_grad(e->gsum + c.poff, e->gout + c.poff, gl + c.lroff, c.cout, (int64_t)c.T() * c.cin, weight, e->s);
+        if (c.bias)
+          launch_meta_lr_grad(e->gsum + c.poff + c.wsize(), e->gout + c.poff + c.wsize(), gl + c.lroff + c.cout,
+                              c.cout, 1, weight, e->s);
+      }
     }
     if (e->lr_level == EOSVOS_LR_NEURON) {
       if (!direct) launch_lr_grad_neuron(gl, e->lr, flat_meta_grad, (int)t.nlr, e->lr_log, e->s);

@@ -364,6 +364,10 @@ void launch_lr_grad_neuron(const float* g, const float* lr, float* out, int n, i
 void launch_meta_lr_grad_elem(const float* gsum, const float* G, const float* lr_elem, float* out, int64_t n,
                               hipStream_t s);
 // g_lr[c] += -sum_row(gsum*G) ;  (G itself is exported by launch_ohwi_to_oihw with add=1)
+void launch_meta_lr_grad_all(const float* gsum, const float* G, float* glr, const long* rbase, const int* rlen, int rows,
+                             float weight, hipStream_t s);      // every tensor's rows in one launch
+void launch_ohwi_to_oihw_all(const float* src, float* dst, const long* toff, const int2* tit, int nent, int64_t n, float alpha,
+                             int add, hipStream_t s);           // the whole arena in one launch
 void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen, float weight,
                          hipStream_t s);
 void launch_radam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float wd,

@@ -94,6 +94,35 @@ void launch_ohwi_to_oihw(const float* src, float* dst, int O, int I, int T, floa
   hipLaunchKernelGGL(ohwi_to_oihw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, O, I, T, alpha,
                      add);
 }
+// every tensor of the arena in one launch: ent[k] = {offset, I, T, 0} of tensor k (biases: I = T = 1), sorted by offset;
+// an element finds its tensor by binary search in LDS
+__global__ __launch_bounds__(256) void ohwi_to_oihw_all_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                const long* __restrict__ toff, const int2* __restrict__ tit,
+                                                                int nent, long n, float alpha, int add) {
+  __shared__ long s_off[160];
+  __shared__ int2 s_it[160];
+  for (int i = threadIdx.x; i < nent; i += 256) { s_off[i] = toff[i]; s_it[i] = tit[i]; }
+  __syncthreads();
+  GRID_STRIDE(e, n) {   // e indexes dst (flat OIHW order of every tensor)
+    int lo = 0, hi = nent - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (e >= s_off[mid]) lo = mid; else hi = mid - 1;
+    }
+    const long r = e - s_off[lo];
+    const int I = s_it[lo].x, T = s_it[lo].y;
+    const int t = (int)(r % T);
+    const int i = (int)((r / T) % I);
+    const long o = r / ((long)I * T);
+    const float v = alpha * src[s_off[lo] + (o * T + t) * I + i];
+    dst[e] = add ? dst[e] + v : v;
+  }
+}
+void launch_ohwi_to_oihw_all(const float* src, float* dst, const long* toff, const int2* tit, int nent, int64_t n, float alpha,
+                             int add, hipStream_t s) {
+  hipLaunchKernelGGL(ohwi_to_oihw_all_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, s, src, dst, toff, tit, nent, (long)n,
+                     alpha, add);
+}
 
 __global__ void fold_norm_kernel(const float* g, const float* be, const float* mu, const float* var,
                                  float eps, float* a, float* b, long n) {
@@ -821,6 +850,23 @@ __global__ __launch_bounds__(256) void meta_lr_grad_kernel(const float* __restri
 void launch_meta_lr_grad(const float* gsum, const float* G, float* glr, int rows, int64_t rowlen, float weight,
                          hipStream_t s) {
   hipLaunchKernelGGL(meta_lr_grad_kernel, dim3(rows), dim3(256), 0, s, gsum, G, glr, (long)rowlen, weight);
+}
+// the same for every trainable tensor in one launch: row r of the per-neuron lr vector covers elements
+// [rbase[r], rbase[r] + rlen[r]) of the parameter arena (one launch per tensor before: 64 launches of ~6 us per meta task)
+__global__ __launch_bounds__(256) void meta_lr_grad_all_kernel(const float* __restrict__ gsum, const float* __restrict__ G,
+                                                                float* __restrict__ glr, const long* __restrict__ rbase,
+                                                                const int* __restrict__ rlen, float weight) {
+  __shared__ float sh[4];
+  const long base = rbase[blockIdx.x];
+  const long rowlen = rlen[blockIdx.x];
+  float s = 0.f;
+  for (long e = threadIdx.x; e < rowlen; e += 256) s = fmaf(gsum[base + e], G[base + e], s);
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) glr[blockIdx.x] -= weight * s;
+}
+void launch_meta_lr_grad_all(const float* gsum, const float* G, float* glr, const long* rbase, const int* rlen, int rows,
+                             float weight, hipStream_t s) {
+  hipLaunchKernelGGL(meta_lr_grad_all_kernel, dim3(rows), dim3(256), 0, s, gsum, G, glr, rbase, rlen, weight);
 }
 
 // ---- RAdam (radam.py:28-94) -----------------------------------------------------------------------------
