@@ -9,7 +9,7 @@ f = glob.glob("gpurun_out/mp/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total kernel ms", round(tot / 1e6, 2))
-for r in rows[:30]:
+for r in sorted(rows, key=lambda r: -int(r["Calls"]))[:40]:
     print("%-72s %7s %9.2f ms %5.1f%%" % (r["Name"][:72], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"])))
 d = json.loads(open("gpurun_out/meta_tpr%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
 print("tasks/s", d["value"], "ms per meta-iteration", d["ms_per_step"])
