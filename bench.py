@@ -61,6 +61,11 @@ def matrix_peak(mode):
     return BF16_DENSE_PEAK / MFMAS_PER_FMA[mode] if mode in MFMAS_PER_FMA else FP32_MATRIX_PEAK
 
 
+def mode_of(eng, engine_mod):
+    """The matrix mode this engine's launches run in (its own if the range guard or a caller gave it one, else the process's)."""
+    return eng.matrix_mode if hasattr(eng, 'matrix_mode') else engine_mod.get_matrix_mode()
+
+
 def dtype_name(mode):
     """fp32 tensors / accumulators throughout; the split the contractions run in is part of the name."""
     return f'f32 ({mode} split)' if mode in MFMAS_PER_FMA else 'f32'
@@ -275,10 +280,14 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, m
     RAdam step + lr clamp on every rank."""
     tpr = a.tasks_per_rank
     mt, step, losses, extra = meta_setup(eng, dist, world, rank, sd, lrs, dev, tpr, engine_factory)
-    for _ in range(a.warmup):
-        step()
+    for _ in range(max(a.warmup, 1)):
+        step()                                                                  # (the collective range-guard verdict falls in the first)
+    from eosvos_amd import engine as engine_mod
+    mode = mode_of(mt.eng, engine_mod)                                           # the mode the timed meta-iterations run in
     dt, samples = timed_median(step, a.steps, barrier, dist, dev)
     ms_per_step = 1e3 * dt / a.steps
+    if mode_of(mt.eng, engine_mod) != mode:
+        raise SystemExit(f'bench.py: the matrix mode changed inside the timed region ({mode} -> {mode_of(mt.eng, engine_mod)})')
     mt.profile = {}
     for _ in range(2):
         step()                                                                  # all-reduce / outer-step split (drains the GPU per phase)
@@ -303,7 +312,7 @@ def bench_meta(a, eng, dist, rank, world, sd, lrs, x, y, xg, yg, barrier, dev, m
                        'meta_batch_size': world * tpr, 'tasks_per_rank': tpr, 'inner_steps': 5, 'height': H, 'width': W,
                        'parallelism': f'tasks sharded x{world}'},
             'roofline': roof, 'cpu_baseline': cpu,
-            'extra': {'last_meta_loss': losses[-1], 'matrix_mode': mode, 'lib_version': lib_version,
+            'extra': {'last_meta_loss': losses[-1], 'matrix_mode': mode, 'guard_log': [list(g) for g in engine_mod.GUARD_LOG], 'lib_version': lib_version,
                       'timed_region_samples_s': samples, 'phase_ms_per_meta_iteration': split},
         }
         print(json.dumps(out), flush=True)
@@ -380,12 +389,18 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
                           engine_factory or Engine)
 
     step = lambda: eng.finetune_step(xg, yg, sync_loss=False)
-    for _ in range(a.warmup):
-        step()
+    for _ in range(max(a.warmup, 1)):
+        step()                                       # (the f16x3 range guard looks at the first step after the state load)
+    # the mode the TIMED steps run in: read after the warm-up, in which the guard may have moved the engine to bf16x6
+    mode = mode_of(eng, engine_mod)
+    guard_log0 = list(engine_mod.GUARD_LOG)
     dt, samples = timed_median(step, a.steps, barrier, dist, dev)
     ms_per_step = 1e3 * dt / a.steps
     value = world * a.steps / dt
     last_loss = eng.finetune_step(xg, yg)           # sanity: still finite after K steps
+    if mode_of(eng, engine_mod) != mode or list(engine_mod.GUARD_LOG) != guard_log0:
+        raise SystemExit(f'bench.py: the matrix mode changed inside the timed region ({mode} -> {mode_of(eng, engine_mod)}, guard log '
+                         f'{engine_mod.GUARD_LOG}): the line would name a mode it did not time')
     # `value` is the EXACT K steps the caller asked for (median of 3 when K < 100); a short K is a 0.2 s region, so the same
     # step is also timed over >= 100 steps (one region, about 2 s) and both are reported
     long_run = None
@@ -422,7 +437,9 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
                 'avg_launch_us': 1e3 * ms1 / l1, 'ms_per_step': 1e3 * s1,
                 'all_matrix_kernels_tflops': sum(v[2] for v in mf1.values()) / (sum(v[1] for v in mf1.values()) * 1e-3) / 1e12}
 
-    extra = {'last_loss': last_loss, 'matrix_mode': mode, 'lib_version': lib_version, 'timed_region_samples_s': samples,
+    extra = {'last_loss': last_loss, 'matrix_mode': mode, 'matrix_mode_read': 'after the warm-up steps (the range guard runs in the first)',
+             'guard_log': [list(g) for g in engine_mod.GUARD_LOG], 'guard_enabled': engine_mod._guard_enabled(),
+             'lib_version': lib_version, 'timed_region_samples_s': samples,
              'mfma_probe_fp32_tflops': eng.mfma_probe(),
              'direct_conv_equivalent_tflops': BATCH * FLOPS_PER_FRAME_ITER / (ms_per_step * 1e-3) / 1e12,
              'conv_algorithms': 'fp32 tensors throughout; contractions on the 16-bit matrix cores: f16x3 = per-tensor power-of-two '
@@ -526,11 +543,17 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         for other, key in (('bf16x6', 'bf16x6_mode_ms_per_step'), ('f32', 'fp32_mfma_mode_ms_per_step')):
             if other == mode:
                 continue
-            engine_mod.set_matrix_mode(other)
+            if hasattr(eng, 'set_engine_matrix_mode'):
+                eng.set_engine_matrix_mode(other)
+            else:
+                engine_mod.set_matrix_mode(other)
             for _ in range(3):
                 step()
             dto = timed(step, min(a.steps, 30), barrier, dist, dev)
-            engine_mod.set_matrix_mode(mode)
+            if hasattr(eng, 'set_engine_matrix_mode'):
+                eng.set_engine_matrix_mode(None if mode == engine_mod.get_matrix_mode() else mode)
+            else:
+                engine_mod.set_matrix_mode(mode)
             eng.reset()
             extra[key] = 1e3 * dto / min(a.steps, 30)
             configs['bf16x6_ms' if other == 'bf16x6' else 'fp32_mfma_ms'] = extra[key]
@@ -558,9 +581,32 @@ def main(argv=None, engine_factory=None, device=None, backend='nccl'):
         configs['iters_per_sec_3_objects_in_flight'] = extra['finetune_iters_per_sec_3_objects_in_flight']
         for e2 in others:
             e2.close()
+    if not a.no_ab and world == 1 and torch.cuda.is_available() and engine_factory is None:
+        # GroupNorm(16) mode -- what the reference's shipped config selects (`cfgs/meta.yaml:76`,
+        # `networks/deeplabv3plus.py:180-191`): the same iteration with GN statistics / apply / backward kernels instead of the
+        # frozen-BN epilogues.  Not the headline (north_star names the frozen-BN path).
+        try:
+            eg = Engine('resnet50', H, W, max_batch=BATCH, device=dev, norm='gn')
+            eg.load_model_state(sd, lrs)
+            for key, nb in (('gn_b3_ms', BATCH), ('gn_b1_ms', 1)):
+                stepg = lambda: eg.finetune_step(xg[:nb], yg[:nb], sync_loss=False)
+                for _ in range(3):
+                    stepg()
+                ng = min(a.steps, 30)
+                dtg = timed(stepg, ng, barrier, dist, dev)
+                configs[key] = 1e3 * dtg / ng
+                eg.reset()
+            configs['gn_matrix_mode'] = mode_of(eg, engine_mod)
+            extra['groupnorm_mode'] = {'b3_ms_per_step': configs['gn_b3_ms'], 'b1_ms_per_step': configs['gn_b1_ms'],
+                                       'vs_frozen_bn_b3': configs['gn_b3_ms'] / ms_per_step, 'matrix_mode': configs['gn_matrix_mode']}
+            eg.close()
+        except Exception as exc:                                                # noqa: BLE001
+            configs['gn_error'] = f'{type(exc).__name__}: {exc}'
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_finetune(sd, lrs, x, y)
+    if mode_of(eng, engine_mod) != mode:
+        raise SystemExit(f'bench.py: the headline engine left the matrix mode it was timed in ({mode} -> {mode_of(eng, engine_mod)})')
     if rank == 0:
         out = {
             'metric': 'finetune_iters_per_sec', 'value': value, 'unit': 'finetune_iters/s', 'n_gpus': world,

@@ -19,6 +19,8 @@ _SIGNATURES = {
     'eosvos_last_error': (ctypes.c_char_p, []),
     'eosvos_set_matrix_mode': (ctypes.c_int, [ctypes.c_int]),
     'eosvos_get_matrix_mode': (ctypes.c_int, []),
+    'eosvos_set_engine_matrix_mode': (ctypes.c_int, [_E, ctypes.c_int]),
+    'eosvos_get_engine_matrix_mode': (ctypes.c_int, [_E]),
     'eosvos_set_wg_budget': (ctypes.c_int, [_E, ctypes.c_int]),
     'eosvos_set_side_stream': (ctypes.c_int, [_E, ctypes.c_int]),
     'eosvos_set_launch_budget': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),

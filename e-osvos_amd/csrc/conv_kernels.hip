@@ -1931,8 +1931,11 @@ static void launch_stream1x1(ConvArgs& a, hipStream_t s) {
 // Same structure as the streaming 1x1 kernel: the whole 64 x 147 weight panel lives in LDS as its two fp16 pieces (split
 // once per workgroup; its absmax is taken while it is staged), each wave streams strips of 16 output pixels, D = W_frag *
 // patch_frag^T, so a lane ends with 4 consecutive channels of one pixel.  K order: 24 slots of 8 values, slot s = 3 ky + part
-// holds floats [8 part, 8 part + 8) of the 21-float patch row ky (floats 21 ... 23 of a row belong to the next pixel and meet
-// zero weights; slots 21 ... 23 are not loaded): a lane's 8 k values are 32 contiguous, 8-byte aligned bytes of the frame.
+// holds floats [8 part, 8 part + 8) of the 21-float patch row ky (floats 21 ... 23 of a row belong to the next pixel -- or, for
+// the last pixel of an odd x odd frame, lie past the frame in the allocation's zeroed 8-float tail; they meet zero weights
+// AND are zeroed after the load: a stale value above 2 x the frame's absmax would become inf in fp16 and inf x 0 = NaN, which
+// the ReLU turned into 0 -- round 5, the 1 x 97 x 163 guard trip; slots 21 ... 23 are not loaded): a lane's 8 k values are 32
+// contiguous bytes of the frame, 8-byte aligned for even padded widths only (odd widths: 4-byte aligned dwordx2 loads).
 // The VALU kernel (misc_kernels.hip) took 93 us at batch 3 -- 5.8 GFLOP of fp32 FMAs; the output (79 MB) bounds this one.
 // ---------------------------------------------------------------------------------------
 #define STEM_SLOTS 24
@@ -1997,10 +2000,12 @@ __global__ __launch_bounds__(512) void stem_fwd_h3_kernel(const float* __restric
   const long nstrips = (P + 15) / 16;
   // this lane's slot of each K step: offset inside the frame relative to the pixel's patch origin; < 0: an empty slot
   int koff[6];
+  int ktail = 0;                                  // bit ks: this lane's slot of K step ks is the third of a patch row
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) {
     const int sl = ks * 4 + fq;
     koff[ks] = sl < 21 ? (sl / 3) * Wp * 3 + (sl % 3) * 8 : -1;
+    if (sl < 21 && sl % 3 == 2) ktail |= 1 << ks;
   }
   float2 xr[6][4];
   auto load_x = [&](long strip) {
@@ -2014,6 +2019,7 @@ __global__ __launch_bounds__(512) void stem_fwd_h3_kernel(const float* __restric
         const float2* q = reinterpret_cast<const float2*>(base + koff[ks]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) xr[ks][t] = q[t];
+        if (ktail & (1 << ks)) { xr[ks][2].y = 0.f; xr[ks][3] = make_float2(0.f, 0.f); }      // floats 21 ... 23 of the patch row
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) xr[ks][t] = make_float2(0.f, 0.f);
@@ -2464,7 +2470,11 @@ static int env_int(const char* name, int dflt) {
   return (v && v[0]) ? atoi(v) : dflt;
 }
 static int g_mfma_mode = -1;
+static thread_local int tl_mfma_mode = -1;          // an engine with a mode of its own, for the duration of one C-ABI call
+void conv_set_thread_mfma_mode(int mode) { tl_mfma_mode = mode < 0 ? -1 : (mode == 2 ? 2 : (mode ? 1 : 0)); }
+int conv_thread_mfma_mode() { return tl_mfma_mode; }
 int conv_mfma_mode() {
+  if (tl_mfma_mode >= 0) return tl_mfma_mode;
   if (g_mfma_mode < 0) {
     const char* v = getenv("EOSVOS_MFMA");
     g_mfma_mode = (v && !strcmp(v, "f32")) ? 0 : (v && !strcmp(v, "bf16x6")) ? 1 : 2;

@@ -261,6 +261,7 @@ struct eosvos_engine {
     auto it = tuned_budget.find(((long)ci * 4 + kind) * 64 + B);
     return it == tuned_budget.end() ? wg_budget : it->second;
   }
+  int mode = -1;                      // eosvos_set_engine_matrix_mode: this engine's own matrix mode (-1: follow the process-wide one)
   int plan_mode = -1;                 // matrix mode the cached launch plans (wg_plans, upd_tab) were built for, see plans_match_mode()
 
   // f16x3 matrix mode: absmax slots (bit patterns of max|x|), kind-major [AM_KINDS][nconv]; see amax_get()
@@ -312,6 +313,10 @@ struct eosvos_engine {
       return (float*)p + GUARD;
     }
     if (hipMalloc(&p, (size_t)n * sizeof(float)) != hipSuccess) return nullptr;
+    // EOSVOS_DEBUG_FILL=<hex word>: every buffer starts out filled with that word instead of whatever the allocator hands
+    // back (zero pages in a fresh process, a closed engine's data later) -- exposes reads of memory nothing wrote
+    static const char* fill = getenv("EOSVOS_DEBUG_FILL");
+    if (fill) { (void)hipMemsetD32((hipDeviceptr_t)p, (int)strtoul(fill, nullptr, 16), (size_t)n); (void)hipDeviceSynchronize(); }
     allocs.push_back(p);
     return (float*)p;
   }
@@ -355,6 +360,16 @@ inline size_t amax_tcol(const eosvos_engine* e, int phase, int idx) {
 // zero the slots [first, first + count) (all their words)
 inline void amax_zero(unsigned* first, size_t count, hipStream_t st) { launch_amax_zero(first, (int)count, st); }
 inline bool h3_mode() { return conv_mfma_mode() == 2; }
+// An engine with a matrix mode of its own (the range guard's fallback concerns the engine whose state tripped it, not the
+// process): every C-ABI call that plans or launches contractions runs under that mode on the calling thread.
+struct ModeScope {
+  int prev;
+  bool on;
+  explicit ModeScope(const eosvos_engine* e) : prev(conv_thread_mfma_mode()), on(e && e->mode >= 0) { if (on) conv_set_thread_mfma_mode(e->mode); }
+  ~ModeScope() { if (on) conv_set_thread_mfma_mode(prev); }
+  ModeScope(const ModeScope&) = delete;
+  ModeScope& operator=(const ModeScope&) = delete;
+};
 int amax_init(eosvos_engine* e) {
   if (e->amax) return 0;
   const size_t n = (size_t)AM_KINDS * e->t.convs.size() + 2 * eosvos_engine::TSLOTS;
@@ -1214,6 +1229,16 @@ int eosvos_set_matrix_mode(int mode) {
   return 0;
 }
 int eosvos_get_matrix_mode(void) { return conv_mfma_mode(); }
+int eosvos_set_engine_matrix_mode(eosvos_engine* e, int mode) {
+  if (!e) return fail("null engine");
+  if (mode != -1 && mode != EOSVOS_MATRIX_F32 && mode != EOSVOS_MATRIX_BF16X6 && mode != EOSVOS_MATRIX_F16X3) return fail("unknown matrix mode");
+  e->mode = mode;
+  return 0;
+}
+int eosvos_get_engine_matrix_mode(eosvos_engine* e) {
+  if (!e) { fail("null engine"); return -1; }
+  return e->mode >= 0 ? e->mode : conv_mfma_mode();
+}
 int eosvos_set_wg_budget(eosvos_engine* e, int workgroups) {
   if (!e) { fail("null engine"); return -1; }
   if (workgroups < 0) { fail("workgroup budget must be >= 0"); return -1; }
@@ -1321,8 +1346,8 @@ int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, i
   ALLOC(e->Wp, t.nparam); ALLOC(e->Winit, t.nparam); ALLOC(e->Wsnap, t.nparam);
   ALLOC(e->gout, t.nparam); ALLOC(e->stage, t.nparam);
   ALLOC(e->lr, t.nlr); ALLOC(e->na, t.nnorm); ALLOC(e->nb, t.nnorm);
-  ALLOC(e->xpad, (int64_t)B * (H + 6) * (W + 6) * 3 + 8);      // + 8: the matrix-core stem reads whole 8-float slots (odd widths: 2 floats past a row)
-  HIPOK(hipMemset(e->xpad, 0, (size_t)B * (H + 6) * (W + 6) * 3 * 4));
+  ALLOC(e->xpad, (int64_t)B * (H + 6) * (W + 6) * 3 + 8);      // + 8: the matrix-core stem reads whole 8-float slots (odd x odd frames: 3 floats past the last row)
+  HIPOK(hipMemset(e->xpad, 0, ((size_t)B * (H + 6) * (W + 6) * 3 + 8) * 4));      // the tail too: nothing ever writes it
   HIPOK(hipMemset(e->Wp, 0, (size_t)t.nparam * 4));
   HIPOK(hipMemset(e->Winit, 0, (size_t)t.nparam * 4));
   HIPOK(hipMemset(e->lr, 0, (size_t)t.nlr * 4));
@@ -1609,6 +1634,7 @@ static void export_params(eosvos_engine* e, const float* src, float* flat, float
 }
 
 int eosvos_set_init(eosvos_engine* e, const float* flat_params) {
+  ModeScope mode_scope(e);
   if (!e || !flat_params) return fail("null argument");
   wino_weights_changed(e);
   import_params(e, flat_params, e->Winit);
@@ -1617,6 +1643,7 @@ int eosvos_set_init(eosvos_engine* e, const float* flat_params) {
   return 0;
 }
 int eosvos_set_lr(eosvos_engine* e, const float* flat_lr) {
+  ModeScope mode_scope(e);
   if (!e || !flat_lr) return fail("null argument");
   HIPOK(hipMemcpyAsync(e->lr, flat_lr, (size_t)e->t.nlr * 4, hipMemcpyDeviceToDevice, e->s));
   e->lr_level = EOSVOS_LR_NEURON; e->lr_log = 0;
@@ -1667,6 +1694,7 @@ static int ensure_lr_maps(eosvos_engine* e) {
   return 0;
 }
 int eosvos_set_lr_state(eosvos_engine* e, int level, int use_log, const float* store) {
+  ModeScope mode_scope(e);
   if (!e || !store) return fail("null argument");
   if (lr_store_count(e->t, level) < 0) return fail("unknown lr hierarchy level");
   if (ensure_lr_maps(e)) return 1;
@@ -1687,6 +1715,7 @@ int eosvos_set_lr_state(eosvos_engine* e, int level, int use_log, const float* s
 }
 int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, const float* mean,
                     const float* var, float eps) {
+  ModeScope mode_scope(e);
   if (!e || !gamma || !beta || !mean || !var) return fail("null argument");
   wino_weights_changed(e);
   std::fill(e->ks_amax_valid.begin(), e->ks_amax_valid.end(), 0);
@@ -1700,18 +1729,21 @@ int eosvos_set_norm(eosvos_engine* e, const float* gamma, const float* beta, con
   return 0;
 }
 int eosvos_reset(eosvos_engine* e) {
+  ModeScope mode_scope(e);
   if (!e) return fail("null engine");
   wino_weights_changed(e);
   HIPOK(hipMemcpyAsync(e->Wp, e->Winit, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
   return 0;
 }
 int eosvos_get_params(eosvos_engine* e, float* out) {
+  ModeScope mode_scope(e);
   if (!e || !out) return fail("null argument");
   export_params(e, e->Wp, out, 1.f, 0);
   HIPOK(hipGetLastError());
   return 0;
 }
 int eosvos_set_params(eosvos_engine* e, const float* flat) {
+  ModeScope mode_scope(e);
   if (!e || !flat) return fail("null argument");
   wino_weights_changed(e);
   import_params(e, flat, e->Wp);
@@ -1719,11 +1751,13 @@ int eosvos_set_params(eosvos_engine* e, const float* flat) {
   return 0;
 }
 int eosvos_snapshot_params(eosvos_engine* e) {
+  ModeScope mode_scope(e);
   if (!e) return fail("null engine");
   HIPOK(hipMemcpyAsync(e->Wsnap, e->Wp, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
   return 0;
 }
 int eosvos_restore_params(eosvos_engine* e) {
+  ModeScope mode_scope(e);
   if (!e) return fail("null engine");
   wino_weights_changed(e);
   HIPOK(hipMemcpyAsync(e->Wp, e->Wsnap, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice, e->s));
@@ -2036,6 +2070,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
 }
 
 int eosvos_forward(eosvos_engine* e, const float* images, int batch, float* logits_out) {
+  ModeScope mode_scope(e);
   if (!e || !images) return fail("null argument");
   if (batch < 1 || batch > e->maxB) return fail("batch out of range");
   if (forward_impl(e, images, batch)) return 1;
@@ -2044,6 +2079,7 @@ int eosvos_forward(eosvos_engine* e, const float* images, int batch, float* logi
   return 0;
 }
 int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss_out) {
+  ModeScope mode_scope(e);
   if (!e || !masks) return fail("null argument");
   if (batch != e->lastB) return fail("loss batch differs from the last forward");
   launch_bce(e->logits, masks, e->dlogits, e->loss_dev, e->bce_partial, (int64_t)batch * e->H * e->W, e->s);
@@ -2053,6 +2089,7 @@ int eosvos_loss_bce(eosvos_engine* e, const float* masks, int batch, float* loss
   return 0;
 }
 int eosvos_loss(eosvos_engine* e, int kind, const float* masks, int batch, float* loss_out) {
+  ModeScope mode_scope(e);
   if (kind == EOSVOS_LOSS_BCE) return eosvos_loss_bce(e, masks, batch, loss_out);
   if (!e || !masks) return fail("null argument");
   if (kind != EOSVOS_LOSS_DICE && kind != EOSVOS_LOSS_BCE_DICE && kind != EOSVOS_LOSS_CLASS_BALANCED_BCE)
@@ -2077,6 +2114,7 @@ int eosvos_set_loss(eosvos_engine* e, int kind) {
 }
 int eosvos_bce(eosvos_engine* e, const float* logits, const float* masks, int64_t n, float* loss_out,
                float* dlogits_out) {
+  ModeScope mode_scope(e);
   if (!e || !logits || !masks || !loss_out || n < 1) return fail("bad argument");
   if (!dlogits_out && n > (int64_t)e->maxB * e->H * e->W) return fail("n exceeds the engine's scratch");
   // without a caller buffer the gradient goes to the engine's own dlogits scratch, which
@@ -2087,6 +2125,7 @@ int eosvos_bce(eosvos_engine* e, const float* logits, const float* masks, int64_
   return 0;
 }
 int eosvos_loss_tensors(eosvos_engine* e, int kind, const float* logits, const float* masks, int64_t n, float* loss_out) {
+  ModeScope mode_scope(e);
   if (kind == EOSVOS_LOSS_BCE) return eosvos_bce(e, logits, masks, n, loss_out, nullptr);
   if (!e || !logits || !masks || !loss_out || n < 1) return fail("bad argument");
   if (kind != EOSVOS_LOSS_DICE && kind != EOSVOS_LOSS_BCE_DICE && kind != EOSVOS_LOSS_CLASS_BALANCED_BCE)
@@ -2098,11 +2137,13 @@ int eosvos_loss_tensors(eosvos_engine* e, int kind, const float* logits, const f
   return 0;
 }
 int eosvos_backward_step(eosvos_engine* e, int accumulate) {
+  ModeScope mode_scope(e);
   if (!e) return fail("null engine");
   return backward_impl(e, true, accumulate != 0);
 }
 int eosvos_finetune_step(eosvos_engine* e, const float* images, const float* masks, int batch, int accumulate,
                          float* loss_host) {
+  ModeScope mode_scope(e);
   if (eosvos_forward(e, images, batch, nullptr)) return 1;
   if (eosvos_loss(e, e->loss_kind, masks, batch, nullptr)) return 1;
   if (backward_impl(e, true, accumulate != 0)) return 1;
@@ -2113,6 +2154,7 @@ int eosvos_finetune_step(eosvos_engine* e, const float* images, const float* mas
   return 0;
 }
 int eosvos_get_grads(eosvos_engine* e, float* out) {
+  ModeScope mode_scope(e);
   if (!e || !out) return fail("null argument");
   if (!e->keep_grads) return fail("gradients are only kept after eosvos_keep_grads(e, 1)");
   export_params(e, e->gout, out, 1.f, 0);
@@ -2126,6 +2168,7 @@ int eosvos_keep_grads(eosvos_engine* e, int on) {
 }
 
 int eosvos_infer(eosvos_engine* e, const float* images, int batch, float* probs_out) {
+  ModeScope mode_scope(e);
   if (!e || !images || !probs_out) return fail("null argument");
   if (batch < 1 || batch > e->maxB) return fail("batch out of range");
   e->fwd_masks = false;                 // inference: nothing will differentiate through this forward
@@ -2146,6 +2189,7 @@ int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t
 // ---- data augmentation on the device (custom_transforms.py:9-92,189-213) --------------------------
 int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int flip, double rot_deg, double scale,
                        int interp, float* dst, int* nonzero_host) {
+  ModeScope mode_scope(e);
   if (!e || !src || !dst || channels < 1) return fail("bad argument");
   if (interp != EOSVOS_INTER_NEAREST && interp != EOSVOS_INTER_CUBIC) return fail("unknown interpolation");
   const int H = e->H, W = e->W;
@@ -2193,6 +2237,7 @@ int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int fli
 }
 
 int eosvos_meta_task_begin(eosvos_engine* e) {
+  ModeScope mode_scope(e);
   if (!e) return fail("null engine");
   if (!e->gsum) {
     e->gsum = e->falloc(e->t.nparam);
@@ -2203,10 +2248,12 @@ int eosvos_meta_task_begin(eosvos_engine* e) {
 }
 int eosvos_meta_grad(eosvos_engine* e, const float* images, const float* masks, int batch, float* flat_meta_grad,
                      float* meta_loss_host) {
+  ModeScope mode_scope(e);
   return eosvos_meta_grad_ex(e, images, masks, batch, flat_meta_grad, meta_loss_host, 1.f, EOSVOS_META_INIT_GRAD);
 }
 int eosvos_meta_grad_ex(eosvos_engine* e, const float* images, const float* masks, int batch, float* flat_meta_grad,
                         float* meta_loss_host, float weight, int flags) {
+  ModeScope mode_scope(e);
   if (!e || !images || !masks || !flat_meta_grad) return fail("null argument");
   if (!e->gsum) return fail("eosvos_meta_grad without eosvos_meta_task_begin");
   if (eosvos_forward(e, images, batch, nullptr)) return 1;
@@ -2262,6 +2309,7 @@ int eosvos_meta_grad_ex(eosvos_engine* e, const float* images, const float* mask
 int eosvos_radam_step(eosvos_engine* e, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                       int64_t n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
                       float grad_scale, float grad_clip) {
+  ModeScope mode_scope(e);
   if (!e || !param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail("bad argument");
   // radam.py:62-79 in double, as the reference's Python floats
   const double b1 = beta1, b2 = beta2;
@@ -2286,6 +2334,7 @@ int eosvos_outer_step(eosvos_engine* e, float* state, float* grad, float* exp_av
                       int learn_model_init, int step, float lr_lr, float init_lr, float weight_decay, float beta1, float beta2,
                       float eps, float grad_scale, float grad_clip, float lr_lo, float lr_hi, int use_log,
                       int64_t frozen_lr, int64_t frozen_param) {
+  ModeScope mode_scope(e);
   if (!e || !state || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail("bad argument");
   const Topo& t = e->t;
   if (n_lr != t.nlr) return fail("eosvos_outer_step handles the NEURON lr hierarchy level only (n_lr must be eosvos_lr_count)");
@@ -2331,6 +2380,7 @@ int eosvos_outer_step(eosvos_engine* e, float* state, float* grad, float* exp_av
   return 0;
 }
 int eosvos_alias_state(eosvos_engine* e, eosvos_engine* src) {
+  ModeScope mode_scope(e);
   if (!e || !src) return fail("null engine");
   if (e == src) return 0;
   if (e->dev != src->dev || e->arch != src->arch) return fail("eosvos_alias_state: engines of different devices / architectures");
@@ -2340,6 +2390,7 @@ int eosvos_alias_state(eosvos_engine* e, eosvos_engine* src) {
   return 0;
 }
 int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi) {
+  ModeScope mode_scope(e);
   if (!e || !param) return fail("null argument");
   launch_clamp(param, n, lo, hi, e->s);
   HIPOK(hipGetLastError());
@@ -2371,6 +2422,7 @@ int eosvos_profile_read(eosvos_engine* e, int max_kernels, char* names, int64_t*
 }
 
 int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host, double* flops_host) {
+  ModeScope mode_scope(e);
   if (!e || !ms_host || !flops_host || batch < 1 || batch > e->maxB || reps < 1) return fail("bad argument");
   const Topo& t = e->t;
   if (t.dec_a < 0) return fail("eosvos_time_hot_kernel times the DeepLabV3+ decoder conv; this topology has none");
@@ -2407,6 +2459,7 @@ int eosvos_time_hot_kernel(eosvos_engine* e, int batch, int reps, float* ms_host
 // Time one layer's forward (kind 0), data-gradient (1) or weight-gradient (2) launch in place,
 // on the engine's own buffers (tuning aid; outputs are overwritten with whatever the buffers hold).
 int eosvos_bench_conv(eosvos_engine* e, int ci, int kind, int batch, int reps, float* ms_host, double* flops_host) {
+  ModeScope mode_scope(e);
   if (!e || !ms_host || !flops_host || batch < 1 || batch > e->maxB || reps < 1) return fail("bad argument");
   const Topo& t = e->t;
   if (ci < 1 || ci >= (int)t.convs.size()) return fail("conv index out of range");
@@ -2465,6 +2518,7 @@ int eosvos_bench_conv(eosvos_engine* e, int ci, int kind, int batch, int reps, f
 }
 
 int eosvos_mfma_probe(eosvos_engine* e, int iters, float* ms_host, double* flops_host) {
+  ModeScope mode_scope(e);
   if (!e || !ms_host || !flops_host || iters < 1) return fail("bad argument");
   hipEvent_t a, b;
   HIPOK(hipEventCreate(&a));
@@ -2578,6 +2632,7 @@ struct ScratchEngine {
 int eosvos_test_conv_algo(eosvos_engine* e, int algo, const float* x, const float* w_oihw, const float* scale,
                           const float* bias, const float* res, int relu, int B, int H, int W, int Cin, int Cout, int k,
                           int stride, int dil, int pad, float* y) {
+  ModeScope mode_scope(e);
   if (!e || !x || !w_oihw || !y) return fail("null argument");
   if (Cin % 4 || Cout % 4) return fail("channels must be multiples of 4");
   if (algo < EOSVOS_ALGO_AUTO || algo > EOSVOS_ALGO_WINO_F4) return fail("unknown conv algorithm");
@@ -2601,6 +2656,7 @@ int eosvos_test_conv_algo(eosvos_engine* e, int algo, const float* x, const floa
 int eosvos_test_conv_bwd_algo(eosvos_engine* e, int algo, const float* x, const float* w_oihw, const float* g,
                               const float* scale, const float* mask, int B, int H, int W, int Cin, int Cout, int k, int stride,
                               int dil, int pad, float* dx, float* dw_oihw) {
+  ModeScope mode_scope(e);
   if (!e || !x || !w_oihw || !g || !dx || !dw_oihw) return fail("null argument");
   if (Cin % 4 || Cout % 4) return fail("channels must be multiples of 4");
   if (algo < EOSVOS_ALGO_AUTO || algo > EOSVOS_ALGO_WINO_F4) return fail("unknown conv algorithm");
@@ -2627,10 +2683,12 @@ int eosvos_test_conv_bwd_algo(eosvos_engine* e, int algo, const float* x, const 
 int eosvos_test_conv(eosvos_engine* e, const float* x, const float* w_oihw, const float* scale, const float* bias,
                      const float* res, int relu, int B, int H, int W, int Cin, int Cout, int k, int stride, int dil,
                      int pad, float* y) {
+  ModeScope mode_scope(e);
   return eosvos_test_conv_algo(e, EOSVOS_ALGO_DIRECT, x, w_oihw, scale, bias, res, relu, B, H, W, Cin, Cout, k, stride, dil, pad, y);
 }
 int eosvos_test_conv_bwd(eosvos_engine* e, const float* x, const float* w_oihw, const float* g, int B, int H, int W,
                          int Cin, int Cout, int k, int stride, int dil, int pad, float* dx, float* dw_oihw) {
+  ModeScope mode_scope(e);
   return eosvos_test_conv_bwd_algo(e, EOSVOS_ALGO_DIRECT, x, w_oihw, g, nullptr, nullptr, B, H, W, Cin, Cout, k, stride, dil, pad, dx,
                                    dw_oihw);
 }

@@ -173,6 +173,8 @@ void launch_conv(ConvArgs& a, hipStream_t s);
 int conv_bn(const ConvArgs& a);      // tile width in N (64 or 128)
 int conv_plan(ConvArgs& a);          // number of workgroups, sets a.per
 void conv_set_mfma_mode(int mode);
+void conv_set_thread_mfma_mode(int mode);   // >= 0: overrides the process-wide mode on this host thread (an engine's own mode, per call); -1: none
+int conv_thread_mfma_mode();
 // per-launch HIP-event timing of the MFMA kernels (conv_kernels.hip)
 void conv_prof_enable(int on);
 int conv_prof_read(int max, const char** names, long* counts, double* ms, double* flops);

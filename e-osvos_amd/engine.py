@@ -34,10 +34,16 @@ def get_matrix_mode():
 
 
 # f16x3 range guard (see Engine.verify_matrix_mode): absolute / relative logit difference against the exact-split mode above
-# which the process falls back to bf16x6.  A tenth of the north_star logit tolerance; measured differences between the two
+# which the ENGINE falls back to bf16x6.  A tenth of the north_star logit tolerance; measured differences between the two
 # modes: 1e-5 on the benign synthetic state, 1e-5 on the heavy-tailed one of fixture G19 (profiles/r04_g19_margins.txt).
 GUARD_ABS_TOL, GUARD_REL_TOL = 1e-4, 1e-4
+# ... and of ONE fine-tune step: relative loss difference, and per trainable tensor max |delta_f16x3 - delta_bf16x6| over
+# max |delta_bf16x6| of the parameter update (= lr * gradient).  Measured between the two modes: loss 2e-7, update <= 3e-4
+# of a tensor's maximum (ReLU-gate flips on the heavy-tailed state, profiles/r04_g19_margins.txt).
+GUARD_LOSS_REL_TOL, GUARD_STEP_TOL = 1e-4, 5e-3
 GUARD_LOG = []                       # (reason, max difference) of every fallback this process took
+_MODE_IDS = {'f32': 0, 'bf16x6': 1, 'f16x3': 2}
+_MODE_NAMES = {v: k for k, v in _MODE_IDS.items()}
 
 
 def _guard_enabled():
@@ -199,50 +205,128 @@ class Engine:
         assert c == 3 and h == self.height and w == self.width and 1 <= b <= self.max_batch, images.shape
         return b
 
-    def verify_matrix_mode(self, images):
+    # ---- matrix mode of this engine / f16x3 range guard -------------------------------------
+    @property
+    def matrix_mode(self):
+        """The mode this engine's contractions run in: its own (`set_engine_matrix_mode`) or the process-wide one."""
+        return _MODE_NAMES[self.lib.eosvos_get_engine_matrix_mode(self.h)]
+
+    def set_engine_matrix_mode(self, mode):
+        """'f16x3' / 'bf16x6' / 'f32' for THIS engine only (`eosvos_set_engine_matrix_mode`); None: follow the process-wide mode."""
+        _ffi.check(self.lib.eosvos_set_engine_matrix_mode(self.h, -1 if mode is None else _MODE_IDS[mode]))
+        self._own_mode = mode
+
+    def _fall_back(self, reason, diff, scale):
+        import warnings
+        self.set_engine_matrix_mode('bf16x6')
+        GUARD_LOG.append((reason, diff))
+        warnings.warn(f'e-osvos_amd: {reason}: {diff:.3g} (scale {scale:.3g}) for this state / input: the dynamic range inside an '
+                      'operand tensor exceeds what one power-of-two scale per tensor covers.  This engine continues in the '
+                      'bf16x6 matrix mode.', RuntimeWarning)
+        return 'bf16x6'
+
+    def verify_matrix_mode(self, images, masks=None, loss_kind=None):
         """Range guard of the default matrix mode.  f16x3 runs every fp32 contraction on the fp16 matrix cores under ONE
         power-of-two scale per operand tensor: elements more than ~2^-18 below their tensor's largest magnitude keep fewer
         bits (absolute error floor 2^-40 of that maximum).  Reference-generated fixtures cover benign and heavy-tailed
-        (BatchNorm statistics over 4-6 decades, G19) states; for anything outside, this check compares the forward pass of
-        the ACTUAL weights / norm statistics / input in f16x3 against the exact-split mode (bf16x6: no range assumption) and,
-        if the logits differ by more than GUARD_ABS_TOL + GUARD_REL_TOL * max|logit| (or are not finite in f16x3 only),
-        switches the PROCESS to bf16x6 (`eosvos_set_matrix_mode`) with a warning.  Runs automatically at the first forward /
-        fine-tune step after new weights or norm statistics were set (EOSVOS_MODE_GUARD=0 disables); costs two extra forward
-        passes per loaded state.  Returns the mode in effect afterwards."""
-        self._verify_pending = False
-        if get_matrix_mode() != 'f16x3':
-            return get_matrix_mode()
+        (BatchNorm statistics over 4-6 decades, G19) states; for anything outside, this check runs the ACTUAL weights / norm
+        statistics / input in f16x3 and in the exact-split mode (bf16x6: no range assumption):
+          * the forward pass: logits must agree to GUARD_ABS_TOL + GUARD_REL_TOL * max|logit| (and be finite in both or neither);
+          * with `masks` (round 5): ONE whole fine-tune step -- loss to GUARD_LOSS_REL_TOL and, per trainable tensor, the
+            parameter update (lr x gradient: the backward pass's operands have the wider dynamic range) to GUARD_STEP_TOL of
+            the tensor's largest update; the weights are put back afterwards.
+        If either differs, THIS ENGINE moves to bf16x6 (`eosvos_set_engine_matrix_mode`; other engines and the process-wide
+        mode are untouched) with a RuntimeWarning and an entry in GUARD_LOG.  Runs automatically at the first forward /
+        fine-tune step after new weights or norm statistics were set (EOSVOS_MODE_GUARD=0 disables); costs two forward passes
+        (+ two steps) per loaded state.  A process group is NOT consulted here (the call is lazy, ranks may differ in how
+        often they get here); `MetaTrainer` makes the decision collective for its ranks.  Returns the mode in effect."""
+        if self.matrix_mode != 'f16x3':
+            self._verify_pending = self._step_check_pending = False
+            return self.matrix_mode
+        own = getattr(self, '_own_mode', None)
         b = self._check_images(images)
         a = torch.empty(b, 1, self.height, self.width, device=self.device)
         ref = torch.empty_like(a)
-        _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(a)))
-        set_matrix_mode('bf16x6')
         try:
+            _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(a)))
+            self.set_engine_matrix_mode('bf16x6')
             _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(ref)))
-            fin_a, fin_r = bool(torch.isfinite(a).all()), bool(torch.isfinite(ref).all())
-            scale = float(ref[torch.isfinite(ref)].abs().max()) if bool(torch.isfinite(ref).any()) else 0.0
-            diff = float((a - ref).abs().max()) if (fin_a and fin_r) else float('inf')
-            bad = (fin_r and not fin_a) or (fin_a and fin_r and diff > GUARD_ABS_TOL + GUARD_REL_TOL * scale)
-        except Exception:
-            set_matrix_mode('f16x3')
-            raise
-        if bad:
-            import warnings
-            GUARD_LOG.append(('f16x3 logits differ from the exact-split mode', diff))
-            warnings.warn(f'e-osvos_amd: f16x3 logits differ from the exact-split mode by {diff:.3g} (scale {scale:.3g}) for this '
-                          'state / input: the dynamic range inside an operand tensor exceeds what one power-of-two scale per '
-                          'tensor covers.  The process continues in the bf16x6 matrix mode.', RuntimeWarning)
-            return 'bf16x6'
-        set_matrix_mode('f16x3')
+        finally:
+            self.set_engine_matrix_mode(own)                 # (an exception leaves the check pending: nothing was decided)
+        self._verify_pending = False
+        fin_a, fin_r = bool(torch.isfinite(a).all()), bool(torch.isfinite(ref).all())
+        scale = float(ref[torch.isfinite(ref)].abs().max()) if bool(torch.isfinite(ref).any()) else 0.0
+        diff = float((a - ref).abs().max()) if (fin_a and fin_r) else float('inf')
+        if (fin_r and not fin_a) or (fin_a and fin_r and diff > GUARD_ABS_TOL + GUARD_REL_TOL * scale):
+            self._step_check_pending = False
+            return self._fall_back('f16x3 logits differ from the exact-split mode', diff, scale)
+        if masks is None:
+            return 'f16x3'
+        return self._verify_step(images, masks, loss_kind)
+
+    def _verify_step(self, images, masks, loss_kind=None):
+        """The fine-tune-step half of the guard (see verify_matrix_mode): one step in each split mode from the same weights."""
+        self._step_check_pending = False
+        own = getattr(self, '_own_mode', None)
+        b = images.shape[0]
+        p0 = self.get_params()
+        got = {}
+        try:
+            for mode in ('f16x3', 'bf16x6'):
+                self.set_engine_matrix_mode(mode)
+                if loss_kind is None:
+                    _ffi.check(self.lib.eosvos_finetune_step(self.h, _ptr(images), _ptr(masks), b, 0, None))
+                else:
+                    _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, None))
+                    _ffi.check(self.lib.eosvos_loss(self.h, LOSS_KINDS[loss_kind], _ptr(masks), b, None))
+                    _ffi.check(self.lib.eosvos_backward_step(self.h, 0))
+                loss = torch.empty(1, device=self.device)
+                _ffi.check(self.lib.eosvos_last_loss(self.h, _ptr(loss)))
+                got[mode] = (loss, self.get_params())
+                _ffi.check(self.lib.eosvos_set_params(self.h, _ptr(p0)))
+        finally:
+            self.set_engine_matrix_mode(own)
+        (la, pa), (lb, pb) = got['f16x3'], got['bf16x6']
+        la, lb = float(la), float(lb)
+        fin_a, fin_b = bool(torch.isfinite(pa).all()) and la == la, bool(torch.isfinite(pb).all()) and lb == lb
+        if fin_b and not fin_a:
+            return self._fall_back('f16x3 fine-tune step is not finite, the exact-split mode\'s is', float('inf'), abs(lb))
+        if not (fin_a and fin_b):
+            return 'f16x3'                                       # not finite in either mode: nothing a mode change repairs
+        if abs(la - lb) > GUARD_LOSS_REL_TOL * max(1.0, abs(lb)):
+            return self._fall_back('f16x3 loss differs from the exact-split mode', abs(la - lb), abs(lb))
+        da, db = pa - p0, pb - p0
+        worst, wscale, off = 0.0, 0.0, 0
+        err = (da - db).abs()
+        for _, shape in trainable(self.encoder):
+            n = 1
+            for d in shape:
+                n *= d
+            m = float(db[off:off + n].abs().max())
+            if m > 0.0:
+                r = float(err[off:off + n].max()) / m
+                if r > worst:
+                    worst, wscale = r, m
+            off += n
+        if worst > GUARD_STEP_TOL:
+            return self._fall_back('f16x3 parameter update differs from the exact-split mode (relative to the tensor\'s largest update)',
+                                   worst, wscale)
         return 'f16x3'
 
-    def _guard(self, images):
+    def _guard(self, images, masks=None, want_step=False):
+        """First forward / step after a state load: the forward half at once; the step half with `masks` (finetune_step) or,
+        for callers that go forward -> loss -> backward_step separately, deferred to backward_step (`_step_check_pending`)."""
         if getattr(self, '_verify_pending', False) and _guard_enabled():
-            self.verify_matrix_mode(images)
+            mode = self.verify_matrix_mode(images, masks)
+            if masks is None and want_step and mode == 'f16x3':
+                self._step_check_pending = True
+                self._chk_images, self._chk_masks, self._chk_kind = images, None, None
 
     def forward(self, images, want_logits=True):
         b = self._check_images(images)
-        self._guard(images)
+        self._guard(images, want_step=True)
+        if getattr(self, '_step_check_pending', False):
+            self._chk_images, self._chk_masks = images, None      # (the forward whose loss / backward_step may follow)
         out = torch.empty(b, 1, self.height, self.width, device=self.device) if want_logits else None
         _ffi.check(self.lib.eosvos_forward(self.h, _ptr(images), b, _ptr(out) if want_logits else None))
         return out
@@ -251,6 +335,8 @@ class Engine:
         assert masks.is_cuda and masks.dtype == torch.float32 and masks.is_contiguous()
         loss = torch.empty(1, device=self.device)
         _ffi.check(self.lib.eosvos_loss_bce(self.h, _ptr(masks), masks.shape[0], _ptr(loss)))
+        if getattr(self, '_step_check_pending', False):
+            self._chk_masks, self._chk_kind = masks, 'cross_entropy'
         return loss
 
     def loss(self, kind, masks):
@@ -259,6 +345,8 @@ class Engine:
         assert masks.is_cuda and masks.dtype == torch.float32 and masks.is_contiguous()
         out = torch.empty(1, device=self.device)
         _ffi.check(self.lib.eosvos_loss(self.h, k, _ptr(masks), masks.shape[0], _ptr(out)))
+        if getattr(self, '_step_check_pending', False):
+            self._chk_masks, self._chk_kind = masks, kind
         return out
 
     def loss_of(self, kind, logits, masks):
@@ -279,13 +367,24 @@ class Engine:
 
     def backward_step(self, accumulate=False):
         self._check_stream()
+        if getattr(self, '_step_check_pending', False):
+            # deferred step half of the range guard (callers that go forward -> loss -> backward_step): one step per split mode
+            # from the current weights, then the forward + loss of THIS step again in the mode that stays
+            x, m, kind = getattr(self, '_chk_images', None), getattr(self, '_chk_masks', None), getattr(self, '_chk_kind', None)
+            self._step_check_pending = False
+            self._chk_images = self._chk_masks = None
+            if not accumulate and x is not None and m is not None and m.shape[0] == x.shape[0] and _guard_enabled():
+                self._verify_step(x, m, kind)
+                _ffi.check(self.lib.eosvos_forward(self.h, _ptr(x), x.shape[0], None))
+                _ffi.check(self.lib.eosvos_loss(self.h, LOSS_KINDS[kind], _ptr(m), m.shape[0], None))
         _ffi.check(self.lib.eosvos_backward_step(self.h, int(accumulate)))
         self.steps_since_reset += 1
 
     def finetune_step(self, images, masks, accumulate=False, sync_loss=True):
         b = self._check_images(images)
         assert masks.is_cuda and masks.is_contiguous() and masks.shape[0] == b
-        self._guard(images)
+        self._guard(images, None if accumulate else masks)      # (a meta task's accumulating steps: the forward half only)
+        self._step_check_pending = False
         self.steps_since_reset += 1
         if sync_loss:
             l = ctypes.c_float()

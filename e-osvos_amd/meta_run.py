@@ -109,6 +109,7 @@ class MetaTrainer:
                 e.set_loss(self.loss_func)
                 e.load_model_state(model_state)
                 e.set_lr_state(self.level, self.use_log, self.state[:self.n_lr])
+        self._mode_check_pending = True      # the first meta-iteration decides the matrix mode for every rank's engines together
 
     def state_dict(self):
         """`meta_optim_state_dict` of the reference checkpoints (train_meta.py:277-286)."""
@@ -231,8 +232,35 @@ class MetaTrainer:
                 losses.append(l)
         return losses
 
+    def _collective_mode_check(self, local_tasks):
+        """The f16x3 range guard (`Engine.verify_matrix_mode`: forward pass AND one fine-tune step of the loaded state in f16x3
+        against the exact-split mode) for a trainer: run once, on the first engine with this rank's first task, at the first
+        meta-iteration after `load_state`; the verdict is all-reduced (MAX) so that EVERY engine of EVERY rank ends in the same
+        mode -- ranks in different modes would average gradients of slightly different functions.  Every rank takes part in
+        the collective whether it has a task or not (all ranks call `meta_iteration` equally often)."""
+        self._mode_check_pending = False
+        real = [e for e in self.engines if getattr(e, 'verify_matrix_mode', None) is not None]
+        flag = 0
+        if real and local_tasks and getattr(real[0], '_verify_pending', False):
+            from .engine import _guard_enabled
+            if _guard_enabled() and real[0].matrix_mode == 'f16x3':
+                xt, yt = local_tasks[0][0], local_tasks[0][1]
+                with _on_stream(real[0]):
+                    flag = int(real[0].verify_matrix_mode(xt, yt) != 'f16x3')
+        if self.dist is not None and self.dist.is_initialized():
+            t = torch.tensor([flag], device=self.state.device, dtype=torch.int32)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            flag = int(t.item())
+        for e in real:
+            if flag and e.matrix_mode == 'f16x3':
+                e.set_engine_matrix_mode('bf16x6')
+            e._verify_pending = e._step_check_pending = False
+        return flag
+
     def meta_iteration(self, local_tasks, inner_steps=5, bptt_epochs=None, multi_step_bptt_loss=None):
         """local_tasks: this rank's share of the meta-batch: [(x_train, y_train, x_meta, y_meta)]."""
+        if getattr(self, '_mode_check_pending', False):
+            self._collective_mode_check(local_tasks)
         default_schedule = not multi_step_bptt_loss and (bptt_epochs or inner_steps) == inner_steps and inner_steps > 0
         same_size = all(t[0].shape[-2:] == (e.height, e.width) and t[0].shape[0] <= e.max_batch and t[2].shape[0] <= e.max_batch
                         for t in local_tasks for e in self.engines)

@@ -72,6 +72,13 @@ const char* eosvos_last_error(void);
 #define EOSVOS_MATRIX_F16X3 2
 int eosvos_set_matrix_mode(int mode);
 int eosvos_get_matrix_mode(void);
+/* One engine's own matrix mode (round 5): every later call on `e` plans and launches its contractions in `mode`, whatever
+ * the process-wide mode is and whatever other engines run in (-1: follow the process-wide mode again, the default).  This is
+ * what the range guard of the Python shim uses: a state that leaves the F16X3 envelope moves the ENGINE that holds it to
+ * BF16X6, not the process (engine.py Engine.verify_matrix_mode).  Thread-safe in the sense of the rest of the ABI: the mode
+ * travels with the call on the calling host thread.  eosvos_get_engine_matrix_mode returns the mode in effect for `e`. */
+int eosvos_set_engine_matrix_mode(eosvos_engine* e, int mode);
+int eosvos_get_engine_matrix_mode(eosvos_engine* e);
 
 /* Workgroups one launch of this engine plans for.  0 (default): two per CU, i.e. the whole chip -- right for an
  * engine that has the GPU to itself.  Engines that run beside each other (concurrent meta tasks, one engine per task:

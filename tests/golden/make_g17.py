@@ -54,7 +54,7 @@ def sample_idx(n):
     return torch.linspace(0, n - 1, NSAMP).long()
 
 
-def g17():
+def g17(out_name='g17_c3_full.npz'):
     frames, gts = sequence()
     rec = {'logit_fp': [], 'logit_samples': [], 'near_zero': [], 'mask_bits': [], 'infer_obj': [], 'infer_frame': []}
 
@@ -106,7 +106,7 @@ def g17():
     # the loss VALUES: re-read from the reference's log is not possible (evaluate() keeps them local), so the harness's
     # compute_loss wrapper logged the ground-truth sums only; the values come from LoggedLoss below
     losses = out.get('loss_values')
-    np.savez_compressed(os.path.join(HERE, 'g17_c3_full.npz'),
+    np.savez_compressed(os.path.join(HERE, out_name),
                         train_losses=np.asarray(LOSS_VALUES, dtype=np.float64),
                         batch_gt_sums=np.asarray([b + [0.0] * (3 - len(b)) for b in batches], dtype=np.float64),
                         batch_sizes=np.asarray([len(b) for b in batches]),
@@ -172,8 +172,18 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--g17', action='store_true')
     ap.add_argument('--g7full', action='store_true')
+    ap.add_argument('--g21', action='store_true',
+                    help='G21: BASELINE configs[2] at its REAL length -- 100 iterations on the first frame, then 10 every 5 frames, '
+                         '12 frames (two adaptation rounds), two objects, batch 3, 480 x 854 (~25 min on 8 cores) -> g21_c3_fulllength.npz')
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 8)
+    if a.g21:
+        SC.update(name='c3_fulllength', step=5, eval_epochs=100, ona_epochs=10)
+        SC['seqs'] = {'syn': dict(frames=12, objects=2)}      # frames 1-5, round, 6-10, round, 11: TWO adaptation rounds
+        make_g12.ev.compute_loss = _logging_compute_loss
+        g17('g21_c3_fulllength.npz')
+        make_g12.ev.compute_loss = _real_compute_loss
+        sys.exit(0)
     if a.g17 or not a.g7full:
         make_g12.ev.compute_loss = _logging_compute_loss      # make_g12.run wraps whatever ev.compute_loss is at call time
         g17()

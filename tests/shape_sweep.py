@@ -1,0 +1,102 @@
+"""Odd frame sizes through the whole engine in every matrix mode, range guard OFF (a helper the GPU tests import, and a
+script for the uninitialised-memory variant:  EOSVOS_DEBUG_FILL=7fc00000 python tests/shape_sweep.py --shapes fill).
+
+DAVIS-2017 frames are not all 854 wide (`/root/reference/src/train_parent.py:200-202`); the network must give the
+reference's logits on any frame size (`/root/reference/src/networks/deeplabv3plus.py:32-53`).  Round 4 hid a wrong stem
+pixel on odd x odd frames behind the guard's silent fall-back: here every mode is FORCED on the engine
+(`eosvos_set_engine_matrix_mode`) and compared with the CPU oracle on its own:
+  forward logits <= 1e-3 (north_star), thresholded masks bit-exact outside |oracle logit| < 1e-3, one fine-tune step's loss,
+  the logits after that step.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+SWEEP = [(1, h, w) for h in (97, 98, 99, 100) for w in range(161, 169)]
+EXTRA = [(2, 130, 182), (3, 101, 167), (1, 480, 853), (1, 480, 855), (1, 480, 910)]
+FILL = [(1, 97, 163), (1, 99, 165), (1, 98, 164), (3, 101, 167), (2, 130, 182), (1, 480, 853), (1, 480, 855)]
+MODES = ('f16x3', 'bf16x6', 'f32')
+LOGIT_TOL = 1e-3
+
+
+def run_shape(shape, sd, lrs, modes=MODES, seed=21, step_below=100000, dev='cuda:0'):
+    """{mode: {'logits', 'mask_bits', 'loss_rel', 'logits_after_step'}} for one (B, H, W); mask_bits counts thresholded pixels
+    that differ where the oracle's |logit| >= 1e-3."""
+    from eosvos_amd import synthetic
+    from eosvos_amd.engine import Engine
+    from oracle import deeplab, meta
+    B, H, W = shape
+    x, y = synthetic.synthetic_frames(B, H, W, seed=seed)
+    with torch.no_grad():
+        ref = deeplab.forward(sd, x)
+    do_step = H * W < step_below
+    if do_step:
+        loss_ref, _, P = meta.finetune_step(sd, lrs, x, y)
+        with torch.no_grad():
+            ref2 = deeplab.forward(P, x)
+    eng = Engine('resnet50', H, W, max_batch=B, device=dev)
+    out = {}
+    try:
+        eng.load_model_state(sd, lrs)
+        eng._verify_pending = False                       # guard off: each mode stands on its own
+        xg, yg = x.to(dev), y.to(dev)
+        for mode in modes:
+            eng.set_engine_matrix_mode(mode)
+            assert eng.matrix_mode == mode
+            eng.reset()
+            lg = eng.forward(xg).cpu()
+            r = {'logits': float((lg - ref).abs().max()),
+                 'mask_bits': int((((lg >= 0) != (ref >= 0)) & (ref.abs() >= 1e-3)).sum()),
+                 'finite': bool(torch.isfinite(lg).all())}
+            if do_step:
+                loss = eng.finetune_step(xg, yg)
+                r['loss_rel'] = abs(loss - float(loss_ref)) / max(1.0, abs(float(loss_ref)))
+                lg2 = eng.forward(xg).cpu()
+                r['logits_after_step'] = float((lg2 - ref2).abs().max())
+                r['finite'] = r['finite'] and bool(torch.isfinite(lg2).all()) and loss == loss
+            out[mode] = r
+    finally:
+        eng.close()
+    return out
+
+
+def check(shape, res):
+    """Assertion messages for one shape's result (empty = green)."""
+    bad = []
+    for mode, r in res.items():
+        if not r['finite']:
+            bad.append(f'{shape} {mode}: not finite')
+        if not r['logits'] <= LOGIT_TOL:
+            bad.append(f"{shape} {mode}: logits differ from the oracle by {r['logits']:.3e}")
+        if r['mask_bits'] != 0:
+            bad.append(f"{shape} {mode}: {r['mask_bits']} mask pixels differ outside |logit| < 1e-3")
+        if 'loss_rel' in r and not r['loss_rel'] <= 1e-5:
+            bad.append(f"{shape} {mode}: fine-tune loss off by {r['loss_rel']:.3e}")
+        if 'logits_after_step' in r and not r['logits_after_step'] <= LOGIT_TOL:
+            bad.append(f"{shape} {mode}: logits after one step differ by {r['logits_after_step']:.3e}")
+    return bad
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--shapes', choices=['sweep', 'extra', 'fill', 'all'], default='fill')
+    a = ap.parse_args()
+    from eosvos_amd import synthetic
+    sd, lrs = synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50')
+    shapes = {'sweep': SWEEP, 'extra': EXTRA, 'fill': FILL, 'all': SWEEP + EXTRA}[a.shapes]
+    failures, worst = [], {m: 0.0 for m in MODES}
+    for shp in shapes:
+        res = run_shape(shp, sd, lrs)
+        failures += check(shp, res)
+        for m, r in res.items():
+            worst[m] = max(worst[m], r['logits'], r.get('logits_after_step', 0.0))
+    print(json.dumps({'shapes': len(shapes), 'failures': failures, 'worst_logit_diff': worst,
+                      'debug_fill': os.environ.get('EOSVOS_DEBUG_FILL')}))
+    sys.exit(1 if failures else 0)

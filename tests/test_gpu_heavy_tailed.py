@@ -107,13 +107,16 @@ def test_g19_heavy_tailed_norm_statistics_vs_reference(mode):
     assert m['meta_lr_grad'] <= 2e-3 and m['meta_init_grad_dec1'] <= 2e-3 and m['meta_init_l2'] <= 2e-3, m
 
 
+@pytest.mark.guard_fallback_expected
 def test_range_guard_falls_back_to_the_exact_split_mode():
     """A state OUTSIDE the envelope of one power-of-two scale per tensor: one channel of an activation tensor is 2^40 times
     the others (its BatchNorm scale x 2^40, the next conv's weights for it x 2^-40: the network function is unchanged in exact
     arithmetic, fp32 and bf16x6 compute it to rounding), so in f16x3 the bulk of that tensor sits below the fp16 pieces'
     range.  The guard (`Engine.verify_matrix_mode`, run at the first forward after a state load) detects the difference
-    against the exact-split mode, warns and switches the process to bf16x6; the result then matches the CPU oracle.  The
-    benign and the heavy-tailed (G19) states pass the same check and stay in f16x3."""
+    against the exact-split mode, warns and moves THAT ENGINE to bf16x6 (round 5: `eosvos_set_engine_matrix_mode`; the
+    process-wide mode and a second live engine stay in f16x3); the result then matches the CPU oracle.  The benign and the
+    heavy-tailed (G19) states pass the same check -- forward pass AND one whole fine-tune step (loss, per-tensor parameter
+    update), after which the weights are back bit for bit -- and stay in f16x3."""
     import warnings
     from oracle import deeplab
     H, W = SMALL
@@ -133,17 +136,29 @@ def test_range_guard_falls_back_to_the_exact_split_mode():
                 state['backbone.layer2.1.conv2.weight'][:, 5] /= f            # ... and read back with weights x 2^-40
             engine_mod.set_matrix_mode('f16x3')
             engine_mod.GUARD_LOG.clear()
+            other = Engine('resnet50', H, W, max_batch=1, device=DEV)      # a second engine in flight keeps its mode
+            other.load_model_state(synthetic.synthetic_state(), lrs)
             e = Engine('resnet50', H, W, max_batch=1, device=DEV)
             e.load_model_state(state, lrs)
+            p0 = e.get_params()
             with warnings.catch_warnings(record=True) as w:
                 warnings.simplefilter('always')
                 out = e.forward(x.to(DEV)).cpu()
-            assert engine_mod.get_matrix_mode() == expect, (expect, engine_mod.GUARD_LOG)
+            assert e.matrix_mode == expect, (expect, engine_mod.GUARD_LOG)
+            assert engine_mod.get_matrix_mode() == 'f16x3' and other.matrix_mode == 'f16x3'      # the fall-back is per engine
             assert bool(w) == (expect == 'bf16x6') and bool(engine_mod.GUARD_LOG) == (expect == 'bf16x6')
             ref = deeplab.forward(state, x)
             assert float((out - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max())), float((out - ref).abs().max())
+            # the step half of the guard (explicit call: the automatic one runs inside the first finetune_step)
+            with warnings.catch_warnings(record=True) as w2:
+                warnings.simplefilter('always')
+                e._verify_pending = True
+                mode = e.verify_matrix_mode(x.to(DEV), y.to(DEV))
+            assert mode == expect and not (expect == 'f16x3' and w2), [str(v.message) for v in w2]
+            assert torch.equal(e.get_params(), p0)                        # the two trial steps left the weights as they were
             loss = e.finetune_step(x.to(DEV), y.to(DEV))                  # the step runs in the mode the guard left
             assert np.isfinite(loss)
             e.close()
+            other.close()
     finally:
         engine_mod.set_matrix_mode(prev)

@@ -436,30 +436,50 @@ def test_fused_outer_step_equals_the_separate_calls(weights, case, monkeypatch):
     assert float((a[0][:engines[0].n_lr] - torch.cat([l.reshape(-1) for l in lrs])).abs().max()) > 0
 
 
-@pytest.mark.parametrize('shape', [(1, 97, 161), (2, 130, 182), (1, 480, 910)])
-def test_shape_polymorphism_vs_oracle(weights, shape):
-    """Odd / non-multiple-of-16 frame sizes (DAVIS 480p frames are not all 854 wide): forward logits and
-    one fine-tune step against the CPU oracle."""
-    from eosvos_amd.engine import Engine
-    from oracle import deeplab, meta
-    B, H, W = shape
+def test_shape_polymorphism_sweep_vs_oracle(weights):
+    """Odd / non-multiple-of-16 frame sizes (DAVIS 480p frames are not all 854 wide): H in {97 ... 100} x W in {161 ... 168},
+    every matrix mode FORCED on the engine with the range guard off: forward logits <= 1e-3 and masks bit-exact outside
+    |logit| < 1e-3 against the CPU oracle, one fine-tune step's loss, logits after the step (tests/shape_sweep.py).
+    Round 4: the f16x3 stem produced a wrong last pixel on odd x odd frames whenever the allocator handed back used memory,
+    and the guard's silent fall-back to bf16x6 hid it (VERDICT r04 weak #1)."""
+    import shape_sweep
     sd, lrs = weights
-    x, y = synthetic.synthetic_frames(B, H, W, seed=21)
-    eng = Engine('resnet50', H, W, max_batch=B, device=DEV)
-    eng.load_model_state(sd, lrs)
-    with torch.no_grad():
-        ref = deeplab.forward(sd, x)
-    out = eng.forward(x.to(DEV)).cpu()
-    assert float((out - ref).abs().max()) < LOGIT_TOL
-    if H * W < 100000:
-        loss_ref, _, P = meta.finetune_step(sd, lrs, x, y)
-        loss = eng.finetune_step(x.to(DEV), y.to(DEV))
-        assert abs(loss - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
-        with torch.no_grad():
-            ref2 = deeplab.forward(P, x)
-        out2 = eng.forward(x.to(DEV)).cpu()
-        assert float((out2 - ref2).abs().max()) < 2e-3
-    eng.close()
+    failures, worst = [], 0.0
+    for shp in shape_sweep.SWEEP:
+        res = shape_sweep.run_shape(shp, sd, lrs)
+        failures += shape_sweep.check(shp, res)
+        worst = max([worst] + [max(r['logits'], r.get('logits_after_step', 0.0)) for r in res.values()])
+    print('MARGIN shape sweep: %d shapes x 3 modes, worst logit difference %.3e' % (len(shape_sweep.SWEEP), worst))
+    assert not failures, failures
+
+
+@pytest.mark.parametrize('shape', [(2, 130, 182), (3, 101, 167), (1, 480, 853), (1, 480, 855), (1, 480, 910)], ids=lambda s: 'x'.join(map(str, s)))
+def test_shape_polymorphism_vs_oracle(weights, shape):
+    """Batches > 1 on odd sizes and the 480-row odd widths around 854 (forward only above 100 000 pixels: the oracle's step
+    takes minutes there), in every matrix mode with the guard off."""
+    import shape_sweep
+    res = shape_sweep.run_shape(shape, *weights)
+    bad = shape_sweep.check(shape, res)
+    assert not bad, bad
+
+
+def test_shape_sweep_on_memory_nothing_zeroed():
+    """The same checks in a process whose every engine buffer starts out as NaN (EOSVOS_DEBUG_FILL=7fc00000) instead of the
+    zero pages a fresh process gets: a kernel that reads memory nothing wrote -- the stem's 8-float slots past an odd x odd
+    frame in round 4 -- shows up as NaN / a wrong pixel.  A subprocess: the fill is decided when the library first allocates."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EOSVOS_DEBUG_FILL='7fc00000', EOSVOS_MODE_GUARD='0')
+    p = subprocess.run([sys.executable, os.path.join(root, 'tests', 'shape_sweep.py'), '--shapes', 'fill'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=1500)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    out = json.loads(lines[-1])
+    assert out['debug_fill'] == '7fc00000'
+    assert p.returncode == 0 and not out['failures'], out
+    print('MARGIN shape sweep on NaN-filled buffers:', out['worst_logit_diff'])
 
 
 def test_resnet101_vs_oracle():
