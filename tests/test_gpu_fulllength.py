@@ -128,29 +128,28 @@ def test_c3_hundred_plus_online_adaptation_vs_reference_evaluate(golden_dir, mon
 
     def call(self, inputs):
         batch_sizes.append(int(inputs.shape[0]))
-        eng = self.engine
-        if eng.matrix_mode != mode:                                      # (the model builds its engine lazily)
-            eng.set_engine_matrix_mode(mode)
-        eng._verify_pending = eng._step_check_pending = False
         return real_call(self, inputs)
     monkeypatch.setattr(type(model), '__call__', call)
     real_infer = Engine.infer
 
     def infer(self, images):
-        if self.matrix_mode != mode:
-            self.set_engine_matrix_mode(mode)
-        self._verify_pending = False
         out = real_infer(self, images)
         logits_seen.extend(self.debug_tensor('logits')[:images.shape[0]].cpu())
         return out
     monkeypatch.setattr(Engine, 'infer', infer)
-    monkeypatch.setenv('EOSVOS_MODE_GUARD', '0')
+    monkeypatch.setenv('EOSVOS_MODE_GUARD', '0')                          # each mode stands on its own
+    from eosvos_amd import engine as engine_mod
+    prev = engine_mod.get_matrix_mode()
+    engine_mod.set_matrix_mode(mode)                                      # (the model builds its engine lazily: process-wide)
     probs, losses = [], []
-    for o in range(n_obj):
-        p, hist = finetune_object(model, mo, msd, seq, objs[o].to(DEV), cfg)
-        probs.append(p)
-        losses += [v for rnd in hist for v in rnd]
-    assert model.engine.matrix_mode == mode
+    try:
+        for o in range(n_obj):
+            p, hist = finetune_object(model, mo, msd, seq, objs[o].to(DEV), cfg)
+            probs.append(p)
+            losses += [v for rnd in hist for v in rnd]
+        assert model.engine.matrix_mode == mode
+    finally:
+        engine_mod.set_matrix_mode(prev)
     assert batch_sizes == g['batch_sizes'].tolist()
     loss_rel = float(np.max(np.abs(np.asarray(losses) - g['train_losses']) / np.abs(g['train_losses'])))
     assert len(logits_seen) == len(g['infer_frame'])

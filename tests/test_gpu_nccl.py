@@ -35,6 +35,7 @@ def test_meta_iteration_through_rccl_world_size_1(tmp_path):
     r = torch.load(out, weights_only=False)
     assert r['backend'] == 'nccl'
     assert r['all_reduce_calls'] == 4                      # 2 meta-iterations x {one task per rank, two in flight}
+    assert r['mode_flag_calls'] == 2                       # + the matrix-mode verdict, once per loaded state (MetaTrainer._collective_mode_check)
     for tag in ('one', 'two'):
         # the sum over ONE rank is the identity: bit-identical to the trainer without a process group, i.e. the
         # all-reduce is ordered after the tasks' gradient accumulation and before the outer step on every stream
