@@ -685,8 +685,9 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
     m.wg_budget = a.wg_budget;
     if (vslot) { m.amax_x = vslot; m.amax_w = amax_slot(e, AM_U, ci); }
     // the output transform writes y (directly, or the raw conv output of the GroupNorm mode)
-    unsigned* yslot = gn ? nullptr : twrite_fused(e, 0, ykey, ldy == c.cout);
-    if (gn) twrite_plain(e, 0, ykey);
+    // (GroupNorm mode: the output transform writes the raw conv output; y and its absmax come from the GroupNorm apply pass)
+    unsigned* const yslot_any = twrite_fused(e, 0, ykey, ldy == c.cout);
+    unsigned* yslot = gn ? nullptr : yslot_any;
     uint8_t* ym8 = (gn || !e->m8w(ykey)) ? nullptr : e->m8w(ykey) + (y - ykey) / 4;
     trace("fwd", ci, m.M, m.N, c.cin, conv_plan(m));
     launch_conv(m, st);
@@ -698,7 +699,7 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
                          (!gn && relu) ? 1 : 0, gn ? e->zbuf[ci] : y, gn ? c.cout : ldy, st, yslot, ym8, ldy / 4);
     if (gn)
       launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
-                        a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st);
+                        a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st, yslot_any, (relu && e->m8w(ykey)) ? e->m8w(ykey) + (y - ykey) / 4 : nullptr, ldy / 4);
     return;
   }
   if (gn) {                       // raw conv output -> GroupNorm kernels (statistics are data dependent)
@@ -710,19 +711,21 @@ void conv_fwd(eosvos_engine* e, int ci, const float* x, int ldx, int Hi, int Wi,
       if (uint8_t* m = e->m8w(ykey)) { a.mask8_out = m + (y - ykey) / 4; a.ldm8_out = ldy / 4; }
   }
   attach_tap_table(e, ci, 0, B, a);
+  unsigned* gn_yslot = nullptr;
   if (h3_mode() && !amax_init(e)) {
     amax_weights(e, st);
     a.amax_x = tlookup(e, 0, xkey);
     if (!a.amax_x) a.amax_x = amax_get(e, AM_X, ci, x, (long)B * Hi * Wi, c.cin, ldx, st);
     a.amax_w = amax_slot(e, AM_W, ci);
-    if (gn) twrite_plain(e, 0, ykey);              // y is written by the GroupNorm kernel
-    else a.amax_y = twrite_fused(e, 0, ykey, ldy == c.cout);
+    gn_yslot = twrite_fused(e, 0, ykey, ldy == c.cout);      // GroupNorm mode: y (and its absmax) is written by the apply pass
+    if (!gn) a.amax_y = gn_yslot;
   }
   trace("fwd", ci, a.M, a.N, (long)c.T() * c.cin, conv_plan(a), conv_exec_frac(a));
   launch_conv(a, st);
   if (gn)
     launch_gn_forward(e->zbuf[ci], c.cout, e->G_(ci), e->nb + c.noff, res, ldres, y, ldy, e->gn_stats[ci], e->gn_partial, B,
-                      a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st);
+                      a.Ho * a.Wo, c.cout, 1e-5f, relu ? 1 : 0, st, gn ? gn_yslot : nullptr,
+                      (relu && e->m8w(ykey)) ? e->m8w(ykey) + (y - ykey) / 4 : nullptr, ldy / 4);
 }
 // gx[B,Hin,Win,cin] (ld ldgx) (+)= dgrad of conv ci applied to g[B,Ho,Wo,cout] (ld ldg)
 void conv_dgrad(eosvos_engine* e, int ci, const float* g, int ldg, int Hin, int Win, float* gx, int ldgx, int B,
@@ -981,10 +984,10 @@ int conv_wgrad(eosvos_engine* e, int ci, const float* g, int ldg, const float* x
   if (!xkey) xkey = x;
   if (e->gn() && c.norm) {        // dz = GroupNorm backward of G_u, written over the stored raw output
     const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
-    launch_gn_backward(e->zbuf[ci], c.cout, g, ldg, e->G_(ci), e->gn_stats[ci], e->gn_sums, e->gn_partial, B, Ho * Wo, c.cout,
-                       e->s);
+    // (round 5: the apply pass reduces max|dz| itself -- the consumers below, weight and data gradient, read the slot)
+    launch_gn_backward(e->zbuf[ci], c.cout, g, ldg, e->G_(ci), e->gn_stats[ci], e->gn_partial, B, Ho * Wo, c.cout,
+                       e->s, twrite_fused(e, 1, e->zbuf[ci], true));
     g = e->zbuf[ci]; ldg = c.cout; gkey = g;
-    twrite_plain(e, 1, gkey);
   }
   const int Ho = conv_out(Hin, c.k, c.stride, c.dil, c.pad), Wo = conv_out(Win, c.k, c.stride, c.dil, c.pad);
   const bool wino = wino_on(e, ci, B, Ho, Wo);
@@ -1362,7 +1365,7 @@ int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, i
   e->gn_stats.assign(t.convs.size(), nullptr);
   if (e->gn()) {
     e->gn_sums = e->falloc((int64_t)B * 32);
-    e->gn_partial = e->falloc((int64_t)B * 16 * 64 * 2);
+    e->gn_partial = e->falloc((int64_t)gn_partial_floats(B));
     e->zbuf[0] = e->falloc((int64_t)B * e->h2 * e->w2 * 64);
     e->gn_stats[0] = e->falloc((int64_t)B * 32);
     e->zbuf[t.pool] = e->falloc((int64_t)B * 256);
@@ -1445,7 +1448,8 @@ int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, i
   ALLOC(e->lowlog, n4); ALLOC(e->g_low, n4);
   ALLOC(e->logits, (int64_t)B * H * W); ALLOC(e->dlogits, (int64_t)B * H * W);
   ALLOC(e->loss_dev, 4); ALLOC(e->bce_partial, 4 * 1024 + 16);
-  if (!e->gn() && !getenv("EOSVOS_TUNE_NO_MASK8")) {          // (A/B switch: data gradients read the fp32 activations as masks)
+  if (!getenv("EOSVOS_TUNE_NO_MASK8")) {          // (A/B switch: data gradients read the fp32 activations as masks)
+    // (GroupNorm mode, round 5: the apply pass that writes y = relu(gn(z) (+ res)) writes the bytes)
     auto m8alloc = [&](const float* key, int64_t floats) {     // one byte per 4 floats
       float* p = e->falloc((floats / 4 + 3) / 4);
       if (p) e->mask8[key] = (uint8_t*)p;
@@ -1870,7 +1874,7 @@ static int forward_impl(eosvos_engine* e, const float* images, int B) {
   for (int i = 0; i < 4; ++i)
     conv_fwd(e, t.aspp[i], l4, 2048, e->h16, e->w16, e->cat + 256 * i, 1280, B, nullptr, 0, true, false, nullptr, e->cat);
   if (!pside) pool_branch();
-  if (h3_mode() && !e->gn() && !amax_init(e)) {
+  if (h3_mode() && !amax_init(e)) {
     // cat = 4 conv outputs (their epilogues fed the tensor's slot) + the broadcast pooling branch (its B x 256 values here)
     if (unsigned* cs = tslot(e, 0, e->cat)) { launch_absmax(e->poolout, 1, B * 256, B * 256, cs, ps); tmark_valid(e, 0, e->cat); }
   }
@@ -1968,7 +1972,7 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
     launch_colsum(e->g_cat + 1024, 1280, e->gp, B, P16, 256, 1.f, e->colscratch, s);
     const float* gpz = e->gp;
     if (e->gn()) {
-      launch_gn_backward(e->zbuf[t.pool], 256, e->gp, 256, e->G_(t.pool), e->gn_stats[t.pool], e->gn_sums, e->gn_partial, B, 1, 256, s);
+      launch_gn_backward(e->zbuf[t.pool], 256, e->gp, 256, e->G_(t.pool), e->gn_stats[t.pool], e->gn_partial, B, 1, 256, s);
       gpz = e->zbuf[t.pool];
     }
     launch_gemv_bwd(e->W_(t.pool), e->vec, gpz, e->A_(t.pool), e->gvec, e->ws_wg + e->ws_off[t.pool], B, 256, 2048, s);
@@ -2042,14 +2046,15 @@ static int backward_impl(eosvos_engine* e, bool update, bool accumulate) {
   // from the pooling backward, the frame's from this iteration's forward (slot (X, conv 0))
   static const bool stem_h3_off = getenv("EOSVOS_TUNE_NO_STEM_H3") != nullptr;
   const auto& xrec = amax_rec_of(e, AM_X, 0);
-  const bool stem_h3 = h3_mode() && !stem_h3_off && !e->gn() && e->amax && xrec.epoch == e->fwd_epoch && xrec.ptr == e->xpad;
-  unsigned* ag = stem_h3 ? amax_fused_slot(e, AM_G, 0, e->g_c1, s) : nullptr;
-  launch_maxpool_bwd(e->g_p1, e->p1idx, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s, ag);
+  const bool stem_h3 = h3_mode() && !stem_h3_off && e->amax && xrec.epoch == e->fwd_epoch && xrec.ptr == e->xpad;
+  // (GroupNorm mode, round 5: the gradient operand is dz of the stem's GroupNorm, whose apply pass reduces its absmax)
+  unsigned* ag = stem_h3 ? amax_fused_slot(e, AM_G, 0, e->gn() ? e->zbuf[0] : e->g_c1, s) : nullptr;
+  launch_maxpool_bwd(e->g_p1, e->p1idx, e->g_c1, B, e->h2, e->w2, 64, e->h4, e->w4, s, e->gn() ? nullptr : ag);
   {
     const int chunks = stem_wgrad_chunks(B, e->h2, e->w2);
     const float* gc1 = e->g_c1;
     if (e->gn()) {
-      launch_gn_backward(e->zbuf[0], 64, e->g_c1, 64, e->G_(0), e->gn_stats[0], e->gn_sums, e->gn_partial, B, e->h2 * e->w2, 64, s);
+      launch_gn_backward(e->zbuf[0], 64, e->g_c1, 64, e->G_(0), e->gn_stats[0], e->gn_partial, B, e->h2 * e->w2, 64, s, ag);
       gc1 = e->zbuf[0];
     }
     if (ag) launch_stem_wgrad_h3(e->xpad, gc1, e->ws_wg + e->ws_off[0], B, e->H, e->W, e->h2, e->w2, chunks, ag, amax_slot(e, AM_X, 0), s);

@@ -334,11 +334,14 @@ void launch_sgd_update(float* w, const float* ws, int splits, int64_t slab, cons
                        const float* lr, float* gsum, float* gout, int64_t rowlen, int64_t n,
                        hipStream_t s);
 // GroupNorm(16, C), frozen affine.  forward: stats + y = relu?(gn(z) (+res)); backward: z <- dL/dz.
+// `amax_y` / `amax_dz`: absmax slot of the tensor the pass writes (f16x3 mode), or null.  `partial`: gn_partial_floats(B) floats.
+// `m8`: ReLU mask bytes of y (one per 4 channels, row pitch ldm8 bytes), written when `relu`.
 void launch_gn_forward(const float* z, int ldz, const float* gamma, const float* beta, const float* res, int ldres,
                        float* y, int ldy, float* stats, float* partial, int B, int P, int C, float eps, int relu,
-                       hipStream_t s);
+                       hipStream_t s, unsigned* amax_y = nullptr, uint8_t* m8 = nullptr, int ldm8 = 0);
 void launch_gn_backward(float* z, int ldz, const float* g, int ldg, const float* gamma, const float* stats,
-                        float* sums, float* partial, int B, int P, int C, hipStream_t s);
+                        float* partial, int B, int P, int C, hipStream_t s, unsigned* amax_dz = nullptr);
+int gn_partial_floats(int B);
 // Whole-network update in one launch: per-layer table over one slab arena.
 struct UpdEntry {
   long w_off;      // offset of the tensor (weight [+ bias]) in the parameter / gsum / gout arenas
@@ -352,7 +355,10 @@ struct UpdEntry {
   int blk0;        // first workgroup of this entry (UPD_CHUNKS x 1024 elements per workgroup)
   int amax_idx;    // f16x3 mode: index of the tensor's absmax word in `amax_w` (the conv index), -1: none
 };
-#define UPD_CHUNKS 1   // 1024-element chunks per workgroup of the update kernel (UpdEntry::blk0 counts those)
+#ifndef UPD_CHUNKS
+#define UPD_CHUNKS 1
+#endif
+// UPD_CHUNKS: 1024-element chunks per workgroup of the update kernel (UpdEntry::blk0 counts those)
 void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W, const float* ws, const float* na,
                            const float* lr, const float* lr_elem, float* gsum, float* gout, hipStream_t s,
                            unsigned* amax_w = nullptr);   // amax_w: max|w| of the updated weights, per UpdEntry::amax_idx

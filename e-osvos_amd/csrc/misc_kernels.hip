@@ -1153,114 +1153,255 @@ void launch_sgd_update_all(const UpdEntry* tab, int nent, int nblocks, float* W,
 }  // namespace eosvos
 
 // ---- GroupNorm(16, C) with frozen affine (deeplabv3plus.py:180-191) ---------------------------------
-// NHWC tensors / channel slices (ld = floats per pixel).  Statistics per (image, group) over
-// P pixels x C/16 channels, two-stage deterministic reduction (float partials, double final).
+// NHWC tensors / channel slices (ld = floats per pixel, C % 4 == 0).  Statistics per (image, group) over P pixels x C/16
+// channels.  Round 5: every pass moves whole float4 rows (the round-1 kernels read one float per thread and divided a
+// 64-bit index per element: 2.5 TB/s): a workgroup owns a run of pixels of ONE image and a block of <= 256 float4 columns,
+// a thread keeps its column, so its 4 channels' group constants are computed once; the statistics are reduced per thread ->
+// per column -> per group in a fixed order (deterministic), one float2 partial per (image, group, pixel chunk), summed in
+// double by one wave per (image, group).  The passes that WRITE a tensor a contraction will read (y = gn(z), dz) also reduce
+// its absmax for the f16x3 mode (round 4 ran a standalone pass per consumer: 114 launches per iteration).
 namespace eosvos {
-#define GN_CHUNKS 64
-// partial[(b*16+g)*GN_CHUNKS + chunk] = {sum u, sum u*v}   with (u,v) = (z, z)  or  (gamma*G, zhat)
-template <bool BWD>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ z, int ldz,
-                                                          const float* __restrict__ g, int ldg,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ stats, float2* __restrict__ partial,
-                                                          int P, int C) {
-  __shared__ float sh[4];
-  const int bg = blockIdx.y, b = bg >> 4, grp = bg & 15, ch = blockIdx.x;
-  const int cg = C >> 4;
-  const int per = (P + GN_CHUNKS - 1) / GN_CHUNKS;
-  const int p0 = ch * per;
-  int p1 = p0 + per;
-  if (p1 > P) p1 = P;
-  const int n = (p1 > p0 ? p1 - p0 : 0) * cg;
-  float mu = 0.f, rs = 0.f;
-  if (BWD) { mu = stats[bg * 2]; rs = stats[bg * 2 + 1]; }
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int p = p0 + i / cg, c = grp * cg + i % cg;
-    const float zv = z[((size_t)b * P + p) * ldz + c];
-    if (BWD) {
-      const float u = gamma[c] * g[((size_t)b * P + p) * ldg + c];
-      s1 += u;
-      s2 += u * ((zv - mu) * rs);
-    } else {
-      s1 += zv;
-      s2 += zv * zv;
+#define GN_UNROLL 8
+#define GN_MAX_CHUNKS 128      // (16 lanes x 8 loads in flight finish a group in the apply pass's prologue)
+struct GnGeom { int ncol, rows, chunks, colblocks, per; };
+static inline GnGeom gn_geom(int B, int P, int C) {
+  GnGeom g;
+  const int C4 = C / 4;
+  g.colblocks = (C4 + 255) / 256;
+  g.ncol = C4 / g.colblocks;                       // C4 in {12, 16, 32, ..., 256, 512}: divides evenly
+  g.rows = 256 / g.ncol;
+  // about 4 workgroups per CU over the whole launch, 8 rows (128 bytes per lane) in flight each; >= 8 passes per workgroup
+  long want = 1024 / ((long)B * g.colblocks);
+  long most = P / (8L * g.rows);
+  if (want > most) want = most;
+  if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
+  if (want < 1) want = 1;
+  g.chunks = (int)want;
+  g.per = (P + g.chunks - 1) / g.chunks;
+  return g;
+}
+// per-thread sums -> partial[(b * 16 + grp) * chunks + chunk]; s1 / s2: this thread's 4 channels
+__device__ __forceinline__ void gn_reduce_groups(float (&s1)[4], float (&s2)[4], float* sh /*[8][256]*/, int ncol, int rows, int col0,
+                                                 int cg, int b, int chunk, int chunks, float2* __restrict__ partial) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh[j * 256 + tid] = s1[j]; sh[(4 + j) * 256 + tid] = s2[j]; }
+  __syncthreads();
+  if (tid < ncol) {                                // rows of one column, in row order
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float a = sh[k * 256 + tid];
+      for (int r = 1; r < rows; ++r) a += sh[k * 256 + r * ncol + tid];
+      sh[k * 256 + tid] = a;
     }
   }
-  s1 = block_sum_256(s1, sh);
-  s2 = block_sum_256(s2, sh);
-  if (threadIdx.x == 0) partial[(size_t)bg * GN_CHUNKS + ch] = make_float2(s1, s2);
-}
-// forward: stats[bg] = {mean, rstd};  backward: sums[bg] = {S1/n, S2/n}
-__global__ void gn_final_kernel(const float2* __restrict__ partial, float* __restrict__ out, int nbg, double inv_n,
-                                float eps, int bwd) {
-  const int bg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bg >= nbg) return;
-  double a = 0.0, b = 0.0;
-  for (int c = 0; c < GN_CHUNKS; ++c) { const float2 v = partial[(size_t)bg * GN_CHUNKS + c]; a += v.x; b += v.y; }
-  if (bwd) { out[bg * 2] = (float)(a * inv_n); out[bg * 2 + 1] = (float)(b * inv_n); }
-  else {
-    const double mean = a * inv_n;
-    double var = b * inv_n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    out[bg * 2] = (float)mean;
-    out[bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  __syncthreads();
+  const int ch0 = col0 * 4, nch = ncol * 4;        // channels [ch0, ch0 + nch) belong to this workgroup
+  const int g0 = ch0 / cg, ng = nch / cg;          // whole groups (cg divides nch for every C of the network)
+  if (tid < ng) {
+    float a = 0.f, q = 0.f;
+    for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += sh[(c & 3) * 256 + (c >> 2)]; q += sh[(4 + (c & 3)) * 256 + (c >> 2)]; }
+    partial[((size_t)b * 16 + g0 + tid) * chunks + chunk] = make_float2(a, q);
   }
 }
-// y = relu?( (z-mean)*rstd*gamma + beta (+ res) )
-__global__ void gn_apply_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy, int B, int P,
-                                int C, int relu) {
+// forward: (u, v) = (z, z^2);  backward: (gamma g, gamma g zhat)
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg,
+                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                        float2* __restrict__ partial, int P, int C, GnGeom gm) {
+  __shared__ float sh[8 * 256];
+  const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y, col0 = blockIdx.z * gm.ncol;
   const int cg = C >> 4;
-  const long n = (long)B * P * C;
-  GRID_STRIDE(e, n) {
-    const int c = (int)(e % C);
-    const long pix = e / C;
-    const int b = (int)(pix / P);
-    const int bg = b * 16 + c / cg;
-    float v = (z[pix * ldz + c] - stats[bg * 2]) * stats[bg * 2 + 1] * gamma[c] + beta[c];
-    if (res) v += res[pix * ldres + c];
-    if (relu) v = fmaxf(v, 0.f);
-    y[pix * ldy + c] = v;
+  const int col = tid % gm.ncol, row = tid / gm.ncol;
+  const bool act = row < gm.rows;
+  const int c = (col0 + col) * 4;
+  const int p0 = chunk * gm.per;
+  int p1 = p0 + gm.per;
+  if (p1 > P) p1 = P;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float ga[4] = {1.f, 1.f, 1.f, 1.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+  if (BWD && act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int bg = b * 16 + (c + j) / cg;
+      ga[j] = gamma[c + j]; mu[j] = stats[bg * 2]; rs[j] = stats[bg * 2 + 1];
+    }
   }
+  if (act) {
+    const float* zp = z + (size_t)b * P * ldz + c;
+    const float* gp = BWD ? g + (size_t)b * P * ldg + c : nullptr;
+    int p = p0 + row;
+    for (; p + (GN_UNROLL - 1) * gm.rows < p1; p += GN_UNROLL * gm.rows) {            // GN_UNROLL rows in flight
+      float4 zv[GN_UNROLL], gv[GN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        zv[u] = *reinterpret_cast<const float4*>(zp + (size_t)(p + u * gm.rows) * ldz);
+        if (BWD) gv[u] = *reinterpret_cast<const float4*>(gp + (size_t)(p + u * gm.rows) * ldg);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        const float zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+        const float gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (BWD) { const float t = ga[j] * gg[j]; s1[j] += t; s2[j] += t * ((zz[j] - mu[j]) * rs[j]); }
+          else { s1[j] += zz[j]; s2[j] += zz[j] * zz[j]; }
+        }
+      }
+    }
+    for (; p < p1; p += gm.rows) {
+      const float4 zv = *reinterpret_cast<const float4*>(zp + (size_t)p * ldz);
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BWD) gv = *reinterpret_cast<const float4*>(gp + (size_t)p * ldg);
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+      const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (BWD) { const float t = ga[j] * gg[j]; s1[j] += t; s2[j] += t * ((zz[j] - mu[j]) * rs[j]); }
+        else { s1[j] += zz[j]; s2[j] += zz[j] * zz[j]; }
+      }
+    }
+  }
+  gn_reduce_groups(s1, s2, sh, gm.ncol, gm.rows, col0, cg, b, chunk, gm.chunks, partial);
 }
-// dz = rstd * (gamma*G - S1/n - zhat*S2/n), written over z
-__global__ void gn_bwd_apply_kernel(float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg,
-                                    const float* __restrict__ stats, const float* __restrict__ sums,
-                                    const float* __restrict__ gamma, int B, int P, int C) {
+// The (image, group) totals of this workgroup's groups from the per-chunk partials, summed in double in a fixed order by 16
+// lanes per group (every workgroup of the launch computes the same bits; round 5: this replaces a 5 us launch per pass, 124
+// per iteration).  st[g] = {mean, rstd} (forward; also written to `stats_out` by the chunk-0 workgroups: the backward pass
+// reads it) or {S1 / n, S2 / n} (backward).
+__device__ __forceinline__ void gn_finish_groups(const float2* __restrict__ partial, int chunks, int b, int g0, int ng, double inv_n,
+                                                 float eps, bool bwd, float* __restrict__ stats_out, float (*st)[2]) {
+  const int gi = threadIdx.x >> 4, l = threadIdx.x & 15;
+  double a = 0.0, q = 0.0;
+  if (gi < ng) {
+    const float2* pp = partial + ((size_t)b * 16 + g0 + gi) * chunks;
+    float2 v[GN_MAX_CHUNKS / 16];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_CHUNKS / 16; ++k) v[k] = (l + 16 * k) < chunks ? pp[l + 16 * k] : make_float2(0.f, 0.f);      // all in flight
+#pragma unroll
+    for (int k = 0; k < GN_MAX_CHUNKS / 16; ++k) { a += v[k].x; q += v[k].y; }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+  if (gi < ng && l == 0) {
+    if (bwd) { st[gi][0] = (float)(a * inv_n); st[gi][1] = (float)(q * inv_n); }
+    else {
+      const double mean = a * inv_n;
+      double var = q * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      st[gi][0] = (float)mean;
+      st[gi][1] = (float)(1.0 / sqrt(var + (double)eps));
+      if (stats_out && blockIdx.x == 0) { stats_out[(b * 16 + g0 + gi) * 2] = st[gi][0]; stats_out[(b * 16 + g0 + gi) * 2 + 1] = st[gi][1]; }
+    }
+  }
+  __syncthreads();
+}
+// forward:  y = relu?((z - mean) * rstd * gamma + beta (+ res))                       (absmax of y into `amax`)
+// backward: z <- rstd * (gamma * g - S1 / n - zhat * S2 / n), zhat = (z - mean) rstd  (absmax of dz into `amax`)
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg,
+                                                        float* __restrict__ stats, const float2* __restrict__ partial, double inv_n, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy,
+                                                        int P, int C, int relu, GnGeom gm, unsigned* __restrict__ amax,
+                                                        uint8_t* __restrict__ m8, int ldm8) {
+  __shared__ float st[16][2];
+  const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y, col0 = blockIdx.z * gm.ncol;
   const int cg = C >> 4;
-  const long n = (long)B * P * C;
-  GRID_STRIDE(e, n) {
-    const int c = (int)(e % C);
-    const long pix = e / C;
-    const int b = (int)(pix / P);
-    const int bg = b * 16 + c / cg;
-    const float rs = stats[bg * 2 + 1];
-    const float zh = (z[pix * ldz + c] - stats[bg * 2]) * rs;
-    z[pix * ldz + c] = rs * (gamma[c] * g[pix * ldg + c] - sums[bg * 2] - zh * sums[bg * 2 + 1]);
+  const int g0 = col0 * 4 / cg;
+  gn_finish_groups(partial, gm.chunks, b, g0, gm.ncol * 4 / cg, inv_n, eps, BWD, BWD ? nullptr : stats, st);
+  const int col = tid % gm.ncol, row = tid / gm.ncol;
+  const bool act = row < gm.rows;
+  const int c = (col0 + col) * 4;
+  const int p0 = chunk * gm.per;
+  int p1 = p0 + gm.per;
+  if (p1 > P) p1 = P;
+  unsigned am = 0;
+  if (act) {
+    // forward: y = (z - mu) * ka + kc;  backward: dz = g * ka - (k1 + zhat * k2), zhat = (z - mu) * rs
+    float ka[4], mu[4], rs[4], kc[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gl = (c + j) / cg - g0, bg = b * 16 + g0 + gl;
+      if (BWD) { mu[j] = stats[bg * 2]; rs[j] = stats[bg * 2 + 1]; kc[j] = rs[j] * st[gl][0]; k2[j] = rs[j] * st[gl][1]; }
+      else { mu[j] = st[gl][0]; rs[j] = st[gl][1]; kc[j] = beta[c + j]; k2[j] = 0.f; }
+      ka[j] = rs[j] * gamma[c + j];
+    }
+    float* zp = z + (size_t)b * P * ldz + c;
+    const float* gp = BWD ? g + (size_t)b * P * ldg + c : nullptr;
+    const float* rp = (!BWD && res) ? res + (size_t)b * P * ldres + c : nullptr;
+    float* yp = BWD ? nullptr : y + (size_t)b * P * ldy + c;
+    auto one = [&](const float4& zv, const float4& xv) -> float4 {      // xv: g (backward) or the residual (forward)
+      float4 o;
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+      float oo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (BWD) oo[j] = xx[j] * ka[j] - (kc[j] + ((zz[j] - mu[j]) * rs[j]) * k2[j]);
+        else {
+          oo[j] = (zz[j] - mu[j]) * ka[j] + kc[j] + xx[j];
+          if (relu) oo[j] = fmaxf(oo[j], 0.f);
+        }
+      }
+      o = make_float4(oo[0], oo[1], oo[2], oo[3]);
+      return o;
+    };
+    int p = p0 + row;
+    for (; p + (GN_UNROLL - 1) * gm.rows < p1; p += GN_UNROLL * gm.rows) {
+      float4 zv[GN_UNROLL], xv[GN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        const size_t pp = (size_t)(p + u * gm.rows);
+        zv[u] = *reinterpret_cast<const float4*>(zp + pp * ldz);
+        if (BWD) xv[u] = *reinterpret_cast<const float4*>(gp + pp * ldg);
+        else xv[u] = rp ? *reinterpret_cast<const float4*>(rp + pp * ldres) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        const size_t pp = (size_t)(p + u * gm.rows);
+        const float4 o = one(zv[u], xv[u]);
+        am = amax_f4(am, o);
+        if (BWD) *reinterpret_cast<float4*>(zp + pp * ldz) = o;
+        else {
+          *reinterpret_cast<float4*>(yp + pp * ldy) = o;
+          if (m8) m8[((size_t)b * P + pp) * ldm8 + (c >> 2)] = relu_bits(o);
+        }
+      }
+    }
+    for (; p < p1; p += gm.rows) {
+      const float4 zv = *reinterpret_cast<const float4*>(zp + (size_t)p * ldz);
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BWD) xv = *reinterpret_cast<const float4*>(gp + (size_t)p * ldg);
+      else if (rp) xv = *reinterpret_cast<const float4*>(rp + (size_t)p * ldres);
+      const float4 o = one(zv, xv);
+      am = amax_f4(am, o);
+      if (BWD) *reinterpret_cast<float4*>(zp + (size_t)p * ldz) = o;
+      else {
+        *reinterpret_cast<float4*>(yp + (size_t)p * ldy) = o;
+        if (m8) m8[((size_t)b * P + p) * ldm8 + (c >> 2)] = relu_bits(o);
+      }
+    }
   }
+  if (amax) amax_block_commit(am, amax);
 }
+int gn_partial_floats(int B) { return B * 16 * GN_MAX_CHUNKS * 2; }
 void launch_gn_forward(const float* z, int ldz, const float* gamma, const float* beta, const float* res, int ldres,
                        float* y, int ldy, float* stats, float* partial, int B, int P, int C, float eps, int relu,
-                       hipStream_t s) {
-  hipLaunchKernelGGL((gn_partial_kernel<false>), dim3(GN_CHUNKS, B * 16), dim3(256), 0, s, z, ldz, nullptr, 0, nullptr,
-                     nullptr, (float2*)partial, P, C);
-  hipLaunchKernelGGL(gn_final_kernel, dim3((B * 16 + 63) / 64), dim3(64), 0, s, (const float2*)partial, stats, B * 16,
-                     1.0 / ((double)P * (C / 16)), eps, 0);
-  const long n = (long)B * P * C;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, z, ldz, stats, gamma, beta, res,
-                     ldres, y, ldy, B, P, C, relu);
+                       hipStream_t s, unsigned* amax_y, uint8_t* m8, int ldm8) {
+  const GnGeom gm = gn_geom(B, P, C);
+  const dim3 grid(gm.chunks, B, gm.colblocks);
+  const double inv_n = 1.0 / ((double)P * (C / 16));
+  hipLaunchKernelGGL((gn_stats_kernel<false>), grid, dim3(256), 0, s, z, ldz, nullptr, 0, nullptr, nullptr, (float2*)partial, P, C, gm);
+  hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(256), 0, s, const_cast<float*>(z), ldz, nullptr, 0, stats, (const float2*)partial,
+                     inv_n, eps, gamma, beta, res, ldres, y, ldy, P, C, relu, gm, amax_y, relu ? m8 : nullptr, ldm8);
 }
 void launch_gn_backward(float* z, int ldz, const float* g, int ldg, const float* gamma, const float* stats,
-                        float* sums, float* partial, int B, int P, int C, hipStream_t s) {
-  hipLaunchKernelGGL((gn_partial_kernel<true>), dim3(GN_CHUNKS, B * 16), dim3(256), 0, s, z, ldz, g, ldg, gamma, stats,
-                     (float2*)partial, P, C);
-  hipLaunchKernelGGL(gn_final_kernel, dim3((B * 16 + 63) / 64), dim3(64), 0, s, (const float2*)partial, sums, B * 16,
-                     1.0 / ((double)P * (C / 16)), 0.f, 1);
-  const long n = (long)B * P * C;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, z, ldz, g, ldg, stats, sums,
-                     gamma, B, P, C);
+                        float* partial, int B, int P, int C, hipStream_t s, unsigned* amax_dz) {
+  const GnGeom gm = gn_geom(B, P, C);
+  const dim3 grid(gm.chunks, B, gm.colblocks);
+  const double inv_n = 1.0 / ((double)P * (C / 16));
+  hipLaunchKernelGGL((gn_stats_kernel<true>), grid, dim3(256), 0, s, z, ldz, g, ldg, gamma, stats, (float2*)partial, P, C, gm);
+  hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, s, z, ldz, g, ldg, const_cast<float*>(stats), (const float2*)partial, inv_n,
+                     0.f, gamma, nullptr, nullptr, 0, nullptr, 0, P, C, 0, gm, amax_dz, nullptr, 0);
 }
 }  // namespace eosvos
 

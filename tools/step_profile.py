@@ -9,7 +9,7 @@ from eosvos_amd import synthetic  # noqa: E402
 from eosvos_amd.engine import Engine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-eng = Engine('resnet50', 480, 854, max_batch=B)
+eng = Engine('resnet50', 480, 854, max_batch=B, norm=os.environ.get('EOSVOS_STEP_NORM', 'bn'))      # EOSVOS_STEP_NORM=gn: GroupNorm(16) mode
 eng.load_model_state(synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50'))
 x, y = synthetic.synthetic_frames(B, 480, 854)
 xg, yg = x.cuda(), y.cuda()
