@@ -71,20 +71,22 @@ def dtype_name(mode):
     return f'f32 ({mode} split)' if mode in MFMAS_PER_FMA else 'f32'
 
 
-def self_launch(a, argv):
+def self_launch(a, argv, script=None, need_gpus=True):
     """`--gpus N > 1` outside torch.distributed.run: start the N ranks as fresh child processes (this process has not
-    touched the GPU: counting devices does not initialise it) and relay rank 0's JSON line."""
+    touched the GPU: counting devices does not initialise it) and relay rank 0's JSON line.  A rank that fails takes the
+    run with it: torch.distributed.run tears the other ranks down and this process exits non-zero without a result line.
+    (`script` / `need_gpus`: the CPU test of exactly that, tests/test_multiprocess.py.)"""
     import socket
     import subprocess
     n = torch.cuda.device_count()
-    if n < a.gpus:
+    if need_gpus and n < a.gpus:
         raise SystemExit(f'bench.py --gpus {a.gpus}: only {n} GPU(s) visible')
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+           '--master-port', str(port), script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for out in proc.stdout:

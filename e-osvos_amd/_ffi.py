@@ -76,6 +76,11 @@ _SIGNATURES = {
                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_int, ctypes.c_int64, ctypes.c_int64]),
     'eosvos_alias_state': (ctypes.c_int, [_E, _E]),
+    'eosvos_unalias_state': (ctypes.c_int, [_E]),
+    'eosvos_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
+    'eosvos_comm_init_rank': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'eosvos_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'eosvos_allreduce_sum': (ctypes.c_int, [_E, c_float_p, ctypes.c_int64, ctypes.c_void_p]),
     'eosvos_time_hot_kernel': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                               ctypes.POINTER(ctypes.c_double)]),
     'eosvos_bench_conv': (ctypes.c_int, [_E, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

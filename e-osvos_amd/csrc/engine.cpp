@@ -18,6 +18,7 @@
 // buffers are written in place by their producers (channel-slice views), gradients of
 // activations hold dL/d(pre-ReLU) so the ReLU mask and the frozen-norm scale never need
 // their own pass.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -258,9 +259,14 @@ struct eosvos_engine {
   std::map<long, int> tuned_budget;
   int budget_for(int ci, int kind, int B) const {
     if (wg_budget != 0 || tuned_budget.empty()) return wg_budget;
-    auto it = tuned_budget.find(((long)ci * 4 + kind) * 64 + B);
+    auto it = tuned_budget.find(((long)ci * 4 + kind) * 4096 + B);
     return it == tuned_budget.end() ? wg_budget : it->second;
   }
+  // eosvos_alias_state: this engine reads `alias_src`'s learned init / per-neuron lr (own_* keep its own buffers for
+  // eosvos_unalias_state and for the day the source goes first); `aliased_by` = the engines that read THIS engine's
+  eosvos_engine* alias_src = nullptr;
+  float *own_Winit = nullptr, *own_lr = nullptr;
+  std::vector<eosvos_engine*> aliased_by;
   int mode = -1;                      // eosvos_set_engine_matrix_mode: this engine's own matrix mode (-1: follow the process-wide one)
   int plan_mode = -1;                 // matrix mode the cached launch plans (wg_plans, upd_tab) were built for, see plans_match_mode()
 
@@ -1255,10 +1261,12 @@ int eosvos_set_wg_budget(eosvos_engine* e, int workgroups) {
 int eosvos_set_launch_budget(eosvos_engine* e, int conv_idx, int kind, int batch, int workgroups) {
   if (!e) return fail("null engine");
   if (conv_idx < 0 || conv_idx >= (int)e->t.convs.size() || kind < 0 || kind > 2 || batch < 1 || batch > e->maxB) return fail("bad launch key");
-  const long key = ((long)conv_idx * 4 + kind) * 64 + batch;
+  const long key = ((long)conv_idx * 4 + kind) * 4096 + batch;      // (batch < 4096: eosvos_create refuses larger engines' operands anyway)
+  if (batch >= 4096) return fail("bad launch key");
   if (workgroups < 0) e->tuned_budget.erase(key);
   else e->tuned_budget[key] = conv_clamp_wg_budget(workgroups);
   for (auto& tab : e->upd_tab) tab = nullptr;      // weight-gradient split counts follow the budget
+  e->wg_plans.clear();                             // ... and so do the grouped launches' tables
   return 0;
 }
 int eosvos_set_side_stream(eosvos_engine* e, int on) {
@@ -1544,8 +1552,16 @@ int eosvos_create_ex(eosvos_engine** out, int arch, int norm_mode, int height, i
   return 0;
 }
 
+static int unalias_impl(eosvos_engine* e);
 int eosvos_destroy(eosvos_engine* e) {
   if (!e) return 0;
+  // engines that read this engine's learned state get their own copy back before its memory goes; an alias leaves its source's list
+  while (!e->aliased_by.empty()) (void)unalias_impl(e->aliased_by.back());
+  if (e->alias_src) {
+    auto& v = e->alias_src->aliased_by;
+    v.erase(std::remove(v.begin(), v.end(), e), v.end());
+    e->alias_src = nullptr;
+  }
   (void)hipStreamSynchronize(e->s);
   if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
   for (auto& evt : e->ev) (void)hipEventDestroy(evt);
@@ -2381,7 +2397,23 @@ int eosvos_outer_step(eosvos_engine* e, float* state, float* grad, float* exp_av
   launch_outer_step(e->outer_tab, (int)t.convs.size(), lr_blocks, lr_blocks + (learn_model_init ? e->outer_blocks : 0), state, grad,
                     exp_avg, exp_avg_sq, e->Winit, e->Wp, e->lr, h, e->s);
   e->lr_level = EOSVOS_LR_NEURON; e->lr_log = use_log ? 1 : 0;
+  for (eosvos_engine* a : e->aliased_by) { a->lr_level = e->lr_level; a->lr_log = e->lr_log; }      // they read the state just written
   HIPOK(hipGetLastError());
+  return 0;
+}
+// give `e` its own learned init / lr buffers back, holding what it has been reading (its source's current values)
+static int unalias_impl(eosvos_engine* e) {
+  eosvos_engine* src = e->alias_src;
+  if (!src) return 0;
+  (void)hipStreamSynchronize(src->s);
+  (void)hipStreamSynchronize(e->s);
+  if (hipMemcpy(e->own_Winit, src->Winit, (size_t)e->t.nparam * 4, hipMemcpyDeviceToDevice) != hipSuccess ||
+      hipMemcpy(e->own_lr, src->lr, (size_t)e->t.nlr * 4, hipMemcpyDeviceToDevice) != hipSuccess)
+    return fail("eosvos_unalias_state: copy of the learned state failed");
+  e->Winit = e->own_Winit; e->lr = e->own_lr;
+  e->lr_level = src->lr_level; e->lr_log = src->lr_log;
+  src->aliased_by.erase(std::remove(src->aliased_by.begin(), src->aliased_by.end(), e), src->aliased_by.end());
+  e->alias_src = nullptr;
   return 0;
 }
 int eosvos_alias_state(eosvos_engine* e, eosvos_engine* src) {
@@ -2389,10 +2421,89 @@ int eosvos_alias_state(eosvos_engine* e, eosvos_engine* src) {
   if (!e || !src) return fail("null engine");
   if (e == src) return 0;
   if (e->dev != src->dev || e->arch != src->arch) return fail("eosvos_alias_state: engines of different devices / architectures");
+  if (src->alias_src) return fail("eosvos_alias_state: the source engine is itself an alias (alias its source instead)");
+  if (!e->aliased_by.empty()) return fail("eosvos_alias_state: other engines read this engine's state");
+  if (e->alias_src == src) return 0;
+  if (e->alias_src && unalias_impl(e)) return 1;
   HIPOK(hipStreamSynchronize(e->s));
-  e->Winit = src->Winit;              // (e's own buffers stay in its allocation list until it is destroyed)
+  e->own_Winit = e->Winit; e->own_lr = e->lr;
+  e->Winit = src->Winit;              // (e's own buffers stay in its allocation list: eosvos_unalias_state / the source's destroy)
   e->lr = src->lr;
+  e->lr_level = src->lr_level; e->lr_log = src->lr_log;
+  e->alias_src = src;
+  src->aliased_by.push_back(e);
   return 0;
+}
+int eosvos_unalias_state(eosvos_engine* e) {
+  ModeScope mode_scope(e);
+  if (!e) return fail("null engine");
+  return unalias_impl(e);
+}
+
+// ---- RCCL: the one exchange of the meta-training path ------------------------------------------------------------------
+// The library has no link-time dependency on RCCL (it loads on a box without it): the first collective call binds the
+// RCCL already in the process (a torch host has loaded its own) or else loads librccl.so.1 / EOSVOS_RCCL_LIB.
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, eosvos_rccl_id, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllReduce; }
+};
+Rccl g_rccl;
+int rccl_load() {
+  if (g_rccl.ok()) return 0;
+  const char* env = getenv("EOSVOS_RCCL_LIB");
+  void* h = nullptr;
+  if (env && env[0]) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  const char* names[] = {"librccl.so", "librccl.so.1"};
+  for (int pass = 0; pass < 2 && !h; ++pass)          // pass 0: an instance the process already has (RTLD_NOLOAD), pass 1: load one
+    for (const char* n : names) {
+      h = dlopen(n, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_GLOBAL));
+      if (h) break;
+    }
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(std::string("RCCL not found (librccl.so / librccl.so.1 / EOSVOS_RCCL_LIB): ") + (dlerror() ? dlerror() : ""));
+  g_rccl.lib = h;
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, eosvos_rccl_id, int))dlsym(h, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.ok()) return fail("RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
+  return 0;
+}
+int rccl_fail(const char* what, int rc) {
+  return fail(std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+int eosvos_comm_unique_id(eosvos_rccl_id* id) {
+  if (!id) return fail("null argument");
+  if (rccl_load()) return 1;
+  const int rc = g_rccl.GetUniqueId(id);
+  return rc ? rccl_fail("ncclGetUniqueId", rc) : 0;
+}
+int eosvos_comm_init_rank(void** comm, int world_size, const eosvos_rccl_id* id, int rank, int device_id) {
+  if (!comm || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail("bad argument");
+  if (rccl_load()) return 1;
+  HIPOK(hipSetDevice(device_id));
+  const int rc = g_rccl.CommInitRank(comm, world_size, *id, rank);
+  return rc ? rccl_fail("ncclCommInitRank", rc) : 0;
+}
+int eosvos_comm_destroy(void* comm) {
+  if (!comm) return 0;
+  if (rccl_load()) return 1;
+  const int rc = g_rccl.CommDestroy(comm);
+  return rc ? rccl_fail("ncclCommDestroy", rc) : 0;
+}
+int eosvos_allreduce_sum(eosvos_engine* e, float* flat, int64_t n, void* comm) {
+  if (!e || !flat || !comm || n < 1) return fail("bad argument");
+  if (rccl_load()) return 1;
+  const int rc = g_rccl.AllReduce(flat, flat, (size_t)n, 7 /* ncclFloat32 */, 0 /* ncclSum */, comm, e->s);
+  return rc ? rccl_fail("ncclAllReduce", rc) : 0;
 }
 int eosvos_clamp(eosvos_engine* e, float* param, int64_t n, float lo, float hi) {
   ModeScope mode_scope(e);

@@ -20,6 +20,14 @@ def _dev_f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _touched(*tensors):
+    """The library wrote these caller tensors through raw pointers: bump their in-place version counters, so that code which
+    keys a cache on `tensor._version` (MetaOptimizer.load_state_dict's skip of an unchanged state) sees the change."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 LR_LEVELS = {'NEURON': 0, 'TENSOR': 1, 'SINGLE': 2, 'PARAM': 3}      # include/eosvos.h EOSVOS_LR_*
 LOSS_KINDS = {'cross_entropy': 0, 'dice': 1, 'cross_entropy_and_dice': 2, 'class_balanced_cross_entropy': 3}
 
@@ -449,10 +457,12 @@ class Engine:
                                                     float(weight), flags))
             out = torch.empty(1, device=self.device)
             _ffi.check(self.lib.eosvos_last_loss(self.h, _ptr(out)))
+            _touched(flat_meta_grad)
             return out
         l = ctypes.c_float()
         _ffi.check(self.lib.eosvos_meta_grad_ex(self.h, _ptr(images), _ptr(masks), b, _ptr(flat_meta_grad),
                                                 ctypes.byref(l), float(weight), flags))
+        _touched(flat_meta_grad)
         return l.value
 
     def radam_step(self, param, grad, exp_avg, exp_avg_sq, lr, weight_decay, step, grad_scale=1.0,
@@ -460,9 +470,11 @@ class Engine:
         _ffi.check(self.lib.eosvos_radam_step(self.h, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                               param.numel(), lr, weight_decay, betas[0], betas[1], eps, step,
                                               grad_scale, grad_clip))
+        _touched(param, exp_avg, exp_avg_sq)
 
     def clamp(self, param, lo, hi):
         _ffi.check(self.lib.eosvos_clamp(self.h, _ptr(param), param.numel(), lo, hi))
+        _touched(param)
 
     def outer_step(self, state, grad, exp_avg, exp_avg_sq, n_lr, learn_model_init, step, lr_lr, init_lr, weight_decay,
                    grad_scale=1.0, grad_clip=0.0, lr_lo=0.0, lr_hi=float('inf'), use_log=False, frozen_lr=0, frozen_param=0,
@@ -477,6 +489,7 @@ class Engine:
                                               int(bool(learn_model_init)), int(step), lr_lr, init_lr, weight_decay, betas[0], betas[1],
                                               eps, grad_scale, grad_clip, lr_lo, lr_hi, int(bool(use_log)), int(frozen_lr),
                                               int(frozen_param)))
+        _touched(state, grad, exp_avg, exp_avg_sq)
         self.lr_level, self.lr_log, self.n_lr_store = 'NEURON', bool(use_log), self.n_lr
         if learn_model_init:
             self.steps_since_reset = 0
@@ -487,6 +500,20 @@ class Engine:
         _ffi.check(self.lib.eosvos_alias_state(self.h, src.h))
         self._alias_of = src              # keeps `src` alive
 
+    def unalias_state(self):
+        """`eosvos_unalias_state`: own buffers again, holding the state this engine has been reading."""
+        _ffi.check(self.lib.eosvos_unalias_state(self.h))
+        self._alias_of = None
+
+    def allreduce_sum(self, flat, comm):
+        """`eosvos_allreduce_sum`: in-place all-reduce(sum) of a flat device tensor over the RCCL communicator `comm` (an
+        `RcclComm`), asynchronous on this engine's stream -- the exchange step of meta-training for hosts that do not run
+        torch.distributed (`src/util/meta_run.py:237-238` + `src/train_meta.py:361-366` in the reference)."""
+        self._check_stream()
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        _ffi.check(self.lib.eosvos_allreduce_sum(self.h, _ptr(flat), flat.numel(), comm.handle))
+        _touched(flat)
+
     def synchronize(self):
         _ffi.check(self.lib.eosvos_synchronize(self.h))
 
@@ -496,6 +523,7 @@ class Engine:
         r = self.lib.eosvos_set_wg_budget(self.h, int(workgroups))
         if r < 0:
             _ffi.check(1)
+        self._wg_budget = r
         return r
 
     def autotune(self, batch, budgets=(0, 448, 384, 320, 256), reps=8, min_gain=0.04):
@@ -505,6 +533,7 @@ class Engine:
         (`eosvos_set_launch_budget`).  Returns {(conv, kind): budget} of the overrides set."""
         n = int(self.lib.eosvos_num_convs(self.arch))
         chosen = {}
+        prev = getattr(self, '_wg_budget', 0)        # the budget in effect is put back afterwards ...
         for ci in range(1, n):
             for kind in (0, 1, 2):
                 ms = {}
@@ -523,6 +552,7 @@ class Engine:
         self.set_wg_budget(0)
         for (ci, kind), b in chosen.items():
             _ffi.check(self.lib.eosvos_set_launch_budget(self.h, ci, kind, batch, b))
+        self.set_wg_budget(prev)                     # (... the overrides apply while the engine plans for the whole chip)
         return chosen
 
     def set_side_stream(self, on):
@@ -624,3 +654,28 @@ class Engine:
         _ffi.check(self.lib.eosvos_test_conv_bwd(self.h, _ptr(x_nhwc), _ptr(w_oihw), _ptr(g_nhwc), B, H, W, Cin,
                                                  Cout, k, stride, dil, pad, _ptr(dx), _ptr(dw)))
         return dx, dw
+
+
+class RcclComm:
+    """An RCCL communicator owned through the C-ABI (`eosvos_comm_*`, include/eosvos.h): one rank per GPU.  Rank 0 makes
+    `RcclComm.unique_id()` (128 bytes) and hands it to the other ranks by the host's own means; constructing the communicator
+    is collective over all `world_size` ranks."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _ffi.check(_ffi.load().eosvos_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, world_size, rank, unique_id, device=0):
+        assert len(unique_id) == 128
+        self.world_size, self.rank = world_size, rank
+        h = ctypes.c_void_p()
+        self._id = ctypes.create_string_buffer(unique_id, 128)
+        _ffi.check(_ffi.load().eosvos_comm_init_rank(ctypes.byref(h), world_size, self._id, rank, int(device)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            _ffi.check(_ffi.load().eosvos_comm_destroy(self.handle))
+            self.handle = None

@@ -43,12 +43,15 @@ class MetaTrainer:
     def __init__(self, engine, dist=None, meta_batch_size=4, model_init_lr=1e-5, log_init_lr_lr=1e-5,
                  model_init_weight_decay=1e-3, grad_clip=None, max_lr=None, lr_hierarchy_level='NEURON',
                  use_log_init_lr=False, loss_func='cross_entropy', learn_model_init=True, freeze_encoder=False,
-                 extra_engines=()):
+                 extra_engines=(), comm=None):
         """`extra_engines`: more engines on the SAME GPU (each built on its own torch stream): the tasks of one
         meta-iteration are then dealt over all of them and run concurrently -- a batch-1 task leaves CUs idle in its
         tails and small grids that a second and third task fill (measured: 3 engines 1.17x the task rate of 1)."""
         self.eng = engine
         self.engines = [engine] + list(extra_engines)
+        # `comm`: an `engine.RcclComm` -- the exchange then goes through the library's own `eosvos_allreduce_sum` (a host
+        # without torch.distributed); default: `dist.all_reduce` (backend nccl = RCCL)
+        self.comm = comm
         # engines that share the GPU plan each launch for part of the chip (`eosvos_set_wg_budget`): less K splitting,
         # fewer parked partial tiles; the other tasks' launches fill the remaining CUs
         self.wg_budget = int(os.environ.get('EOSVOS_META_WG_BUDGET', CONCURRENT_WG_BUDGET.get(min(len(self.engines), 4), 0)))
@@ -247,7 +250,13 @@ class MetaTrainer:
                 xt, yt = local_tasks[0][0], local_tasks[0][1]
                 with _on_stream(real[0]):
                     flag = int(real[0].verify_matrix_mode(xt, yt) != 'f16x3')
-        if self.dist is not None and self.dist.is_initialized():
+        if self.comm is not None:
+            t = torch.tensor([float(flag)], device=self.state.device)
+            with _on_stream(self.eng):
+                self.eng.allreduce_sum(t, self.comm)
+                self.eng.synchronize()
+            flag = int(float(t.item()) > 0.0)
+        elif self.dist is not None and self.dist.is_initialized():
             t = torch.tensor([flag], device=self.state.device, dtype=torch.int32)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             flag = int(t.item())
@@ -277,7 +286,15 @@ class MetaTrainer:
             if self.state.is_cuda and getattr(self.eng, 'stream', None) is not None:
                 torch.cuda.current_stream(self.state.device).wait_stream(self.eng.stream)
         t1 = tick()
-        if self.dist is not None and self.dist.is_initialized():
+        if self.comm is not None:
+            # the library's own collective, on the first engine's stream (ordered after the tasks: the streams were joined above)
+            es = getattr(self.eng, 'stream', None)
+            cur = torch.cuda.current_stream(self.state.device) if self.state.is_cuda else None
+            if es is not None and cur is not None and es != cur:
+                es.wait_stream(cur)
+            with _on_stream(self.eng):
+                self.eng.allreduce_sum(self.grad, self.comm)
+        elif self.dist is not None and self.dist.is_initialized():
             # sum over ranks, one 161 MB message (also with ONE rank: the collective, its device binding and its stream
             # ordering are then the code that runs on a node -- tests/test_gpu_nccl.py)
             self.dist.all_reduce(self.grad)

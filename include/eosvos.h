@@ -296,6 +296,27 @@ int eosvos_outer_step(eosvos_engine* e, float* state, float* grad, float* exp_av
  * eosvos_outer_step / eosvos_set_init / eosvos_set_lr on `src` serves all of them).  `src` must outlive `e`, both on one
  * device; the caller orders `e`'s stream after the stream of `src` that wrote the state. */
 int eosvos_alias_state(eosvos_engine* e, eosvos_engine* src);
+/* Undo eosvos_alias_state: `e` gets its own buffers back, holding the learned init / lr it has been reading (a copy of the
+ * source's current state).  The library tracks the relation: destroying a source first un-aliases every engine that reads it
+ * (they keep a valid copy), destroying an alias removes it from its source's list, eosvos_outer_step on the source updates
+ * the lr level / log flag of its aliases. */
+int eosvos_unalias_state(eosvos_engine* e);
+
+/* ---- the exchange step of meta-training over RCCL (SURVEY 8b `allreduce_sum(flat, n, comm)`) ------------------------
+ * Replaces the reference's hand-off of per-process gradients into shared CPU tensors (src/util/meta_run.py:237-238) +
+ * the main process's sum (src/train_meta.py:361-366) by ONE in-place all-reduce(sum) of the flat meta-gradient
+ * ([lr state | init], 40 318 387 floats for ResNet-50) on the engine's stream, between the tasks' gradient accumulation and
+ * eosvos_outer_step.  For hosts that are not torch processes (a torch host may keep using torch.distributed, backend "nccl" =
+ * RCCL: the Python shim's default): rank 0 calls eosvos_comm_unique_id and hands the 128 bytes to the other ranks by its own
+ * means, every rank calls eosvos_comm_init_rank (collective: blocks until all `world_size` ranks have called; one GPU per
+ * rank), then eosvos_allreduce_sum once per meta-iteration (collective, asynchronous on the engine's stream, deterministic
+ * for a fixed world size and topology), eosvos_comm_destroy at the end.  RCCL is bound at the first of these calls (the
+ * instance already in the process, else librccl.so.1 / $EOSVOS_RCCL_LIB); the library itself loads without it. */
+typedef struct { char internal[128]; } eosvos_rccl_id; /* = ncclUniqueId */
+int eosvos_comm_unique_id(eosvos_rccl_id* id);
+int eosvos_comm_init_rank(void** comm, int world_size, const eosvos_rccl_id* id, int rank, int device_id);
+int eosvos_comm_destroy(void* comm);
+int eosvos_allreduce_sum(eosvos_engine* e, float* flat, int64_t n, void* comm);
 
 /* ---- instrumentation ----------------------------------------------------------------- */
 /* Time `reps` launches of the largest conv_igemm launch of a fine-tune iteration (decoder.last_conv.0

@@ -82,3 +82,19 @@ def test_concurrent_validation_process_beside_meta_training(tmp_path):
     # child gone: its pid was logged by nobody, so check there is no process left with our run dir on its command line
     left = subprocess.run(['pgrep', '-f', run], capture_output=True, text=True).stdout.split()
     assert not left, left
+
+
+def test_c_abi_rccl_allreduce_world_size_1(tmp_path):
+    """`eosvos_comm_unique_id / _init_rank / _destroy` + `eosvos_allreduce_sum` (`allreduce_sum(flat, n, comm)`):
+    the library's own RCCL collective, no torch.distributed in the process, in a fresh process on the GPU.  Also: destroying
+    the engine whose learned state the others alias FIRST leaves them with a valid copy (`eosvos_unalias_state` semantics,
+    ADVICE r04)."""
+    out = str(tmp_path / 'rccl_cabi.pt')
+    env = clean_env()
+    p = subprocess.run([sys.executable, os.path.join(HERE, 'mp_workers', 'rccl_cabi_worker.py'), out], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = torch.load(out, weights_only=False)
+    assert r['identity']
+    for tag in ('one', 'two'):
+        assert r[tag]['equal'] and r[tag]['finite'] and r[tag]['moved'] > 0, r[tag]
+        assert r[tag]['losses'] == r[tag]['losses_ref']

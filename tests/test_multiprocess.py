@@ -91,6 +91,21 @@ def test_bench_gpus_flag_must_match_the_world_size(tmp_path):
     assert p.returncode != 0 and 'WORLD_SIZE=1' in p.stderr and p.stdout.strip() == ''
 
 
+def test_bench_self_launch_fails_when_a_rank_fails():
+    """`bench.py --gpus N` starts its N ranks as fresh children (`python -m torch.distributed.run`); when one of them dies --
+    here rank 1 of 2, before the first collective, while rank 0 waits in a barrier -- the launcher tears the others down and
+    bench.py exits non-zero WITHOUT a result line (round-4 verdict, next #8)."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location('bench_under_test2', os.path.join(os.path.dirname(HERE), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = types.SimpleNamespace(gpus=2)
+    with pytest.raises(SystemExit) as exc:
+        bench.self_launch(a, ['--gpus', '2'], script=os.path.join(W, 'failing_rank_worker.py'), need_gpus=False)
+    assert 'rank processes failed' in str(exc.value) and 'result line: False' in str(exc.value)
+
+
 def test_bench_traffic_lookup_covers_every_leading_kernel_symbol(tmp_path, monkeypatch):
     """`roofline.traffic` comes from the committed PMC passes; three kernel symbols take a similar share of the step and which
     one leads flips between runs, so the artifact records all of them (`others`) and the lookup must find each -- and must
