@@ -2964,12 +2964,15 @@ int wgrad_pick_splits(int P, int Cout, int Cin, int T, int wg_budget, int mode) 
   int best = 1;
   double best_eff = 0.0;
   static const int minsteps = env_int("EOSVOS_TUNE_WG_MINSTEPS", 384 / EOSVOS_WG_BKP);   // 12 steps = 384 pixels per split (round 4: batch 1 4.57 -> 4.54 ms, batch 3 +-0; 8 before; 4 / 6: batch 1 +1.3 ... 2 %)
+  // the first (= smallest) split count that fills its rounds to `eff_enough`: fewer splits park fewer slabs (each one a full
+  // copy of the weight gradient that the update kernel reads back)
+  static const double eff_enough = env_int("EOSVOS_TUNE_WG_EFF", 80) / 100.0;      // round 5: 93 -> 80: batch 3 8.79 -> 8.75 ms in three interleaved rounds (70: +-0, 55: +0.15)
   for (int s = 1; s <= 512 && steps / s >= minsteps; ++s) {
     const long wgs = (long)tiles * s;
     const long rounds = (wgs + RES - 1) / RES;
     const double eff = (double)wgs / (double)(rounds * RES);
     if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
-    if (eff >= 0.93) { best = s; break; }
+    if (eff >= eff_enough) { best = s; break; }
   }
   return best;
 }
