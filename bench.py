@@ -49,7 +49,7 @@ H, W, BATCH = 480, 854, 3
 FLOPS_PER_FRAME_ITER = 647.8e9      # fwd + dgrad + wgrad as direct convolutions, no stem dgrad
 FP32_MATRIX_PEAK = 157.3            # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_DENSE_PEAK = 2500.0            # TFLOP/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_dominant_kernel.json', 'r03_pmc_dominant_kernel.json')]
+PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r05_pmc_dominant_kernel.json', 'r04_pmc_dominant_kernel.json')]
 
 
 MFMAS_PER_FMA = {'f16x3': 3, 'bf16x6': 6}      # 16-bit MFMA issues per fp32 multiply-accumulate

@@ -34,4 +34,4 @@ if 'GPU_MAX_HW_QUEUES' not in _os_env.environ:
     del _sys, _t
 del _os_env
 
-__version__ = '0.6.0'
+__version__ = '0.7.0'

@@ -1229,7 +1229,7 @@ int wgrad_max_splits(int P, int Cout, int Cin, int T, int wg_budget) {
 
 extern "C" {
 
-const char* eosvos_version(void) { return "eosvos-mi355x 0.6 (gfx950, fp32 implicit GEMM on the fp16 matrix cores: 2-way split, 3 partial products on v_mfma_f32_16x16x32_f16; bf16x6 and fp32-MFMA modes selectable)"; }
+const char* eosvos_version(void) { return "eosvos-mi355x 0.7 (gfx950, fp32 implicit GEMM on the fp16 matrix cores: 2-way split, 3 partial products on v_mfma_f32_16x16x32_f16; bf16x6 and fp32-MFMA modes selectable)"; }
 const char* eosvos_last_error(void) { return g_err.c_str(); }
 
 int eosvos_set_matrix_mode(int mode) {

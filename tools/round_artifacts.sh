@@ -3,7 +3,7 @@
 #   PMC passes of the step's dominant kernel (-> profiles/$R_pmc_dominant_kernel.json, read by bench.py for roofline.traffic),
 #   the bench lines (fine-tune + meta), rocprofv3 --kernel-trace --stats of the same bench command, per-layer reports.
 # usage: tools/round_artifacts.sh r03
-R=${1:-r04}
+R=${1:-r05}
 O=$PWD/gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --no-cpu-baseline --no-meta --no-ab > $O/bench_quick.json 2> $O/bench_quick.err
@@ -22,3 +22,6 @@ tools/layer_prof.sh $R 1 > /dev/null 2>&1
 python3 tools/parity_margins.py > $O/parity_margins.txt 2>&1
 python3 tools/two_engines.py 1 > $O/two_engines_b1.txt 2>&1
 python3 tools/two_engines.py 3 > $O/two_engines_b3.txt 2>&1
+python3 tools/steptime_gn.py > $O/gn_steptime.txt 2>&1
+tools/gn_profile.sh $R/gn 3 > /dev/null 2>&1; cp $O/gn/gn_b3_kernel_stats.csv $O/gn_b3_kernel_stats.csv 2>/dev/null
+python3 tools/eval_sequence_time.py > $O/eval_sequence_time.txt 2>&1
