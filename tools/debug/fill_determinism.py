@@ -59,9 +59,22 @@ if __name__ == '__main__':
     H, W, B = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (480, 854, 3)
     norm = sys.argv[4] if len(sys.argv) > 4 else 'bn'
     outs = {}
-    for name, fill in FILLS.items():
+    runs = dict(FILLS)
+    # AB_LIBS="before=e-osvos_amd/variants/libeosvos_before.so": instead of the fills, the default library ('zero_pages') against
+    # other builds -- is a kernel change bit-identical?
+    libs = {}
+    if os.environ.get('AB_LIBS'):
+        runs = {'zero_pages': None}
+        for item in os.environ['AB_LIBS'].split(','):
+            k, v = item.split('=')
+            runs[k] = None
+            libs[k] = os.path.abspath(v)
+    for name, fill in runs.items():
         env = dict(os.environ, EOSVOS_MODE_GUARD='0')
         env.pop('EOSVOS_DEBUG_FILL', None)
+        env.pop('EOSVOS_LIB', None)
+        if name in libs:
+            env['EOSVOS_LIB'] = libs[name]
         if fill:
             env['EOSVOS_DEBUG_FILL'] = fill
         path = f'/tmp/fill_{name}.pt'
