@@ -797,3 +797,39 @@ def test_wg_budget_changes_rounding_only(small_engine, weights):
             assert abs(a - b) <= LOSS_RTOL * 50 * abs(b), (budget, a, b)          # 4 steps of accumulated rounding
         d = (out[budget][1] - out[0][1]).norm() / (out[0][1] - theta0).norm()
         assert float(d) < 2e-3, (budget, float(d))                             # vs the size of the update itself
+
+
+@pytest.mark.parametrize('norm', ['bn', 'gn'])
+@pytest.mark.parametrize('hw', [SMALL, (97, 163)], ids=lambda s: 'x'.join(map(str, s)))
+def test_smaller_batch_after_a_larger_one_is_bit_identical_to_a_fresh_engine(weights, hw, norm):
+    """Rows beyond the current batch hold the previous, larger batch's data (an engine of max_batch 3 that ran 3 frames and then
+    runs 1 or 2: inference tails, adaptation batches with empty pseudo-labels, `evaluate.py:231-240`).  No kernel may read them:
+    a fine-tune step at batch 1 / 2 on such an engine equals, bit for bit, the same step on a fresh engine -- loss, parameters,
+    logits -- in every matrix mode.  (The round-4 stem bug was a read of memory the current call had not written.)"""
+    from eosvos_amd.engine import Engine
+    sd, lrs = weights
+    H, W = hw
+    x3, y3 = synthetic.synthetic_frames(3, H, W, seed=41)
+    used = Engine('resnet50', H, W, max_batch=3, device=DEV, norm=norm)
+    fresh = Engine('resnet50', H, W, max_batch=3, device=DEV, norm=norm)
+    try:
+        for e in (used, fresh):
+            e.load_model_state(sd, lrs)
+            e._verify_pending = False
+        for mode in ('f16x3', 'bf16x6', 'f32'):
+            for b in (1, 2):
+                xb, yb = synthetic.synthetic_frames(b, H, W, seed=50 + b)
+                xb, yb = xb.to(DEV), yb.to(DEV)
+                for e in (used, fresh):
+                    e.set_engine_matrix_mode(mode)
+                    e.reset()
+                used.finetune_step(x3.to(DEV), y3.to(DEV))           # fills every row of every buffer with batch-3 data
+                used.infer(x3.to(DEV))
+                used.reset()
+                la, lb = used.finetune_step(xb, yb), fresh.finetune_step(xb, yb)
+                assert la == lb, (mode, b, la, lb)
+                assert torch.equal(used.get_params(), fresh.get_params()), (mode, b)
+                assert torch.equal(used.forward(xb), fresh.forward(xb)), (mode, b)
+    finally:
+        used.close()
+        fresh.close()
