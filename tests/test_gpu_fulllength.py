@@ -37,10 +37,19 @@ def _record(name, row):
             f.write(json.dumps(dict(row, case=name)) + '\n')
 
 
+@pytest.mark.parametrize('fixture', ['g20', 'g20b', 'g20c'])
 @pytest.mark.parametrize('mode', MODES)
-def test_c2_fifty_iterations_batch3_vs_reference(golden_dir, mode):
+def test_c2_fifty_iterations_batch3_vs_reference(golden_dir, mode, fixture):
+    """G20 = G15's batch sequence continued to 50 iterations (marks after 3, 10, 25, 50); G20b / G20c = two more 50-iteration
+    reference trajectories on other batch sequences (final mark only): the drift of a trajectory is amplified rounding noise, so
+    ONE trajectory says little about where another lands (profiles/r05_ab_log.txt: a different split plan moved a 240-iteration
+    trajectory from 3.6e-4 to 1.0e-3)."""
     from eosvos_amd.engine import Engine
-    g = np.load(os.path.join(golden_dir, 'g20_c2_fulllength.npz'))
+    path = os.path.join(golden_dir, f'{fixture}_c2_fulllength.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'fixture {fixture} not generated')
+    g = np.load(path)
+    seed0 = int(g['seed0'][0]) if 'seed0' in g.files else 21
     T = len(g['losses'])
     marks = [int(m) for m in g['marks']]
     tr = topology.trainable('resnet50')
@@ -50,10 +59,10 @@ def test_c2_fifty_iterations_batch3_vs_reference(golden_dir, mode):
         eng.load_model_state(synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50'))
         eng._verify_pending = False
         eng.set_engine_matrix_mode(mode)
-        x0 = synthetic.synthetic_frames(3, *FULL, seed=21)[0].to(DEV)
+        x0 = synthetic.synthetic_frames(3, *FULL, seed=seed0)[0].to(DEV)
         losses, rows = [], []
         for it in range(T):
-            x, y = synthetic.synthetic_frames(3, *FULL, seed=21 + it)
+            x, y = synthetic.synthetic_frames(3, *FULL, seed=seed0 + it)
             losses.append(eng.finetune_step(x.to(DEV), y.to(DEV)))
             k = it + 1
             if k in marks:
@@ -75,10 +84,10 @@ def test_c2_fifty_iterations_batch3_vs_reference(golden_dir, mode):
             ref = g[f'param_{i}']
             got = params[offs[i]:offs[i + 1]].view(*ref.shape).numpy()
             pel = max(pel, float(np.abs(got - ref).max() / np.abs(ref).max()))
-        print(f'MARGIN C2 T=50 {mode}: loss rel {loss_rel:.2e}, params elementwise {pel:.2e}, ' +
+        print(f'MARGIN C2 T=50 {fixture} {mode}: loss rel {loss_rel:.2e}, params elementwise {pel:.2e}, ' +
               '; '.join('after %d: logits %.2e, mask bits %d (near-zero %d), param L2 %.1e' % (
                   r['iter'], r['logits'], r['mask_bits'], r['near_zero'], r['param_l2_rel']) for r in rows))
-        _record('c2_t50_b3', {'mode': mode, 'loss_rel': loss_rel, 'param_elem': pel, 'marks': rows})
+        _record('c2_t50_b3' if fixture == 'g20' else f'c2_t50_b3_{fixture}', {'mode': mode, 'loss_rel': loss_rel, 'param_elem': pel, 'marks': rows})
         assert loss_rel <= 2e-4, loss_rel
         for r in rows:
             assert r['logits'] <= 1e-3, r                                  # north_star: logits within 1e-3, at every mark
