@@ -243,13 +243,14 @@ class MetaTrainer:
         the collective whether it has a task or not (all ranks call `meta_iteration` equally often)."""
         self._mode_check_pending = False
         real = [e for e in self.engines if getattr(e, 'verify_matrix_mode', None) is not None]
-        flag = 0
+        flag, checked = 0, False
         if real and local_tasks and getattr(real[0], '_verify_pending', False):
             from .engine import _guard_enabled
             if _guard_enabled() and real[0].matrix_mode == 'f16x3':
                 xt, yt = local_tasks[0][0], local_tasks[0][1]
                 with _on_stream(real[0]):
                     flag = int(real[0].verify_matrix_mode(xt, yt) != 'f16x3')
+                checked = True
         if self.comm is not None:
             t = torch.tensor([float(flag)], device=self.state.device)
             with _on_stream(self.eng):
@@ -263,7 +264,8 @@ class MetaTrainer:
         for e in real:
             if flag and e.matrix_mode == 'f16x3':
                 e.set_engine_matrix_mode('bf16x6')
-            e._verify_pending = e._step_check_pending = False
+            if checked or flag:          # (a rank that had no task to check with keeps its engines' own lazy check, unless the
+                e._verify_pending = e._step_check_pending = False      # collective verdict already moved them to the exact mode)
         return flag
 
     def meta_iteration(self, local_tasks, inner_steps=5, bptt_epochs=None, multi_step_bptt_loss=None):

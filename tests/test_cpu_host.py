@@ -265,3 +265,59 @@ def test_config_accepts_every_reference_key(golden_dir):
             assert cfg[k] == v, (name, k)
     with pytest.raises(KeyError):
         config.parse_cli(['with', 'not_a_reference_key=1'])
+
+
+def test_collective_matrix_mode_verdict_reaches_every_engine(monkeypatch):
+    """`MetaTrainer._collective_mode_check` (round 5): the f16x3 range guard runs once, on the first engine with the rank's first task,
+    at the first meta-iteration after `load_state`; its verdict moves EVERY engine of the trainer (and, all-reduced, of every rank)
+    -- engines of one trainer in different modes would average gradients of slightly different functions.  Host logic only: a
+    stand-in engine with the product engine's guard attributes."""
+    from eosvos_amd import synthetic
+    from eosvos_amd.meta_run import MetaTrainer
+    from fake_engine import FakeEngine
+
+    class GuardedFake(FakeEngine):
+        verdict = 'f16x3'
+
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self._mode, self._verify_pending, self._step_check_pending, self.verified_with = 'f16x3', True, True, None
+
+        @property
+        def matrix_mode(self):
+            return self._mode
+
+        def set_engine_matrix_mode(self, mode):
+            self._mode = mode
+
+        def verify_matrix_mode(self, images, masks=None, loss_kind=None):
+            self.verified_with = (images, masks)
+            self._verify_pending = False
+            if GuardedFake.verdict != 'f16x3':
+                self._mode = GuardedFake.verdict
+            return self._mode
+
+        def load_model_state(self, sd, lrs=None):
+            super().load_model_state(sd, lrs)
+            self._verify_pending = True
+
+    sd, lrs = synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50')
+    x, y = torch.zeros(1, 3, 8, 8), torch.zeros(1, 1, 8, 8)
+    for verdict in ('f16x3', 'bf16x6'):
+        GuardedFake.verdict = verdict
+        engines = [GuardedFake('resnet50', 8, 8, 1) for _ in range(3)]
+        mt = MetaTrainer(engines[0], meta_batch_size=3, extra_engines=engines[1:])
+        mt.load_state(sd, lrs)
+        assert mt._mode_check_pending
+        flag = mt._collective_mode_check([(x, y, x, y)])
+        assert flag == (verdict != 'f16x3') and not mt._mode_check_pending
+        assert engines[0].verified_with[0] is x and engines[0].verified_with[1] is y      # the step half needs the masks
+        assert engines[1].verified_with is None                                           # once per trainer, not per engine
+        assert [e.matrix_mode for e in engines] == [verdict] * 3
+        assert not any(e._verify_pending or e._step_check_pending for e in engines)
+    # a rank without a task this iteration still takes part (flag 0) and keeps its engines' own lazy check for its first task
+    GuardedFake.verdict = 'bf16x6'
+    eng = GuardedFake('resnet50', 8, 8, 1)
+    mt = MetaTrainer(eng, meta_batch_size=1)
+    mt.load_state(sd, lrs)
+    assert mt._collective_mode_check([]) == 0 and eng.matrix_mode == 'f16x3' and eng._verify_pending
