@@ -193,6 +193,8 @@ class Engine:
     def get_params(self):
         out = torch.empty(self.n_param, device=self.device)
         _ffi.check(self.lib.eosvos_get_params(self.h, _ptr(out)))
+        if torch.cuda.current_stream(self.device) != self.stream:
+            self.synchronize()            # the export ran on the engine's stream: a caller on another stream must not read it early
         return out
 
     def set_params(self, flat):
@@ -422,6 +424,8 @@ class Engine:
     def get_grads(self):
         out = torch.empty(self.n_param, device=self.device)
         _ffi.check(self.lib.eosvos_get_grads(self.h, _ptr(out)))
+        if torch.cuda.current_stream(self.device) != self.stream:
+            self.synchronize()
         return out
 
     def infer(self, images):

@@ -47,9 +47,11 @@ for tag, tpr in (('one', 1), ('two', 2)):
         # close the SOURCE of the aliased state first on purpose: the library un-aliases the others (they keep a valid copy)
         engines[0].close()
         for e in engines[1:]:
-            e.reset()
-            p = e.get_params()
-            assert bool(torch.isfinite(p).all())
+            with torch.cuda.stream(e.stream):
+                e.reset()
+                p = e.get_params()
+                e.synchronize()
+                assert bool(torch.equal(p, mt.state[mt.n_lr:]))        # its own copy of the learned init the source held
             e.close()
     out[tag] = {'equal': bool(torch.equal(states[0][0], states[1][0])), 'losses': states[0][1], 'losses_ref': states[1][1],
                 'finite': bool(torch.isfinite(states[0][0]).all()), 'moved': states[0][2]}
