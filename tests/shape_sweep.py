@@ -20,7 +20,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 SWEEP = [(1, h, w) for h in (97, 98, 99, 100) for w in range(161, 169)]
-EXTRA = [(2, 130, 182), (3, 101, 167), (1, 480, 853), (1, 480, 855), (1, 480, 910), (1, 479, 853), (1, 481, 857), (1, 65, 97), (2, 64, 64)]
+EXTRA = [(2, 130, 182), (3, 101, 167), (1, 480, 853), (1, 480, 855), (1, 480, 910), (1, 479, 853), (1, 481, 857), (1, 65, 97), (2, 64, 64),
+         (1, 720, 1280)]      # YouTube-VOS frames are fed at their native size (no resize in the reference's data layer)
 FILL = [(1, 97, 163), (1, 99, 165), (1, 98, 164), (3, 101, 167), (2, 130, 182), (1, 480, 853), (1, 480, 855)]
 MODES = ('f16x3', 'bf16x6', 'f32')
 LOGIT_TOL = 1e-3

@@ -454,7 +454,7 @@ def test_shape_polymorphism_sweep_vs_oracle(weights):
 
 
 @pytest.mark.parametrize('shape', [(2, 130, 182), (3, 101, 167), (1, 480, 853), (1, 480, 855), (1, 480, 910), (1, 479, 853), (1, 481, 857), (1, 65, 97),
-                                   (2, 64, 64)], ids=lambda s: 'x'.join(map(str, s)))
+                                   (2, 64, 64), (1, 720, 1280)], ids=lambda s: 'x'.join(map(str, s)))
 def test_shape_polymorphism_vs_oracle(weights, shape):
     """Batches > 1 on odd sizes and the 480-row odd widths around 854 (forward only above 100 000 pixels: the oracle's step
     takes minutes there), in every matrix mode with the guard off."""
