@@ -45,6 +45,8 @@ _SIGNATURES = {
     'eosvos_loss_tensors': (ctypes.c_int, [_E, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int64, c_float_p]),
     'eosvos_warp_affine': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_int, c_float_p, ctypes.POINTER(ctypes.c_int)]),
+    'eosvos_warp_affine_hw': (ctypes.c_int, [_E, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_int, c_float_p, ctypes.POINTER(ctypes.c_int)]),
     'eosvos_set_norm': (ctypes.c_int, [_E, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float]),
     'eosvos_reset': (ctypes.c_int, [_E]),
     'eosvos_get_params': (ctypes.c_int, [_E, c_float_p]),

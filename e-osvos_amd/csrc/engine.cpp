@@ -2216,10 +2216,15 @@ int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t
 // ---- data augmentation on the device (custom_transforms.py:9-92,189-213) --------------------------
 int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int flip, double rot_deg, double scale,
                        int interp, float* dst, int* nonzero_host) {
+  if (!e) return fail("bad argument");
+  return eosvos_warp_affine_hw(e, src, channels, e->H, e->W, flip, rot_deg, scale, interp, dst, nonzero_host);
+}
+int eosvos_warp_affine_hw(eosvos_engine* e, const float* src, int channels, int height, int width, int flip, double rot_deg,
+                          double scale, int interp, float* dst, int* nonzero_host) {
   ModeScope mode_scope(e);
-  if (!e || !src || !dst || channels < 1) return fail("bad argument");
+  if (!e || !src || !dst || channels < 1 || height < 1 || width < 1) return fail("bad argument");
   if (interp != EOSVOS_INTER_NEAREST && interp != EOSVOS_INTER_CUBIC) return fail("unknown interpolation");
-  const int H = e->H, W = e->W;
+  const int H = height, W = width;
   if (!e->aug_tab) {
     e->aug_tab = (int*)e->falloc(4);            // the non-zero counter of label warps
     e->aug_ctab = e->falloc(128);

@@ -23,12 +23,12 @@ INTER_NEAREST, INTER_CUBIC = 0, 2           # include/eosvos.h EOSVOS_INTER_*
 def warp_affine(engine, src, flip, rot, sc, interp, out=None, count_nonzero=False):
     """One flip + scale/rotate warp of a (C,H,W) device tensor; returns (dst, nonzero or None)."""
     assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 3
-    assert src.shape[1] == engine.height and src.shape[2] == engine.width, src.shape
+    # (any frame size: `eosvos_warp_affine_hw` -- the engine lends its stream and coefficient table only)
     dst = torch.empty_like(src) if out is None else out
     cnt = ctypes.c_int(0)
-    _ffi.check(engine.lib.eosvos_warp_affine(engine.h, ctypes.c_void_p(src.data_ptr()), src.shape[0], int(bool(flip)),
-                                             float(rot), float(sc), interp, ctypes.c_void_p(dst.data_ptr()),
-                                             ctypes.byref(cnt) if count_nonzero else None))
+    _ffi.check(engine.lib.eosvos_warp_affine_hw(engine.h, ctypes.c_void_p(src.data_ptr()), src.shape[0], int(src.shape[1]), int(src.shape[2]),
+                                                int(bool(flip)), float(rot), float(sc), interp, ctypes.c_void_p(dst.data_ptr()),
+                                                ctypes.byref(cnt) if count_nonzero else None))
     return dst, (cnt.value if count_nonzero else None)
 
 

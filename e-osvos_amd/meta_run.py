@@ -107,6 +107,8 @@ class MetaTrainer:
         lrs = list(lrs) if isinstance(lrs, (list, tuple)) else [lrs]
         self.state[:self.n_lr] = torch.cat([l.reshape(-1).float() for l in lrs]).to(dev)
         self.state[self.n_lr:] = torch.cat([model_state[n].reshape(-1).float() for n in names]).to(dev)
+        self._model_state = model_state          # (frozen norm statistics + the init of engines built later for other frame sizes)
+        self._drop_pool()
         for e in self.engines:
             with _on_stream(e):
                 e.set_loss(self.loss_func)
@@ -135,8 +137,70 @@ class MetaTrainer:
             off += k
         return out
 
+    # ---- engines for other frame sizes --------------------------------------------------------------
+    # The reference feeds every video at its native size (no resize in its data layer): DAVIS 480p sequences are 854 or 910 wide,
+    # YouTube-VOS is mostly 1280 x 720 -- the tasks of one meta-batch differ in size.  An engine is built for one size, so the
+    # trainer keeps a small pool of engine sets keyed by (H, W); they READ the first engine's learned state (`eosvos_alias_state`)
+    # or are uploaded with it after every outer step, carry the same frozen norm statistics, loss, budget and matrix mode.
+    MAX_POOLED_SIZES = int(os.environ.get('EOSVOS_META_ENGINE_SIZES', '6'))
+
+    def _all_engines(self):
+        return self.engines + [e for es in getattr(self, '_pool', {}).values() for e in es]
+
+    def _drop_pool(self):
+        for es in getattr(self, '_pool', {}).values():
+            for e in es:
+                e.close()
+        self._pool, self._pool_use = {}, []
+
+    def _new_engine(self, height, width):
+        eng = self.eng
+        on_gpu = getattr(eng, 'stream', None) is not None
+        kw = dict(norm=getattr(eng, 'norm', 'bn'))
+        if on_gpu:
+            with torch.cuda.stream(torch.cuda.Stream(eng.device)):
+                e = type(eng)(eng.encoder, height, width, eng.max_batch, str(eng.device), side_stream=False, **kw)
+        else:
+            e = type(eng)(eng.encoder, height, width, eng.max_batch, **kw)
+        with _on_stream(e):
+            if on_gpu:
+                e.stream.wait_stream(eng.stream)
+            e.set_loss(self.loss_func)
+            e.load_model_state(self._model_state)
+            e.set_lr_state(self.level, self.use_log, self.state[:self.n_lr])
+            if self.fused_outer:
+                e.alias_state(eng)
+            elif getattr(e, 'verify_matrix_mode', None) is not None:
+                e.set_init(self.state[self.n_lr:], verify=False)
+            else:
+                e.set_init(self.state[self.n_lr:])
+            if getattr(e, 'verify_matrix_mode', None) is not None:      # one matrix mode per trainer (the first engine's verdict)
+                e.set_engine_matrix_mode(getattr(eng, '_own_mode', None))
+                e._verify_pending = e._step_check_pending = False
+            if hasattr(e, 'set_wg_budget'):
+                e.set_wg_budget(self.wg_budget)
+        return e
+
+    def _engines_for(self, height, width, want):
+        """Up to `want` engines for frames of this size (the trainer's own for its primary size)."""
+        if (height, width) == (self.eng.height, self.eng.width):
+            return self.engines
+        if not hasattr(self, '_pool'):
+            self._pool, self._pool_use = {}, []
+        key = (height, width)
+        es = self._pool.setdefault(key, [])
+        if key in self._pool_use:
+            self._pool_use.remove(key)
+        self._pool_use.append(key)
+        while len(self._pool_use) > self.MAX_POOLED_SIZES:              # least recently used size goes
+            for e in self._pool.pop(self._pool_use.pop(0)):
+                e.close()
+        while len(es) < max(1, min(want, len(self.engines))):
+            es.append(self._new_engine(height, width))
+        return es
+
     def _push_state(self):
-        for k, e in enumerate(self.engines):
+        for k, e in enumerate(self._all_engines()):
             with _on_stream(e):
                 if k and getattr(e, 'stream', None) is not None:
                     e.stream.wait_stream(self.eng.stream)       # the outer step wrote the state on the first engine's stream
@@ -147,7 +211,7 @@ class MetaTrainer:
                     e.set_init(self.state[self.n_lr:])
 
     # ---- one task ---------------------------------------------------------------------
-    def run_task(self, x_train, y_train, x_meta, y_meta, inner_steps=5, bptt_epochs=None, multi_step_bptt_loss=None):
+    def run_task(self, x_train, y_train, x_meta, y_meta, inner_steps=5, bptt_epochs=None, multi_step_bptt_loss=None, eng=None):
         """Returns the (last) meta loss.  Adds the task's meta-gradient into self.grad unless a meta loss is NaN
         (meta_run.py:209-211,226: skipped tasks contribute zeros but the average still divides by
         meta_batch_size).  `bptt_epochs` < inner_steps = truncated BPTT (`:187-221`): every bptt_epochs steps the
@@ -155,7 +219,7 @@ class MetaTrainer:
         state lr (`meta_optim.py:145-151`), so only the first segment leaves gradients on the learned init / lr;
         the later segments are still run (inner steps, meta loss, NaN check) but need no backward here.
         `multi_step_bptt_loss` = per-step weights of the meta loss (`:154-177`)."""
-        eng = self.eng
+        eng = eng or self.eng
         if multi_step_bptt_loss:
             assert inner_steps == len(multi_step_bptt_loss)             # meta_run.py:156
         bptt = bptt_epochs or inner_steps
@@ -194,38 +258,39 @@ class MetaTrainer:
     def _apply_wg_budget(self):
         """(Re)apply the budget: the first engine is the model's and an evaluation in between may have changed it.
         Engines that run side by side also give up their side stream (one queue each: `eosvos_set_side_stream`)."""
-        for e in self.engines:
+        for e in self._all_engines():
             if hasattr(e, 'set_wg_budget'):
                 e.set_wg_budget(self.wg_budget)
             if len(self.engines) > 1 and hasattr(e, 'set_side_stream') and os.environ.get('EOSVOS_INFLIGHT_SIDE_STREAM', '0') != '1':
                 e.set_side_stream(False)
 
-    def run_tasks_concurrent(self, tasks, inner_steps):
+    def run_tasks_concurrent(self, tasks, inner_steps, engines=None):
         """The default schedule (one meta frame after `inner_steps` steps) for several tasks at once, task i on engine
         i % n: every call is enqueued without waiting, one synchronisation at the end.  NaN tasks are skipped as in
         run_task.  Returns the meta losses."""
-        n = len(self.engines)
+        engines = engines or self.engines
+        n = len(engines)
         self._apply_wg_budget()
-        if not hasattr(self, '_task_grads'):
+        if len(getattr(self, '_task_grads', [])) < n:
             self._task_grads = [torch.zeros_like(self.grad) for _ in range(n)]
         losses = []
         for base in range(0, len(tasks), n):
             group = tasks[base:base + n]
             out = []
-            for e, tg, _ in zip(self.engines, self._task_grads, group):
+            for e, tg, _ in zip(engines, self._task_grads, group):
                 with _on_stream(e):
                     if getattr(e, 'stream', None) is not None:
                         e.stream.wait_stream(self.eng.stream)
                     e.meta_task_begin()
                     tg.zero_()
             for _ in range(inner_steps):
-                for e, (xt, yt, _, _) in zip(self.engines, group):
+                for e, (xt, yt, _, _) in zip(engines, group):
                     with _on_stream(e):
                         e.finetune_step(xt, yt, accumulate=True, sync_loss=False)
-            for e, tg, (_, _, xm, ym) in zip(self.engines, self._task_grads, group):
+            for e, tg, (_, _, xm, ym) in zip(engines, self._task_grads, group):
                 with _on_stream(e):
                     out.append(e.meta_grad(xm, ym, tg, init_grad=self.learn_model_init, new_segment=True, sync=False))
-            for e, tg, l in zip(self.engines, self._task_grads, out):
+            for e, tg, l in zip(engines, self._task_grads, out):
                 e.synchronize()
                 l = float(l)
                 if math.isnan(l):
@@ -242,15 +307,21 @@ class MetaTrainer:
         mode -- ranks in different modes would average gradients of slightly different functions.  Every rank takes part in
         the collective whether it has a task or not (all ranks call `meta_iteration` equally often)."""
         self._mode_check_pending = False
-        real = [e for e in self.engines if getattr(e, 'verify_matrix_mode', None) is not None]
+        real = [e for e in self._all_engines() if getattr(e, 'verify_matrix_mode', None) is not None]
         flag, checked = 0, False
         if real and local_tasks and getattr(real[0], '_verify_pending', False):
             from .engine import _guard_enabled
             if _guard_enabled() and real[0].matrix_mode == 'f16x3':
                 xt, yt = local_tasks[0][0], local_tasks[0][1]
-                with _on_stream(real[0]):
-                    flag = int(real[0].verify_matrix_mode(xt, yt) != 'f16x3')
+                ve = self._engines_for(int(xt.shape[-2]), int(xt.shape[-1]), 1)[0]      # (an engine of the first task's frame size)
+                if ve is not self.eng and getattr(ve, 'stream', None) is not None:
+                    ve.stream.wait_stream(self.eng.stream)
+                with _on_stream(ve):
+                    flag = int(ve.verify_matrix_mode(xt, yt) != 'f16x3')
+                    if ve is not self.eng:
+                        ve.synchronize()
                 checked = True
+                real = [e for e in self._all_engines() if getattr(e, 'verify_matrix_mode', None) is not None]
         if self.comm is not None:
             t = torch.tensor([float(flag)], device=self.state.device)
             with _on_stream(self.eng):
@@ -273,20 +344,35 @@ class MetaTrainer:
         if getattr(self, '_mode_check_pending', False):
             self._collective_mode_check(local_tasks)
         default_schedule = not multi_step_bptt_loss and (bptt_epochs or inner_steps) == inner_steps and inner_steps > 0
-        same_size = all(t[0].shape[-2:] == (e.height, e.width) and t[0].shape[0] <= e.max_batch and t[2].shape[0] <= e.max_batch
-                        for t in local_tasks for e in self.engines)
+        for t in local_tasks:
+            if t[0].shape[0] > self.eng.max_batch or t[2].shape[0] > self.eng.max_batch:
+                raise ValueError(f'task batch {t[0].shape[0]} / {t[2].shape[0]} exceeds the engines\' max_batch {self.eng.max_batch}')
         prof = getattr(self, 'profile', None)       # bench.py: {'tasks_ms', 'allreduce_ms', 'outer_step_ms'} summed over calls
         tick = self._tick if prof is not None else (lambda: 0.0)
         t0 = tick()
         self._apply_wg_budget()                     # an evaluation in between may have changed the first engine's budget
-        if len(self.engines) > 1 and len(local_tasks) > 1 and default_schedule and same_size:
-            losses = self.run_tasks_concurrent(local_tasks, inner_steps)
-        else:
-            with _on_stream(self.eng):
-                losses = [self.run_task(*t, inner_steps=inner_steps, bptt_epochs=bptt_epochs,
-                                        multi_step_bptt_loss=multi_step_bptt_loss) for t in local_tasks]
-            if self.state.is_cuda and getattr(self.eng, 'stream', None) is not None:
-                torch.cuda.current_stream(self.state.device).wait_stream(self.eng.stream)
+        # runs of consecutive tasks with one frame size (the usual case: all of them), each on the engines of that size; the tasks'
+        # gradients enter self.grad in task order either way
+        losses, i = [], 0
+        while i < len(local_tasks):
+            hw = tuple(local_tasks[i][0].shape[-2:])
+            j = i
+            while j < len(local_tasks) and tuple(local_tasks[j][0].shape[-2:]) == hw:
+                j += 1
+            run = local_tasks[i:j]
+            engines = self._engines_for(hw[0], hw[1], len(run))
+            if len(engines) > 1 and len(run) > 1 and default_schedule:
+                losses += self.run_tasks_concurrent(run, inner_steps, engines)
+            else:
+                e0 = engines[0]
+                if e0 is not self.eng and getattr(e0, 'stream', None) is not None:
+                    e0.stream.wait_stream(self.eng.stream)                  # the learned state was written on the first engine's stream
+                with _on_stream(e0):
+                    losses += [self.run_task(*t, inner_steps=inner_steps, bptt_epochs=bptt_epochs,
+                                             multi_step_bptt_loss=multi_step_bptt_loss, eng=e0) for t in run]
+                if self.state.is_cuda and getattr(e0, 'stream', None) is not None:
+                    torch.cuda.current_stream(self.state.device).wait_stream(e0.stream)
+            i = j
         t1 = tick()
         if self.comm is not None:
             # the library's own collective, on the first engine's stream (ordered after the tasks: the streams were joined above)
@@ -313,7 +399,7 @@ class MetaTrainer:
     def _tick(self):
         """Wall clock after everything queued so far has finished (profiling passes only: it drains the GPU)."""
         import time
-        for e in self.engines:
+        for e in self._all_engines():
             e.synchronize()
         if self.state.is_cuda:
             torch.cuda.synchronize(self.state.device)

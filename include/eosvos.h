@@ -223,6 +223,11 @@ int eosvos_merge_labels(eosvos_engine* e, const float* probs, int n_obj, int64_t
 #define EOSVOS_INTER_CUBIC 2
 int eosvos_warp_affine(eosvos_engine* e, const float* src, int channels, int flip, double rot_deg,
                        double scale, int interp, float* dst, int* nonzero_host);
+/* The same warp for a frame of any size (round 5): the videos of a meta-batch reach the network at their native sizes (no resize
+ * in the reference's data layer), so the augmentation of a task's frames cannot be tied to one engine's frame size.  `e` lends
+ * its stream and coefficient table only. */
+int eosvos_warp_affine_hw(eosvos_engine* e, const float* src, int channels, int height, int width, int flip, double rot_deg,
+                          double scale, int interp, float* dst, int* nonzero_host);
 
 /* ---- learning-rate hierarchy (meta_optim.py:27-67) ------------------------------------ */
 /* `lr_hierarchy_level`: how the learned lr state is stored.  NEURON (cfgs/meta.yaml:36) one

@@ -124,6 +124,32 @@ def test_warp_affine_vs_restatement(size):
 
 
 @pytest.mark.gpu
+def test_warp_affine_of_a_frame_whose_size_is_not_the_engines():
+    """`eosvos_warp_affine_hw` (round 5): the tasks of a meta-batch come at their videos' native sizes, so a frame is warped at ITS
+    size whatever size the engine was built for -- equal to the restatement, and bit-identical to the warp through an engine of that
+    size."""
+    from eosvos_amd.custom_transforms import INTER_CUBIC, INTER_NEAREST, warp_affine
+    from eosvos_amd.engine import Engine
+    H, W = 97, 163
+    other = Engine('resnet50', *SMALL, max_batch=1, device=DEV)
+    own = Engine('resnet50', H, W, max_batch=1, device=DEV)
+    img, gt = _smooth_image(H, W), _label(H, W)
+    timg = torch.from_numpy(img).permute(2, 0, 1).contiguous().to(DEV)
+    tgt = torch.from_numpy(gt)[None].contiguous().to(DEV)
+    for flip, rot, sc in [(0, 14.5, 1.15), (1, -29.0, 0.76)]:
+        src_i = img[:, ::-1].copy() if flip else img
+        src_g = gt[:, ::-1].copy() if flip else gt
+        lab, nz = warp_affine(other, tgt, flip, rot, sc, INTER_NEAREST, count_nonzero=True)
+        ref_g = augment.rot_and_sc(src_g, rot, sc, True)
+        assert np.array_equal(lab[0].cpu().numpy(), ref_g) and nz == int((ref_g != 0).sum())
+        out, _ = warp_affine(other, timg, flip, rot, sc, INTER_CUBIC)
+        assert np.abs(out.permute(1, 2, 0).cpu().numpy() - augment.rot_and_sc(src_i, rot, sc, False)).max() <= 2e-6
+        assert torch.equal(out, warp_affine(own, timg, flip, rot, sc, INTER_CUBIC)[0])
+    other.close()
+    own.close()
+
+
+@pytest.mark.gpu
 def test_first_frame_augmenter_matches_reference_sequence():
     from eosvos_amd.custom_transforms import FirstFrameAugmenter
     from eosvos_amd.engine import Engine

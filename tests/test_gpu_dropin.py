@@ -243,10 +243,13 @@ def test_train_meta_entry_points(tmp_path):
     assert mt.step == 1
 
 
-def test_train_meta_on_dataset_files(tmp_path, capsys):
+@pytest.mark.parametrize('camel_size', [(96, 160), (80, 128)], ids=['one_size', 'two_sizes'])
+def test_train_meta_on_dataset_files(tmp_path, capsys, camel_size):
     """`train_meta.main` in meta-train mode on a DAVIS-2017 tree on disk: `MetaTaskset` sampling, the one-iteration-ahead
     prefetch of decoding + colour jitter on a worker thread, device-side flip / scale-rotate, three meta-iterations of two
-    tasks in flight."""
+    tasks in flight.  `two_sizes`: the second video has another frame size than the trainer's engines (the reference feeds
+    videos at their native sizes): its tasks run on pooled engines of that size (`MetaTrainer._engines_for`) and their frames
+    are warped at their own size (`eosvos_warp_affine_hw`)."""
     import json
     from PIL import Image
     from eosvos_amd import train_meta
@@ -255,12 +258,13 @@ def test_train_meta_on_dataset_files(tmp_path, capsys):
     for seq in ('bear', 'camel'):
         (root / 'JPEGImages' / '480p' / seq).mkdir(parents=True)
         (root / 'Annotations' / '480p' / seq).mkdir(parents=True)
+        hh, ww = camel_size if seq == 'camel' else (96, 160)
         for f in range(5):
-            Image.fromarray(rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)).save(root / 'JPEGImages' / '480p' / seq / f'{f:05d}.jpg')
-            lab = np.zeros((96, 160), np.uint8)
+            Image.fromarray(rng.integers(0, 256, (hh, ww, 3), dtype=np.uint8)).save(root / 'JPEGImages' / '480p' / seq / f'{f:05d}.jpg')
+            lab = np.zeros((hh, ww), np.uint8)
             lab[30:60, 50 + 3 * f:100 + 3 * f] = 1
             if seq == 'camel':
-                lab[70:90, 20:60] = 2
+                lab[65:78, 20:60] = 2
             Image.fromarray(lab, mode='L').save(root / 'Annotations' / '480p' / seq / f'{f:05d}.png')
     (root / 'train_seqs.txt').write_text('bear\ncamel\n')
     capsys.readouterr()
@@ -273,6 +277,8 @@ def test_train_meta_on_dataset_files(tmp_path, capsys):
     assert [len(l['meta_losses']) for l in lines] == [2, 1, 2], lines
     assert all(np.isfinite(v) for l in lines for v in l['meta_losses'])
     assert mt.step == 3 and mt.skipped_tasks == 0 and len(mt.engines) == 2
+    assert sorted(mt._pool) == ([] if camel_size == (96, 160) else [camel_size])
+    mt._drop_pool()
 
 
 @pytest.mark.parametrize('level,use_log', [('TENSOR', True), ('SINGLE', False)])
@@ -485,3 +491,41 @@ def test_cli_loads_the_parent_checkpoint_into_the_engine(tmp_path, capsys):
     assert torch.allclose(a, ref_a, rtol=1e-6, atol=1e-7) and torch.allclose(b, ref_b, rtol=1e-5, atol=1e-6)
     syn = synthetic.synthetic_state('resnet50')
     assert not torch.allclose(a, syn['backbone.bn1.weight'] / torch.sqrt(syn['backbone.bn1.running_var'] + 1e-5), rtol=1e-3)
+
+
+def test_meta_batch_with_two_frame_sizes_does_not_depend_on_which_size_is_primary():
+    """The reference feeds every video at its native size (no resize in its data layer; DAVIS 480p is 854 or 910 wide, YouTube-VOS
+    mostly 1280 x 720), so the tasks of one meta-batch differ in frame size.  `MetaTrainer` keeps a pool of engines per (H, W) that
+    read the first engine's learned state: three tasks of two sizes through a trainer whose own engines have the first size, and
+    through one whose engines have the second -- meta losses, the accumulated meta-gradient and the state after two outer steps are
+    bit-identical, with one engine per size and with two in flight."""
+    from eosvos_amd import synthetic
+    from eosvos_amd.engine import Engine
+    from eosvos_amd.meta_run import MetaTrainer
+    sd, lrs = synthetic.synthetic_state('resnet50'), synthetic.synthetic_lrs('resnet50')
+    sizes = [(96, 160), (97, 163)]
+    tasks = []
+    for t, hw in enumerate([sizes[0], sizes[1], sizes[1]]):
+        x, y = synthetic.synthetic_frames(1, *hw, seed=3000 + t)
+        x, y = x.to(DEV), y.to(DEV)
+        tasks.append((x, y, torch.flip(x, dims=[3]).contiguous(), torch.flip(y, dims=[3]).contiguous()))
+    for n_engines in (1, 2):
+        out = []
+        for primary in sizes:
+            engines = []
+            for _ in range(n_engines):
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    engines.append(Engine('resnet50', *primary, max_batch=1, device=DEV, side_stream=False))
+            mt = MetaTrainer(engines[0], meta_batch_size=3, extra_engines=engines[1:])
+            mt.load_state(sd, lrs)
+            losses = [mt.meta_iteration(tasks, inner_steps=2) for _ in range(2)]
+            torch.cuda.synchronize()
+            pooled = {k: len(v) for k, v in mt._pool.items()}
+            assert list(pooled) == [s for s in sizes if s != primary] and all(v <= n_engines for v in pooled.values()), pooled
+            out.append((losses, mt.state.clone().cpu(), mt.exp_avg.clone().cpu()))
+            mt._drop_pool()
+            for e in reversed(engines):
+                e.close()
+        assert out[0][0] == out[1][0], (n_engines, out[0][0], out[1][0])
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2]), n_engines
+        assert all(np.isfinite(v) for it in out[0][0] for v in it)
