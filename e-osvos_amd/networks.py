@@ -193,9 +193,19 @@ class DeepLabV3Plus:
                                            'size max_batch for the adaptation batches up front')
                 if e.steps_since_reset > 0 and not self._dirty:
                     carry = e.get_params()
-                e.close()
-            self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm,
-                                 **({} if getattr(self, 'side_stream', True) else {'side_stream': False}))
+                self._park_engine(e)
+            want_side = getattr(self, 'side_stream', True)
+            parked = self.__dict__.setdefault('_engine_cache', {}).pop((height, width), None)
+            if parked is not None and (parked.max_batch < max(batch, self.max_batch) or getattr(parked, '_built_with_side', True) != want_side):
+                parked.close()
+                parked = None
+            if parked is not None:           # the engine this model used for that frame size before (state re-uploaded below)
+                self.engine = parked
+                parked.steps_since_reset, parked.has_snapshot, parked.in_meta_task = 0, False, False
+            else:
+                self.engine = Engine(self.encoder, height, width, max(batch, self.max_batch), str(self.device), norm=self.norm,
+                                     **({} if want_side else {'side_stream': False}))
+                self.engine._built_with_side = want_side
             if getattr(self, 'wg_budget', 0) and hasattr(self.engine, 'set_wg_budget'):
                 self.engine.set_wg_budget(self.wg_budget)
             if not getattr(self, 'side_stream', True) and hasattr(self.engine, 'set_side_stream'):
@@ -214,6 +224,28 @@ class DeepLabV3Plus:
                 self.engine.in_meta_task = False
             self._pending_task_begin = self._pending_task_eval = False
         return self.engine
+
+    ENGINE_CACHE = 2        # engines of other frame sizes kept for the next sequence of that size (creation costs ~0.5 s, 4-17 GB each)
+
+    def _park_engine(self, e):
+        """Videos come at their native sizes (854 / 910 x 480, 1280 x 720 ...): the engine of the size just left is kept, the least
+        recently parked one beyond ENGINE_CACHE is closed."""
+        cache = self.__dict__.setdefault('_engine_cache', {})
+        old = cache.pop((e.height, e.width), None)
+        if old is not None and old is not e:
+            old.close()
+        cache[(e.height, e.width)] = e
+        while len(cache) > self.ENGINE_CACHE:
+            cache.pop(next(iter(cache))).close()
+
+    def close_engines(self):
+        for e in self.__dict__.get('_engine_cache', {}).values():
+            e.close()
+        self.__dict__['_engine_cache'] = {}
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+            self._dirty = True
 
     def push_state(self):
         """Upload init weights / norm statistics (/ learning rates) to the engine; theta <- init."""

@@ -529,3 +529,36 @@ def test_meta_batch_with_two_frame_sizes_does_not_depend_on_which_size_is_primar
         assert out[0][0] == out[1][0], (n_engines, out[0][0], out[1][0])
         assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2]), n_engines
         assert all(np.isfinite(v) for it in out[0][0] for v in it)
+
+
+def test_model_keeps_the_engine_of_the_frame_size_it_just_left(model_and_optim):
+    """Videos come at their native sizes; building an engine costs ~0.5 s (`tools/engine_create_time.py`).  The model parks the
+    engine of the size it leaves (`DeepLabV3Plus._park_engine`, 2 kept) and takes it back for the next sequence of that size --
+    with the learned state re-uploaded: the same logits bit for bit, also after a fine-tune step in between on the other size."""
+    from eosvos_amd.helper_func import compute_loss
+    model, mo, msd = model_and_optim
+    mo.load_state_dict(msd)
+    mo.reset()
+    mo.eval()
+    model.train_without_dropout()
+    xa, ya = synthetic.synthetic_frames(1, 96, 160, seed=61)
+    xb, yb = synthetic.synthetic_frames(1, 80, 128, seed=62)
+    xa, ya, xb, yb = xa.to(DEV), ya.to(DEV), xb.to(DEV), yb.to(DEV)
+    la = model(xa)[-1].clone()
+    ea = model.engine
+    lb = model(xb)[-1].clone()
+    eb = model.engine
+    assert eb is not ea and model._engine_cache.get((96, 160)) is ea
+    assert torch.equal(model(xa)[-1], la) and model.engine is ea and model._engine_cache.get((80, 128)) is eb
+    assert torch.equal(model(xb)[-1], lb) and model.engine is eb
+    # a step on one size travels to the other size's engine (the fine-tuned weights are carried, networks._ensure_engine)
+    out = model(xb)
+    loss = compute_loss('cross_entropy', out[-1], yb)
+    model.zero_grad()
+    mo.set_train_loss(loss)
+    mo.step(loss)
+    l2 = model(xa)[-1].clone()
+    assert model.engine is ea and not torch.equal(l2, la)
+    mo.reset()                                     # theta <- learned init: both sizes back at the first logits
+    assert torch.equal(model(xa)[-1], la) and torch.equal(model(xb)[-1], lb)
+    model.close_engines()
