@@ -142,4 +142,13 @@ def parse_cli(argv):
             raise KeyError(f'unknown named config: {a}')
     for k, v in updates:
         _set_dotted(cfg, k, v)
+    unsupported(cfg)
     return cfg
+
+
+def unsupported(cfg):
+    """Options of cfgs/meta.yaml this build accepts as keys but does not implement must not be ignored silently."""
+    crops = (cfg.get('data_cfg') or {}).get('crop_sizes') or {}
+    if any(v is not None for v in crops.values()):
+        raise NotImplementedError('data_cfg.crop_sizes (pad + random crop of every frame, data/vos_dataset.py:246-275) is not implemented: '
+                                  'frames are fed at their native size')

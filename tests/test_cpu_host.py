@@ -321,3 +321,11 @@ def test_collective_matrix_mode_verdict_reaches_every_engine(monkeypatch):
     mt = MetaTrainer(eng, meta_batch_size=1)
     mt.load_state(sd, lrs)
     assert mt._collective_mode_check([]) == 0 and eng.matrix_mode == 'f16x3' and eng._verify_pending
+
+
+def test_unimplemented_options_raise_instead_of_being_ignored():
+    """Keys of cfgs/meta.yaml are all accepted (fixture G16); the ones this build does not implement must raise."""
+    from eosvos_amd import config
+    config.parse_cli(['with', 'DAVIS-2017', 'e-OSVOS'])
+    with pytest.raises(NotImplementedError):
+        config.parse_cli(['with', 'DAVIS-2017', 'data_cfg.crop_sizes.train=[256, 256]'])
