@@ -159,6 +159,9 @@ class DeepLabV3Plus:
     def copy_state_from(self, other):
         """Take `other`'s learned init and frozen norm statistics (a spawned worker re-synchronised with its parent after
         the parent loaded another checkpoint: `evaluate_dataset` per dataset key, reference `evaluate.py:46-50`)."""
+        if (self._flat.shape == other._flat.shape and torch.equal(self._flat, other._flat.to(self._flat.device)) and
+                list(self._norm) == list(other._norm) and all(torch.equal(v, other._norm[k].to(v.device)) for k, v in self._norm.items())):
+            return                          # nothing changed since the last copy: no re-upload, no new range-guard run
         self._flat.copy_(other._flat)
         self._norm = OrderedDict((k, v.clone()) for k, v in other._norm.items())
         self._dirty = True
